@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- MMFS ms_deform_attn forward+backward throughput on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N = 1: plain process.  N > 1: launched by torch.distributed.run, one rank per GPU
+  (RCCL).  W untimed warm-up steps, then exactly K timed steps bracketed by
+  barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE
+  JSON line.
+
+Workload (BASELINE.json configs[1] / north_star synthetic tensors, SURVEY.md 8d
+"Config 2"):  per GPU  B=8, Nq=4096, n_levels=4 (64^2,32^2,16^2,8^2 -> S=5440), n_heads=8,
+n_points=4, C=1024 (D=128), bf16 storage / fp32 arithmetic, synthetic inputs in the
+reference's test distribution, already resident in HBM.  One step = one forward +
+one backward of the op through the drop-in boundary (MSDeformAttnFunction ->
+MultiScaleDeformableAttention shim -> C ABI -> gfx950 kernels), including the
+zero-fill and the fp32->bf16 cast of grad_value that belong to the op.
+
+Multi-GPU: the path shards on the batch axis with no data-path collective
+(SURVEY.md 8e); every rank processes its own B samples -> "scaling": "weak";
+value = N * B * K / t_max.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel's algorithmic bytes per launch / its mean duration (HIP
+               events recorded on the launch stream inside the timed region) vs 8 TB/s
+  cpu_baseline the oracle's restatement of the reference's only CPU path
+               (ms_deform_attn_core_pytorch) timed on this host, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mm-interleaved_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # name: (B, Nq, H, D, P, per-image level shapes, n_images, dtype)
+    "cfg2_northstar": dict(B=8, Nq=4096, H=8, D=128, P=4,
+                           shapes=[(64, 64), (32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
+    "cfg1": dict(B=2, Nq=1024, H=8, D=32, P=4,
+                 shapes=[(64, 64), (32, 32), (16, 16), (8, 8)], n=1, dtype="f32"),
+    "cfg2_sd_real": dict(B=8, Nq=4096, H=16, D=64, P=8,
+                         shapes=[(64, 64), (32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
+    "cfg5_llm_n4": dict(B=4, Nq=2048, H=16, D=64, P=8,
+                        shapes=[(32, 32), (16, 16), (8, 8)], n=4, dtype="bf16"),
+}
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def algorithmic_bytes(w, e):
+    """compulsory traffic, every distinct tensor element touched once."""
+    B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
+    Leff = len(w["shapes"]) * w["n"]
+    S = sum(h * ww for h, ww in w["shapes"]) * w["n"]
+    C = H * D
+    pts = B * Nq * H * Leff * P
+    fwd = e * (B * S * C + 3 * pts + B * Nq * C)
+    bwd = e * (2 * B * S * C + 6 * pts + B * Nq * C)
+    return dict(msda_fwd=fwd, msda_bwd=bwd, fwdbwd=fwd + bwd)
+
+
+def make_inputs(w, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    dt = DTYPES[w["dtype"]]
+    shapes = torch.tensor(w["shapes"] * w["n"], dtype=torch.long, device=device)
+    start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
+    S, L = int(shapes.prod(1).sum()), shapes.shape[0]
+    value = torch.rand(B, S, H, D, device=device, generator=g).to(dt)
+    loc = torch.rand(B, Nq, H, L, P, 2, device=device, generator=g).to(dt)
+    attn = torch.rand(B, Nq, H, L, P, device=device, generator=g) + 1e-5
+    attn = (attn / attn.sum((-1, -2), keepdim=True)).to(dt)
+    grad = torch.randn(B, Nq, H * D, device=device, generator=g).to(dt)
+    return value, shapes, start, loc, attn, grad
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """Times oracle/msda_torch.py (restatement of the reference's CPU path) on a bounded
+    sample of the same workload: ONE batch element, fp32 on storage-rounded inputs."""
+    from oracle import msda_torch
+    g = torch.Generator().manual_seed(0)
+    dt = DTYPES[w["dtype"]]
+    shapes = w["shapes"] * w["n"]
+    B, Nq, H, D, P = 1, w["Nq"], w["H"], w["D"], w["P"]
+    S, L = sum(h * ww for h, ww in shapes), len(shapes)
+    rt = lambda t: t.to(dt).float()
+    value = rt(torch.rand(B, S, H, D, generator=g))
+    loc = rt(torch.rand(B, Nq, H, L, P, 2, generator=g))
+    attn = torch.rand(B, Nq, H, L, P, generator=g) + 1e-5
+    attn = rt(attn / attn.sum((-1, -2), keepdim=True))
+    grad = rt(torch.randn(B, Nq, H * D, generator=g))
+    msda_torch.fwd_bwd(value, shapes, loc, attn, grad)            # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        msda_torch.fwd_bwd(value, shapes, loc, attn, grad)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 10:
+            break
+    return {"value": round(B * iters / el, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/msda_torch.py (ms_deform_attn_core_pytorch restated), fp32, B=1 slice of the "
+                      f"workload (Nq={Nq}), {iters} fwd+bwd iterations in {el:.1f}s on "
+                      f"{os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2_northstar", choices=sorted(WORKLOADS))
+    ap.add_argument("--nq", type=int, default=None, help="override Nq (parity/sweep use)")
+    ap.add_argument("--dtype", default=None, choices=sorted(DTYPES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.functions import MSDeformAttnFunction
+
+    w = dict(WORKLOADS[args.workload])
+    if args.nq:
+        w["Nq"] = args.nq
+    if args.dtype:
+        w["dtype"] = args.dtype
+    value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank)
+    value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
+
+    def step():
+        out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
+        return torch.autograd.grad(out, (value, loc, attn), grad)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    MSDA._event_log = []                       # per-kernel HIP events on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    log, MSDA._event_log = MSDA._event_log, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        e = torch.empty((), dtype=DTYPES[w["dtype"]]).element_size()
+        ab = algorithmic_bytes(w, e)
+        per_kernel = {}
+        for name, a, b in log:
+            per_kernel.setdefault(name, []).append(a.elapsed_time(b))     # ms
+        mean_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+        dom = max((k for k in mean_ms if k in ab), key=lambda k: mean_ms[k])
+        achieved = ab[dom] / (mean_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")          # from a separate --pmc run
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        Leff = len(w["shapes"]) * w["n"]
+        res = {
+            "metric": "mmfs_ms_deform_attn_fwd_bwd_samples_per_sec",
+            "value": round(world * w["B"] * args.steps / elapsed, 2),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": w["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: ms_deform_attn fwd+bwd, per-GPU B={w['B']} Nq={w['Nq']} "
+                                   f"L={Leff} H={w['H']} P={w['P']} C={w['H'] * w['D']} S={sum(h * x for h, x in w['shapes']) * w['n']}",
+                       "global_batch": world * w["B"], "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes": ab[dom], "mean_us": round(mean_ms[dom] * 1e3, 2)},
+            "kernels_mean_us": {k: round(v * 1e3, 2) for k, v in mean_ms.items()},
+            "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+/*
+ * include/mmfs_msda.h -- C ABI of libmmfs_msda.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the one hot path this repository replaces in
+ * OpenGVLab/MM-Interleaved: the native extension ``MultiScaleDeformableAttention``
+ * behind the Multi-modal Feature Synchronizer (MMFS).  The reference binds that
+ * extension with pybind11 (two functions); each entry point below names the
+ * reference interface it replaces.  The Python shim that adapts torch tensors to
+ * these raw pointers is mm-interleaved_amd/MultiScaleDeformableAttention.py; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP) unless stated otherwise;
+ *   - all tensors are contiguous, row-major, in the layouts of the reference op:
+ *       value   [B, S, H, D]          S = sum_l Hl*Wl over all L levels
+ *       shapes  [L, 2]  int64 (Hl, Wl)        (device memory, as in the reference,
+ *       start   [L]     int64                  ms_deform_attn_cuda.cu:68-69)
+ *       loc     [B, Nq, H, L, P, 2]   (x, y) normalised to [0, 1]
+ *       attn    [B, Nq, H, L, P]
+ *       out     [B, Nq, H*D]
+ *   - ``dtype`` selects the storage type of value/loc/attn/out/grad_out; arithmetic
+ *     is fp32 for 16-bit storage (the reference's opmath, ms_deform_im2col_cuda.cuh:32);
+ *   - ``stream`` is a hipStream_t (NULL = the null stream).  Launches are
+ *     asynchronous; the library keeps no state, allocates and frees nothing, and is
+ *     re-entrant from any host thread (autograd engine threads, checkpoint re-runs);
+ *   - return value: 0 on success; < 0 argument error (MMFS_E_*); > 0 a hipError_t
+ *     from the launch.  Unlike the reference, launch errors are returned, not
+ *     printed (ms_deform_im2col_cuda.cuh:951-955).
+ */
+#ifndef MMFS_MSDA_H_
+#define MMFS_MSDA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMFS_MSDA_ABI_VERSION 1
+
+enum mmfs_dtype {
+    MMFS_F32  = 0,
+    MMFS_F16  = 1,
+    MMFS_BF16 = 2,   /* new capability: the reference has no bf16 (ms_deform_attn_cuda.cu:65) */
+    MMFS_F64  = 3
+};
+
+enum mmfs_status {
+    MMFS_OK          = 0,
+    MMFS_E_DTYPE     = -1,   /* unknown dtype code */
+    MMFS_E_DIMS      = -2,   /* negative dim or a product that overflows the kernel's index range */
+    MMFS_E_NULLPTR   = -3,   /* required pointer is NULL while the tensor is non-empty */
+    MMFS_E_ALIGN     = -4,   /* tensor base not aligned to its element size */
+    MMFS_E_UNSUPPORTED = -5
+};
+
+/* ABI version of the loaded library (== MMFS_MSDA_ABI_VERSION at build time). */
+int mmfs_msda_abi_version(void);
+
+/* Static description of the build, e.g. "gfx950 hipcc <ver>".  Host string. */
+const char *mmfs_msda_build_info(void);
+
+/* Text for a status returned by any entry point.  Host string, never NULL. */
+const char *mmfs_msda_status_string(int status);
+
+/*
+ * Forward.  Replaces ``ms_deform_attn_forward`` of the reference extension
+ *   mm_interleaved/models/utils/ops/src/vision.cpp:14
+ *   -> src/ms_deform_attn.h:20-39 -> src/cuda/ms_deform_attn_cuda.cu:21-81
+ *   -> kernel src/cuda/ms_deform_im2col_cuda.cuh:240-302.
+ * Writes every element of ``out`` (no pre-zeroing needed).  One launch covers the
+ * whole batch; ``im2col_step`` of the reference has no effect on results and is
+ * not part of this ABI.
+ */
+int mmfs_msda_forward(int dtype,
+                      const void *value, const int64_t *shapes, const int64_t *start,
+                      const void *loc, const void *attn, void *out,
+                      int64_t B, int64_t S, int64_t H, int64_t D,
+                      int64_t L, int64_t Nq, int64_t P, void *stream);
+
+/*
+ * Backward.  Replaces ``ms_deform_attn_backward`` of the reference extension
+ *   src/vision.cpp:15 -> src/ms_deform_attn.h:42-61
+ *   -> src/cuda/ms_deform_attn_cuda.cu:84-166
+ *   -> kernels src/cuda/ms_deform_im2col_cuda.cuh:304-923.
+ *
+ *   grad_out        [B, Nq, H*D]          storage dtype
+ *   grad_value_acc  [B, S, H, D]          fp32 (fp64 for MMFS_F64), MUST be zero-filled
+ *                                         by the caller (the reference zero-fills with
+ *                                         at::zeros, .cu:127); accumulated with hardware
+ *                                         float atomics, exactly the reference's
+ *                                         "accumulate in fp32, cast at the end" (.cu:122-165)
+ *   grad_loc        [B, Nq, H, L, P, 2]   storage dtype, fully overwritten
+ *   grad_attn       [B, Nq, H, L, P]      storage dtype, fully overwritten
+ *
+ * For MMFS_F32 / MMFS_F64 ``grad_value_acc`` IS the final grad_value.  For 16-bit
+ * storage the caller converts it with mmfs_msda_cast_from_f32().
+ */
+int mmfs_msda_backward(int dtype,
+                       const void *value, const int64_t *shapes, const int64_t *start,
+                       const void *loc, const void *attn, const void *grad_out,
+                       void *grad_value_acc, void *grad_loc, void *grad_attn,
+                       int64_t B, int64_t S, int64_t H, int64_t D,
+                       int64_t L, int64_t Nq, int64_t P, void *stream);
+
+/*
+ * dst[i] = (dtype) src[i], round-to-nearest-even.  Replaces the trailing
+ * ``grad_value.to(torch::kHalf)`` of the reference backward (ms_deform_attn_cuda.cu:156-165).
+ * ``dtype`` must be MMFS_F16 or MMFS_BF16 (MMFS_F32 copies).
+ */
+int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMFS_MSDA_H_ */

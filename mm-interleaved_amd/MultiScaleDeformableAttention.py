@@ -1,0 +1,212 @@
+"""Drop-in for the reference's native extension module ``MultiScaleDeformableAttention``.
+
+The reference imports it as ``import MultiScaleDeformableAttention as MSDA`` in
+  mm_interleaved/models/utils/ops/functions/ms_deform_attn_func.py:18-21
+  mm_interleaved/models/encoders/vit_adapter/ops/functions/ms_deform_attn_func.py:19-22
+and calls exactly two functions, exported by its pybind module
+(mm_interleaved/models/utils/ops/src/vision.cpp:13-16):
+
+    ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+                           sampling_loc, attn_weight, im2col_step) -> Tensor[B, Nq, H*D]
+    ms_deform_attn_backward(value, spatial_shapes, level_start_index,
+                            sampling_loc, attn_weight, grad_output, im2col_step)
+        -> [grad_value, grad_sampling_loc, grad_attn_weight]
+
+Putting this directory on ``sys.path`` makes that import resolve here; the two
+functions keep the reference's argument order, preconditions and error
+behaviour (ms_deform_attn_cuda.cu:29-53, 94-118) and run the hand-written gfx950
+kernels of ``libmmfs_msda.so`` through its C ABI (include/mmfs_msda.h) with ctypes.
+
+There is NO CPU or PyTorch fallback: CPU tensors raise, exactly as the reference
+does (src/ms_deform_attn.h:29-38: "Not implemented on the CPU"), and a missing
+shared library raises at import time.
+"""
+import ctypes
+import os
+
+import torch
+
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "library_path", "build_info"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("MMFS_MSDA_LIB", os.path.join(_HERE, "libmmfs_msda.so"))
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"MultiScaleDeformableAttention: {_LIB_PATH} not found. Build it with "
+        f"`make -C {os.path.join(_HERE, 'csrc')}` (hipcc, gfx950); there is no fallback path.")
+
+_lib = ctypes.CDLL(_LIB_PATH)
+
+_ABI_VERSION = 1
+_i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+
+_lib.mmfs_msda_abi_version.restype = _int
+_lib.mmfs_msda_abi_version.argtypes = []
+_lib.mmfs_msda_build_info.restype = ctypes.c_char_p
+_lib.mmfs_msda_build_info.argtypes = []
+_lib.mmfs_msda_status_string.restype = ctypes.c_char_p
+_lib.mmfs_msda_status_string.argtypes = [_int]
+_lib.mmfs_msda_forward.restype = _int
+_lib.mmfs_msda_forward.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_backward.restype = _int
+_lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 9 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_cast_from_f32.restype = _int
+_lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
+
+if _lib.mmfs_msda_abi_version() != _ABI_VERSION:
+    raise ImportError(f"{_LIB_PATH}: ABI version {_lib.mmfs_msda_abi_version()} != {_ABI_VERSION}")
+
+# enum mmfs_dtype (include/mmfs_msda.h)
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build_info():
+    return _lib.mmfs_msda_build_info().decode()
+
+
+def _check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what}: {_lib.mmfs_msda_status_string(status).decode()} (status {status})")
+
+
+def _require(cond, msg):
+    # AT_ASSERTM in the reference raises a RuntimeError
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _validate(named, value):
+    for name, t in named:
+        _require(isinstance(t, torch.Tensor), f"{name} must be a tensor")
+        _require(t.is_contiguous(), f"{name} tensor has to be contiguous")
+        # PyTorch-ROCm exposes HIP devices under the "cuda" device type
+        _require(t.is_cuda, f"{name} must be a CUDA tensor")   # reference wording, .cu:35-39
+        _require(t.device == value.device, f"{name} must be on the same device as value")
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    _require(value.dim() == 4, "value must be [B, S, H, D]")
+    B, S, H, D = value.shape
+    _require(spatial_shapes.dim() == 2 and spatial_shapes.shape[1] == 2, "spatial_shapes must be [L, 2]")
+    L = spatial_shapes.shape[0]
+    _require(sampling_loc.dim() == 6, "sampling_loc must be [B, Nq, H, L, P, 2]")
+    Nq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    _require(tuple(sampling_loc.shape) == (B, Nq, H, L, P, 2),
+             f"sampling_loc shape {tuple(sampling_loc.shape)} != {(B, Nq, H, L, P, 2)}")
+    _require(tuple(attn_weight.shape) == (B, Nq, H, L, P),
+             f"attn_weight shape {tuple(attn_weight.shape)} != {(B, Nq, H, L, P)}")
+    _require(level_start_index.numel() == L, "level_start_index must have one entry per level")
+    _require(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
+             "spatial_shapes and level_start_index must be int64 (reference reads data<int64_t>)")
+    return B, S, H, D, L, Nq, P
+
+
+def _same_dtype(value, sampling_loc, attn_weight):
+    """The reference reads all three through one scalar_t (.cu:67-73).  softmax under
+    autocast may hand an fp32 attn_weight next to fp16 values; cast instead of reading
+    garbage (SURVEY.md section 8a "Dtype flow")."""
+    _require(value.dtype in _DTYPE_CODE, f"unsupported dtype {value.dtype}")
+    if sampling_loc.dtype != value.dtype:
+        sampling_loc = sampling_loc.to(value.dtype)
+    if attn_weight.dtype != value.dtype:
+        attn_weight = attn_weight.to(value.dtype)
+    return sampling_loc, attn_weight
+
+
+def _aligned(t, nbytes=16):
+    return t if t.data_ptr() % nbytes == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# bench.py sets this to a list to time individual kernels with HIP events recorded on
+# the very stream the kernel is launched on: entries are (kernel_name, start, end).
+_event_log = None
+
+
+def _launch(name, device, fn, *args):
+    if _event_log is None:
+        return fn(*args)
+    st = torch.cuda.current_stream(device)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(st)
+    status = fn(*args)
+    t1.record(st)
+    _event_log.append((name, t0, t1))
+    return status
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """Reference: ms_deform_attn_cuda_forward, src/cuda/ms_deform_attn_cuda.cu:21-81."""
+    _require(isinstance(value, torch.Tensor) and value.is_cuda, "Not implemented on the CPU")
+    _validate([("value", value), ("spatial_shapes", spatial_shapes),
+               ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+               ("attn_weight", attn_weight)], value)
+    B, S, H, D, L, Nq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    step = min(B, int(im2col_step)) if B > 0 else 1
+    _require(step > 0 and B % step == 0, f"batch({B}) must divide im2col_step({step})")
+    sampling_loc, attn_weight = _same_dtype(value, sampling_loc, attn_weight)
+    value = _aligned(value)
+    out = torch.empty((B, Nq, H * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        status = _launch(
+            "msda_fwd", value.device, _lib.mmfs_msda_forward, _DTYPE_CODE[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            out.data_ptr(), B, S, H, D, L, Nq, P, _stream(value.device))
+    _check(status, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """Reference: ms_deform_attn_cuda_backward, src/cuda/ms_deform_attn_cuda.cu:84-166.
+    Returns [grad_value, grad_sampling_loc, grad_attn_weight] shaped and typed like the
+    corresponding inputs."""
+    _require(isinstance(value, torch.Tensor) and value.is_cuda, "Not implemented on the CPU")
+    _validate([("value", value), ("spatial_shapes", spatial_shapes),
+               ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+               ("attn_weight", attn_weight), ("grad_output", grad_output)], value)
+    B, S, H, D, L, Nq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _require(grad_output.numel() == B * Nq * H * D, "grad_output must be [B, Nq, H*D]")
+    step = min(B, int(im2col_step)) if B > 0 else 1
+    _require(step > 0 and B % step == 0, f"batch({B}) must divide im2col_step({step})")
+    loc_dtype, attn_dtype = sampling_loc.dtype, attn_weight.dtype
+    sampling_loc, attn_weight = _same_dtype(value, sampling_loc, attn_weight)
+    if grad_output.dtype != value.dtype:
+        grad_output = grad_output.to(value.dtype)
+    value, grad_output = _aligned(value), _aligned(grad_output)
+
+    dt = value.dtype
+    acc_dtype = torch.float64 if dt == torch.float64 else torch.float32
+    grad_value_acc = torch.zeros(value.shape, dtype=acc_dtype, device=value.device)  # .cu:127
+    grad_loc = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
+    grad_attn = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = _stream(value.device)
+        status = _launch(
+            "msda_bwd", value.device, _lib.mmfs_msda_backward, _DTYPE_CODE[dt], value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            grad_value_acc.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+            B, S, H, D, L, Nq, P, stream)
+        _check(status, "ms_deform_attn_backward")
+        if dt in (torch.float16, torch.bfloat16):                    # .cu:156-165
+            grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
+            status = _launch("msda_cast", value.device, _lib.mmfs_msda_cast_from_f32,
+                             _DTYPE_CODE[dt], grad_value_acc.data_ptr(), grad_value.data_ptr(),
+                             grad_value_acc.numel(), stream)
+            _check(status, "ms_deform_attn_backward(cast)")
+        else:
+            grad_value = grad_value_acc
+    if loc_dtype != dt:
+        grad_loc = grad_loc.to(loc_dtype)
+    if attn_dtype != dt:
+        grad_attn = grad_attn.to(attn_dtype)
+    return [grad_value, grad_loc, grad_attn]

@@ -1,0 +1,315 @@
+// msda_bwd.hip -- backward kernels of multi-scale deformable attention for gfx950.
+//
+// Replaces the reference backward family
+//   mm_interleaved/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:304-923
+//   (block = D threads per (b,q,h); per sample two __syncthreads, a shared-memory
+//   reduction by thread 0 or a tree, and 4 scalar atomics per thread)
+// with the forward's organisation (msda_fwd.hip): tap records staged in LDS per
+// query tile, LPI lanes x 16-byte channel vectors per query, head -> XCD affinity.
+//
+// Per sample the reference needs, for the location / weight gradients, sums over the
+// D channels of  g*v1, g*v2, g*v3, g*v4  (g = grad_out row, v1..v4 = the four corner
+// rows): everything else is per-sample scalar algebra (cuh:119-161):
+//     grad_attn  = w1*d1 + w2*d2 + w3*d3 + w4*d4
+//     grad_loc.x = Wl * attn * ( (1-fy)*(d2-d1) + fy*(d4-d3) )
+//     grad_loc.y = Hl * attn * ( (1-fx)*(d3-d1) + fx*(d4-d2) )
+// so each lane forms 4 partial dot products over its own channels and the LPI lanes
+// of the query combine them with wavefront shuffles -- no barrier, no shared-memory
+// reduction inside the sample loop.  Every (query, sample) has exactly one writer for
+// grad_loc / grad_attn; the results go back through the LDS record so the global
+// stores are as coalesced as the loads were.
+//
+// grad_value is accumulated in fp32 with hardware global_atomic_add_f32, matching the
+// reference's "accumulate in fp32, cast at the end" (ms_deform_attn_cuda.cu:122-165).
+// For the atomics the lanes of a query switch to an interleaved channel map
+// (channel = j*LPI + lane) so one atomic instruction covers LPI consecutive floats.
+#include "msda_device.h"
+#include "msda_launch.h"
+
+namespace mmfs {
+
+constexpr int kThreads = 256;
+constexpr int kRecsPerBlock = 512;
+constexpr int kUnroll = 2;
+
+template <typename A>
+__device__ __forceinline__ void atomic_add(A *p, A v)
+{
+    // relaxed, agent scope: the slice may be touched from any XCD
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int LPI>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int off = LPI / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T, int LPI>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+             const int64_t *__restrict__ start, const T *__restrict__ loc,
+             const T *__restrict__ attn, const T *__restrict__ grad_out,
+             float *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
+             const Dims d)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int QPB = kThreads / LPI;
+    constexpr int KC = (kRecsPerBlock / QPB) > kUnroll ? (kRecsPerBlock / QPB) : kUnroll;
+    constexpr int STRIDE = 2 * KC + 1;
+    __shared__ uint4 lds[QPB * STRIDE];
+
+    const BlockCoord bc = block_coord(d, QPB);
+    const int tid = threadIdx.x;
+    const int qi = tid / LPI, lig = tid % LPI;
+    const int q = bc.q0 + qi;
+    const bool q_ok = q < d.Nq;
+
+    const int64_t HD = (int64_t)d.H * d.D;
+    const int64_t slice = ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;
+    const T *vbase = value + slice + lig * VEC;
+    float *gvbase = grad_value + slice + lig;
+
+    // upstream gradient of this query: contiguous map for the dots, interleaved for atomics
+    float g[VEC], gat[VEC];
+    if (q_ok) {
+        const T *gp = grad_out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D;
+        V::unpack(*reinterpret_cast<const uint4 *>(gp + lig * VEC), g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gat[j] = to_f32(gp[j * LPI + lig]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[j] = 0.f; gat[j] = 0.f; }
+    }
+
+    for (int k0 = 0; k0 < d.K; k0 += KC) {
+        const int kc = min(KC, d.K - k0);
+        const int kc_pad = (kc + kUnroll - 1) / kUnroll * kUnroll;
+        if (k0 > 0) __syncthreads();
+        // ---- stage
+        for (int r = tid; r < QPB * KC; r += kThreads) {
+            const int rq = r / KC, kk = r % KC;
+            if (kk >= kc_pad) continue;
+            int row[4] = {-1, -1, -1, -1};
+            float fx = 0.f, fy = 0.f, a = 0.f;
+            uint32_t wh = 0;
+            const int sq = bc.q0 + rq;
+            if (kk < kc && sq < d.Nq) {
+                const int k = k0 + kk;
+                const int l = k / d.P;
+                const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
+                const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+                const Tap<float> t = locate<float>(to_f32(loc[2 * s]), to_f32(loc[2 * s + 1]), Hl, Wl,
+                                                   (int)start[l]);
+                row[0] = t.row[0]; row[1] = t.row[1]; row[2] = t.row[2]; row[3] = t.row[3];
+                fx = t.fx; fy = t.fy; a = to_f32(attn[s]);
+                wh = ((uint32_t)Hl << 16) | (uint32_t)Wl;
+            }
+            uint4 *dst = &lds[rq * STRIDE + 2 * kk];
+            dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
+            dst[1] = make_uint4(__float_as_uint(fx), __float_as_uint(fy), __float_as_uint(a), wh);
+        }
+        __syncthreads();
+        // ---- gather + reduce + scatter
+        if (q_ok) {
+            uint4 *recs = &lds[qi * STRIDE];
+            for (int kk = 0; kk < kc_pad; kk += kUnroll) {
+                uint4 raw[kUnroll][4];
+                int rows[kUnroll][4];
+                uint4 meta[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const uint4 rr = recs[2 * (kk + u)];
+                    meta[u] = recs[2 * (kk + u) + 1];
+                    rows[u][0] = (int)rr.x; rows[u][1] = (int)rr.y; rows[u][2] = (int)rr.z; rows[u][3] = (int)rr.w;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        raw[u][c] = *reinterpret_cast<const uint4 *>(vbase + (int64_t)max(rows[u][c], 0) * HD);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    float dot[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v[VEC];
+                        V::unpack(raw[u][c], v);
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc = fmaf(g[i], v[i], acc);
+                        dot[c] = group_sum<LPI>(rows[u][c] >= 0 ? acc : 0.f);
+                    }
+                    const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
+                    const float a = __uint_as_float(meta[u].z);
+                    const float Wl = (float)(meta[u].w & 0xffffu), Hl = (float)(meta[u].w >> 16);
+                    const float gy = 1.f - fy, gx = 1.f - fx;
+                    const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+                    if (lig == 0) {
+                        const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
+                        const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
+                        const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
+                        recs[2 * (kk + u)] = make_uint4(__float_as_uint(ga), __float_as_uint(Wl * dw * a),
+                                                        __float_as_uint(Hl * dh * a), 0u);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (rows[u][c] >= 0) {
+                            const float coef = w[c] * a;
+                            float *p = gvbase + (int64_t)rows[u][c] * HD;
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) atomic_add(p + j * LPI, coef * gat[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- coalesced store of this chunk's grad_attn / grad_loc
+        for (int r = tid; r < QPB * KC; r += kThreads) {
+            const int rq = r / KC, kk = r % KC;
+            const int sq = bc.q0 + rq;
+            if (kk >= kc || sq >= d.Nq) continue;
+            const uint4 res = lds[rq * STRIDE + 2 * kk];
+            const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + (k0 + kk);
+            grad_attn[s] = (T)__uint_as_float(res.x);
+            grad_loc[2 * s] = (T)__uint_as_float(res.y);
+            grad_loc[2 * s + 1] = (T)__uint_as_float(res.z);
+        }
+    }
+}
+
+// Scalar fallback (any D, fp64): one thread per (b, q, h), serial over samples and
+// channels; single writer for grad_loc / grad_attn, atomics for grad_value.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_scalar(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                const int64_t *__restrict__ start, const T *__restrict__ loc,
+                const T *__restrict__ attn, const T *__restrict__ grad_out,
+                typename Acc<T>::type *__restrict__ grad_value, T *__restrict__ grad_loc,
+                T *__restrict__ grad_attn, const Dims d, const int64_t items)
+{
+    typedef typename Acc<T>::type A;
+    const int64_t HD = (int64_t)d.H * d.D;
+    for (int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x; item < items;
+         item += (int64_t)gridDim.x * kThreads) {
+        const int h = (int)(item % d.H);
+        const int64_t b = item / d.H / d.Nq;
+        const int64_t slice = b * d.S * HD + (int64_t)h * d.D;
+        const T *g = grad_out + item * d.D;
+        for (int k = 0; k < d.K; ++k) {
+            const int l = k / d.P;
+            const int64_t s = item * d.K + k;
+            const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+            const Tap<A> t = locate<A>((A)loc[2 * s], (A)loc[2 * s + 1], Hl, Wl, (int)start[l]);
+            const A gy = 1 - t.fy, gx = 1 - t.fx, a = (A)attn[s];
+            const A w[4] = {gy * gx, gy * t.fx, t.fy * gx, t.fy * t.fx};
+            A dot[4] = {0, 0, 0, 0};
+            for (int c = 0; c < d.D; ++c) {
+                const A gc = (A)g[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (t.row[i] >= 0) {
+                        const int64_t off = slice + (int64_t)t.row[i] * HD + c;
+                        dot[i] += gc * (A)value[off];
+                        atomic_add(grad_value + off, w[i] * a * gc);
+                    }
+                }
+            }
+            grad_attn[s] = (T)(w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3]);
+            grad_loc[2 * s] = (T)((A)Wl * a * (gy * (dot[1] - dot[0]) + t.fy * (dot[3] - dot[2])));
+            grad_loc[2 * s + 1] = (T)((A)Hl * a * (gx * (dot[2] - dot[0]) + t.fx * (dot[3] - dot[1])));
+        }
+    }
+}
+
+// dst = (T) src, 4 elements per thread
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+cast_kernel(const float *__restrict__ src, T *__restrict__ dst, const int64_t n)
+{
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[i];
+        T o[4] = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+        reinterpret_cast<uint2 *>(dst)[i] = *reinterpret_cast<const uint2 *>(o);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+        dst[i] = (T)src[i];
+}
+
+// ---------------------------------------------------------------- launchers
+template <typename T, int LPI>
+static hipError_t launch_vec(const void *value, const int64_t *shapes, const int64_t *start,
+                             const void *loc, const void *attn, const void *go, void *gv, void *gl,
+                             void *ga, Dims d, hipStream_t st)
+{
+    constexpr int QPB = kThreads / LPI;
+    d.q_tiles = (d.Nq + QPB - 1) / QPB;
+    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((msda_bwd_vec<T, LPI>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                       (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
+                       (float *)gv, (T *)gl, (T *)ga, d);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_scalar(const void *value, const int64_t *shapes, const int64_t *start,
+                                const void *loc, const void *attn, const void *go, void *gv, void *gl,
+                                void *ga, Dims d, hipStream_t st)
+{
+    const int64_t items = (int64_t)d.B * d.Nq * d.H;
+    const int64_t blocks = std::min<int64_t>((items + kThreads - 1) / kThreads, 256 * 32);
+    hipLaunchKernelGGL((msda_bwd_scalar<T>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                       (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
+                       (typename Acc<T>::type *)gv, (T *)gl, (T *)ga, d, items);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t dispatch_bwd(const void *value, const int64_t *shapes, const int64_t *start,
+                               const void *loc, const void *attn, const void *go, void *gv, void *gl,
+                               void *ga, const Dims &d, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    if (d.D % VEC == 0) {
+        switch (d.D / VEC) {
+#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, go, gv, gl, ga, d, st);
+            MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
+#undef MMFS_CASE
+            default: break;
+        }
+    }
+    return launch_scalar<T>(value, shapes, start, loc, attn, go, gv, gl, ga, d, st);
+}
+
+hipError_t backward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                    const void *loc, const void *attn, const void *grad_out,
+                    void *gv, void *gl, void *ga, const Dims &d, hipStream_t st)
+{
+    switch (dtype) {
+        case 0: return dispatch_bwd<float>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        case 1: return dispatch_bwd<half_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        case 2: return dispatch_bwd<bf16_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        case 3: return launch_scalar<double>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((n / 4 + kThreads) / kThreads, 256 * 16);
+    switch (dtype) {
+        case 0: return hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
+        case 1: hipLaunchKernelGGL((cast_kernel<half_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, src, (half_t *)dst, n); break;
+        case 2: hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, src, (bf16_t *)dst, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mmfs

@@ -1,0 +1,132 @@
+// msda_capi.hip -- the extern "C" surface declared in include/mmfs_msda.h.
+// Validates arguments, narrows the dims to the kernels' 32-bit index range and
+// forwards to the kernel launchers.  No state, no allocation.
+#include "../../include/mmfs_msda.h"
+#include "msda_launch.h"
+
+namespace {
+
+int elem_size(int dtype)
+{
+    switch (dtype) {
+        case MMFS_F32: return 4;
+        case MMFS_F16: case MMFS_BF16: return 2;
+        case MMFS_F64: return 8;
+        default: return 0;
+    }
+}
+
+// Fills d; returns MMFS_OK, or an error.  *empty is set when there is nothing to launch.
+int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+              mmfs::Dims *d)
+{
+    const int64_t lim = 0x7fffffffLL;
+    if (B < 0 || S < 0 || H < 0 || D < 0 || L < 0 || Nq < 0 || P < 0) return MMFS_E_DIMS;
+    if (B > lim || S > lim || H > lim || D > lim || L > lim || Nq > lim || P > lim) return MMFS_E_DIMS;
+    if (L * P > lim || H * D > lim) return MMFS_E_DIMS;
+    // pixel-row indices (level start + y*W + x) are kept as int32 in the tap records
+    if (S > lim - 2) return MMFS_E_DIMS;
+    // level extents are packed into 16 bits each in the backward's records; checked
+    // on the device tables by the host shim (they live in device memory here).
+    d->B = (int)B; d->S = (int)S; d->H = (int)H; d->D = (int)D;
+    d->L = (int)L; d->Nq = (int)Nq; d->P = (int)P;
+    d->K = (int)(L * P);
+    d->q_tiles = 0;
+    return MMFS_OK;
+}
+
+bool misaligned(const void *p, int esize) { return ((uintptr_t)p % (uintptr_t)esize) != 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mmfs_msda_abi_version(void) { return MMFS_MSDA_ABI_VERSION; }
+
+const char *mmfs_msda_build_info(void)
+{
+    return "libmmfs_msda gfx950 (CDNA4) hip " __VERSION__;
+}
+
+const char *mmfs_msda_status_string(int status)
+{
+    switch (status) {
+        case MMFS_OK: return "ok";
+        case MMFS_E_DTYPE: return "mmfs_msda: unknown dtype code";
+        case MMFS_E_DIMS: return "mmfs_msda: negative or out-of-range dimension";
+        case MMFS_E_NULLPTR: return "mmfs_msda: NULL pointer for a non-empty tensor";
+        case MMFS_E_ALIGN: return "mmfs_msda: tensor base pointer not aligned to 16 bytes / element size";
+        case MMFS_E_UNSUPPORTED: return "mmfs_msda: unsupported configuration";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "mmfs_msda: unknown status";
+}
+
+int mmfs_msda_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                      const void *loc, const void *attn, void *out,
+                      int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                      void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_out = B * Nq * H * D;
+    if (n_out == 0) return MMFS_OK;
+    if (!out) return MMFS_E_NULLPTR;
+    if (d.K == 0 || S == 0)                          // nothing to sample: the op's value is 0
+        return (int)hipMemsetAsync(out, 0, (size_t)n_out * es, st);
+    if (!value || !shapes || !start || !loc || !attn) return MMFS_E_NULLPTR;
+    // the vector kernels move 16-byte channel vectors; rows are D*es apart, so the
+    // bases must be 16-byte aligned whenever D*es is a multiple of 16
+    const int al = ((D * es) % 16 == 0) ? 16 : es;
+    if (misaligned(value, al) || misaligned(out, al) || misaligned(loc, es) || misaligned(attn, es))
+        return MMFS_E_ALIGN;
+    return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st);
+}
+
+int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                       const void *loc, const void *attn, const void *grad_out,
+                       void *grad_value_acc, void *grad_loc, void *grad_attn,
+                       int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                       void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_samples = B * Nq * H * L * P;
+    if (n_samples == 0) return MMFS_OK;              // grad_value_acc stays zero
+    if (!grad_loc || !grad_attn) return MMFS_E_NULLPTR;
+    if (S == 0 || D == 0) {
+        hipError_t e = hipMemsetAsync(grad_loc, 0, (size_t)n_samples * 2 * es, st);
+        if (e != hipSuccess) return (int)e;
+        return (int)hipMemsetAsync(grad_attn, 0, (size_t)n_samples * es, st);
+    }
+    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value_acc)
+        return MMFS_E_NULLPTR;
+    const int al = ((D * es) % 16 == 0) ? 16 : es;
+    if (misaligned(value, al) || misaligned(grad_out, al) || misaligned(loc, es) ||
+        misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es) ||
+        misaligned(grad_value_acc, dtype == MMFS_F64 ? 8 : 4))
+        return MMFS_E_ALIGN;
+    return (int)mmfs::backward(dtype, value, shapes, start, loc, attn, grad_out,
+                               grad_value_acc, grad_loc, grad_attn, d, st);
+}
+
+int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream)
+{
+    if (dtype != MMFS_F32 && dtype != MMFS_F16 && dtype != MMFS_BF16) return MMFS_E_DTYPE;
+    if (n < 0) return MMFS_E_DIMS;
+    if (n == 0) return MMFS_OK;
+    if (!src || !dst) return MMFS_E_NULLPTR;
+    if (misaligned(src, 16) || misaligned(dst, 8)) return MMFS_E_ALIGN;
+    return (int)mmfs::cast_from_f32(dtype, src, dst, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// msda_device.h -- device-side building blocks shared by the forward and backward
+// kernels of the multi-scale deformable attention op (gfx950 / CDNA4 only).
+//
+// Semantics follow the reference kernels
+//   mm_interleaved/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:36-87 (bilinear tap),
+//   :288-291 (pixel coordinates and the strict range test);
+// the organisation (one 16-byte channel vector per lane, tap records staged in LDS
+// by the whole workgroup, head -> XCD affinity) is this repository's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmfs {
+
+struct Dims {
+    int B, S, H, D, L, Nq, P;
+    int K;          // L * P samples per (b, q, h)
+    int q_tiles;    // ceil(Nq / queries-per-block), filled by the launcher
+};
+
+// ---------------------------------------------------------------- storage types
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+
+template <typename T> struct Acc { typedef float type; };
+template <> struct Acc<double> { typedef double type; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+// 16 bytes of T -> VEC floats
+template <typename T> struct Vec16;
+
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const uint4 &r, float (&o)[4]) {
+        o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y);
+        o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[4]) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]),
+                          __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+};
+
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const uint4 &r, float (&o)[8]) {
+        // bf16 -> f32 is a 16-bit shift: low half via shl, high half via mask
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+        o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+        o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint32_t pk(float a, float b) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        bf2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;          // RNE; v_cvt_pk_bf16_f32 on gfx950
+        return __builtin_bit_cast(uint32_t, p);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+        return make_uint4(pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7]));
+    }
+};
+
+template <> struct Vec16<half_t> {
+    static constexpr int N = 8;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void up(uint32_t w, float &a, float &b) {
+        h2 p = __builtin_bit_cast(h2, w); a = (float)p[0]; b = (float)p[1];
+    }
+    static __device__ __forceinline__ void unpack(const uint4 &r, float (&o)[8]) {
+        up(r.x, o[0], o[1]); up(r.y, o[2], o[3]); up(r.z, o[4], o[5]); up(r.w, o[6], o[7]);
+    }
+    static __device__ __forceinline__ uint32_t pk(float a, float b) {
+        h2 p; p[0] = (_Float16)a; p[1] = (_Float16)b;        // RNE
+        return __builtin_bit_cast(uint32_t, p);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+        return make_uint4(pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7]));
+    }
+};
+
+// ---------------------------------------------------------------- bilinear tap
+// One sample's 2x2 footprint.  row[i] is the pixel index inside the whole value
+// tensor's S axis (level start included), or -1 when the corner is outside the map
+// or the sample fails the range test (then it contributes nothing, cuh:291).
+template <typename A>
+struct Tap {
+    int row[4];     // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    A fx, fy;       // fractional parts ("lw", "lh" in the reference)
+    int Hl, Wl;
+};
+
+template <typename A>
+__device__ __forceinline__ Tap<A> locate(A lx, A ly, int Hl, int Wl, int level_start)
+{
+    Tap<A> t;
+    t.Hl = Hl; t.Wl = Wl;
+    const A y = ly * (A)Hl - (A)0.5;
+    const A x = lx * (A)Wl - (A)0.5;
+    // strict comparisons: NaN fails, exactly -1 / Hl / Wl fail (cuh:291)
+    const bool inside = (y > (A)-1) && (x > (A)-1) && (y < (A)Hl) && (x < (A)Wl);
+    const A yf = floor(y), xf = floor(x);
+    const int y0 = inside ? (int)yf : 0, x0 = inside ? (int)xf : 0;
+    t.fy = inside ? y - yf : (A)0;
+    t.fx = inside ? x - xf : (A)0;
+    const bool top = y0 >= 0, left = x0 >= 0, bottom = y0 + 1 <= Hl - 1, right = x0 + 1 <= Wl - 1;
+    const int base = level_start + y0 * Wl + x0;
+    t.row[0] = (inside && top && left) ? base : -1;
+    t.row[1] = (inside && top && right) ? base + 1 : -1;
+    t.row[2] = (inside && bottom && left) ? base + Wl : -1;
+    t.row[3] = (inside && bottom && right) ? base + Wl + 1 : -1;
+    return t;
+}
+
+// Workgroup -> (b, h, first query).  Blocks are dealt to XCDs round-robin
+// (block i -> XCD i % 8, observed, MI355X_MICROARCH.md "Workgroup dispatch"), so
+// taking h = block % H pins every head's value slice [S, D] of a sample to one
+// XCD's 4 MiB L2 when H is a multiple of 8 (and to H of the 8 L2s otherwise).
+// This is a speed choice only: any placement gives the same results.
+struct BlockCoord { int b, h, q0; };
+__device__ __forceinline__ BlockCoord block_coord(const Dims &d, int queries_per_block)
+{
+    BlockCoord c;
+    const int bid = blockIdx.x;
+    c.h = bid % d.H;
+    const int t = bid / d.H;
+    c.q0 = (t % d.q_tiles) * queries_per_block;
+    c.b = t / d.q_tiles;
+    return c;
+}
+
+}  // namespace mmfs

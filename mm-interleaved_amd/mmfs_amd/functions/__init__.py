@@ -1,0 +1,2 @@
+# mirrors mm_interleaved/models/utils/ops/functions/__init__.py:9
+from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch  # noqa: F401

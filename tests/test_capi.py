@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: libmmfs_msda.so loads, exports every
+symbol include/mmfs_msda.h declares, validates arguments without touching a GPU, and
+the Python shim keeps the reference's error behaviour (no CPU path:
+ops/src/ms_deform_attn.h:29-38)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mmfs_msda.h")
+LIB = os.path.join(ROOT, "mm-interleaved_amd", "libmmfs_msda.so")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmfs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    names = declared_functions()
+    for n in ("mmfs_msda_forward", "mmfs_msda_backward", "mmfs_msda_cast_from_f32",
+              "mmfs_msda_abi_version", "mmfs_msda_status_string"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "run __graft_entry__.build() / make -C mm-interleaved_amd/csrc"
+    lib = ctypes.CDLL(LIB)
+    for n in declared_functions():
+        assert hasattr(lib, n), f"{n} declared in include/mmfs_msda.h but not exported"
+    lib.mmfs_msda_abi_version.restype = ctypes.c_int
+    assert lib.mmfs_msda_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = ctypes.CDLL(LIB)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    lib.mmfs_msda_forward.restype = ctypes.c_int
+    lib.mmfs_msda_forward.argtypes = [ctypes.c_int] + [vp] * 6 + [i64] * 7 + [vp]
+    lib.mmfs_msda_status_string.restype = ctypes.c_char_p
+    lib.mmfs_msda_status_string.argtypes = [ctypes.c_int]
+    null = [None] * 6
+    assert lib.mmfs_msda_forward(9, *null, 1, 1, 1, 1, 1, 1, 1, None) == -1       # dtype
+    assert lib.mmfs_msda_forward(0, *null, -1, 1, 1, 1, 1, 1, 1, None) == -2      # dims
+    assert lib.mmfs_msda_forward(0, *null, 1, 1, 1, 1, 1, 1, 1, None) == -3       # null
+    assert lib.mmfs_msda_forward(0, *null, 0, 1, 1, 1, 1, 1, 1, None) == 0        # empty batch
+    assert b"dtype" in lib.mmfs_msda_status_string(-1)
+    assert lib.mmfs_msda_status_string(-99) is not None
+
+
+def test_shim_has_the_reference_surface_and_no_cpu_path():
+    import MultiScaleDeformableAttention as MSDA
+    assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
+    v = torch.zeros(1, 4, 1, 8)
+    sh = torch.tensor([[2, 2]]); st = torch.tensor([0])
+    loc = torch.zeros(1, 1, 1, 1, 1, 2); attn = torch.zeros(1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="CPU"):
+        MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 1)
+    with pytest.raises(RuntimeError, match="CPU"):
+        MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, torch.zeros(1, 1, 8), 1)
+
+
+def test_autograd_function_surface():
+    from mmfs_amd.functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+    assert hasattr(MSDeformAttnFunction, "apply")
+    with pytest.raises(RuntimeError):
+        ms_deform_attn_core_pytorch(torch.zeros(1, 4, 1, 8), [(2, 2)], torch.zeros(1, 1, 1, 1, 1, 2),
+                                    torch.zeros(1, 1, 1, 1, 1))

@@ -1,0 +1,221 @@
+"""GPU parity tests of the HIP op (through the Python shim -> C ABI -> gfx950 kernels)
+against the committed reference goldens and the CPU oracle.
+
+Bars (BASELINE.json north_star): fp32 <= 1e-5, fp16 <= 1e-3 (bf16 reported with the
+same protocol: fp64 oracle on storage-rounded inputs)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, level_tables, load_golden, make_inputs, max_abs
+from oracle import msda_oracle
+
+pytestmark = pytest.mark.gpu
+OP_GOLDENS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "op_*.npz")))
+DEV = "cuda"
+
+# absolute tolerance on outputs whose magnitude is O(1); gradients use a relative bar
+TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def run_hip(x, dtype, use_autograd=True):
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.functions import MSDeformAttnFunction
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
+    value, loc, attn, grad = dev(x["value"]), dev(x["loc"]), dev(x["attn"]), dev(x["grad"])
+    sh, st = dev(x["shapes"]), dev(x["start"])
+    if use_autograd:
+        value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
+        out = MSDeformAttnFunction.apply(value, sh, st, loc, attn, 1)
+        out.backward(grad.reshape(out.shape))
+        res = out.detach(), value.grad, loc.grad, attn.grad
+    else:
+        out = MSDA.ms_deform_attn_forward(value, sh, st, loc, attn, 1)
+        gv, gl, ga = MSDA.ms_deform_attn_backward(value, sh, st, loc, attn, grad.reshape(out.shape), 1)
+        res = out, gv, gl, ga
+    torch.cuda.synchronize()
+    return [r.double().cpu().numpy() for r in res]
+
+
+def run_oracle(x):
+    out = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    gv, gl, ga = msda_oracle.backward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"], x["grad"])
+    return out, gv, gl, ga
+
+
+def check(got, want, dtype, what=""):
+    tol = TOL[dtype]
+    names = ("out", "grad_value", "grad_loc", "grad_attn")
+    for n, g, w in zip(names, got, want):
+        scale = max(1.0, float(np.abs(w).max())) if w.size else 1.0
+        err = max_abs(g, w)
+        assert err <= tol * scale, f"{what} {n}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+def golden_inputs(z, dtype):
+    rt = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).to(dtype).to(torch.float64)
+    return dict(value=rt(z["value"]), shapes=torch.from_numpy(z["spatial_shapes"]),
+                start=torch.from_numpy(z["level_start_index"]), loc=rt(z["loc"]), attn=rt(z["attn"]),
+                grad=rt(z["grad_out"]))
+
+
+@pytest.mark.parametrize("name", OP_GOLDENS)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hip_matches_reference_goldens(name, dtype):
+    z = load_golden(name)
+    x = golden_inputs(z, dtype)
+    got = run_hip(x, dtype)
+    want = [z["out_f64"], z["grad_value_f64"], z["grad_loc_f64"], z["grad_attn_f64"]]
+    if dtype == torch.float64 and z["grad_value_f64"].dtype == np.float32:
+        want[1] = run_oracle(x)[1]            # golden stored in fp32: use the (pinned) oracle
+    check(got, want, dtype, name)
+
+
+@pytest.mark.parametrize("name", ["op_g1_d64", "op_g3_llm_n1", "op_g3_rect_n3", "op_g3_sd_n4"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hip_16bit_against_oracle_on_rounded_goldens(name, dtype):
+    x = golden_inputs(load_golden(name), dtype)
+    check(run_hip(x, dtype), run_oracle(x), dtype, name)
+
+
+CASES = [
+    # B, H, D, Nq, P, shapes                                   what it exercises
+    (2, 8, 32, 70, 4, [(16, 16), (8, 8), (4, 4), (2, 2)]),      # config-1 geometry, ragged Nq tile
+    (2, 8, 128, 33, 4, [(16, 16), (8, 8), (4, 4), (2, 2)]),     # north-star head width
+    (1, 16, 64, 40, 8, [(8, 8), (4, 4), (2, 2)] * 4),           # LLM MMFS, n=4 -> Leff=12, K=96 (chunked)
+    (2, 16, 64, 17, 8, [(8, 8), (4, 4), (2, 2), (1, 1)] * 3),   # SD MMFS, n=3 -> Leff=12
+    (3, 16, 32, 50, 4, [(16, 16)]),                             # ViT-Adapter extractor (L=1)
+    (1, 2, 8, 300, 2, [(5, 7), (3, 2)]),                        # tiny head width, many queries
+    (1, 3, 24, 9, 3, [(5, 7), (2, 3)]),                         # scalar path (D not 16B * 2^k)
+    (1, 1, 256, 5, 2, [(4, 4), (2, 2)]),                        # one head, wide
+    (1, 4, 64, 6, 2, [(3, 3)] * 90),                            # Leff = 90 (30 images x 3 levels)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in CASES])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_hip_matches_oracle_seeded(case, dtype):
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=7, loc_range=(-0.15, 1.15), dtype=dtype)
+    check(run_hip(x, dtype), run_oracle(x), dtype, str(case[:5]))
+
+
+def test_direct_extension_calls_match_autograd_path():
+    x = make_inputs(2, 4, 32, 19, 4, [(6, 5), (3, 3)], seed=11, dtype=torch.float32)
+    a = run_hip(x, torch.float32, use_autograd=True)
+    b = run_hip(x, torch.float32, use_autograd=False)
+    assert max_abs(a[0], b[0]) == 0.0                      # forward is deterministic
+    check(b, run_oracle(x), torch.float32)
+
+
+def test_edge_locations_follow_the_kernel_not_grid_sample():
+    sh, start = level_tables([(2, 2)])
+    value = torch.arange(1.0, 5.0).reshape(1, 4, 1, 1).repeat(1, 1, 1, 4).to(torch.float64)
+    pts = [(0.25, 0.25), (0.5, 0.5), (0.0, 0.0), (1.0, 1.0), (float("nan"), 0.5), (float("inf"), 0.5),
+           (-0.25, 0.5), (1.25, 0.5), (1.2499, 0.5), (0.5, -float("inf"))]
+    loc = torch.tensor(pts, dtype=torch.float64).reshape(1, len(pts), 1, 1, 1, 2)
+    attn = torch.ones(1, len(pts), 1, 1, 1, dtype=torch.float64)
+    x = dict(value=value, shapes=sh, start=start, loc=loc, attn=attn,
+             grad=torch.ones(1, len(pts), 4, dtype=torch.float64))
+    for dtype in (torch.float64, torch.float32):
+        got, want = run_hip(x, dtype), run_oracle(x)
+        assert np.isfinite(got[0]).all() and np.isfinite(got[2]).all()
+        check(got, want, dtype, "edges")
+
+
+def test_non_finite_values_outside_the_tap_do_not_leak():
+    # invalid corners must be skipped, not multiplied by zero (cuh:58-81)
+    sh, start = level_tables([(2, 2)])
+    value = torch.ones(1, 4, 1, 8, dtype=torch.float64)
+    value[0, 0] = float("inf")                           # pixel (0,0)
+    loc = torch.tensor([1.0, 1.0], dtype=torch.float64).reshape(1, 1, 1, 1, 1, 2)   # touches pixel (1,1) only
+    attn = torch.ones(1, 1, 1, 1, 1, dtype=torch.float64)
+    x = dict(value=value, shapes=sh, start=start, loc=loc, attn=attn, grad=torch.ones(1, 1, 8, dtype=torch.float64))
+    got = run_hip(x, torch.float32)
+    assert np.allclose(got[0], 0.25) and np.isfinite(got[2]).all() and np.isfinite(got[3]).all()
+
+
+def test_empty_inputs():
+    import MultiScaleDeformableAttention as MSDA
+    sh, start = level_tables([(2, 2)], DEV)
+    v = torch.rand(2, 4, 2, 8, device=DEV)
+    out = MSDA.ms_deform_attn_forward(v, sh, start, torch.zeros(2, 0, 2, 1, 3, 2, device=DEV),
+                                      torch.zeros(2, 0, 2, 1, 3, device=DEV), 1)
+    assert out.shape == (2, 0, 16)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, start, torch.zeros(2, 0, 2, 1, 3, 2, device=DEV),
+                                              torch.zeros(2, 0, 2, 1, 3, device=DEV),
+                                              torch.zeros(2, 0, 16, device=DEV), 1)
+    assert gv.shape == v.shape and not gv.any() and gl.numel() == 0 and ga.numel() == 0
+
+
+def test_reference_preconditions_raise():
+    import MultiScaleDeformableAttention as MSDA
+    sh, start = level_tables([(2, 2)], DEV)
+    v = torch.rand(3, 4, 2, 8, device=DEV)
+    loc = torch.rand(3, 2, 2, 1, 3, 2, device=DEV); attn = torch.rand(3, 2, 2, 1, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        MSDA.ms_deform_attn_forward(torch.rand(3, 2, 4, 8, device=DEV).permute(0, 2, 1, 3),
+                                    sh, start, loc, attn, 1)
+    with pytest.raises(RuntimeError, match="im2col_step"):
+        MSDA.ms_deform_attn_forward(v, sh, start, loc, attn, 2)          # 3 % 2 != 0 (.cu:51-53)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        MSDA.ms_deform_attn_forward(v, sh.cpu(), start, loc, attn, 1)
+
+
+def test_mixed_dtype_attention_is_cast_not_misread():
+    # softmax under autocast yields fp32 weights next to fp16 values (SURVEY 8a "Dtype flow")
+    x = make_inputs(1, 4, 32, 12, 4, [(4, 4), (2, 2)], seed=5, dtype=torch.float16)
+    import MultiScaleDeformableAttention as MSDA
+    v = x["value"].to(DEV, torch.float16); loc = x["loc"].to(DEV, torch.float16)
+    out = MSDA.ms_deform_attn_forward(v, x["shapes"].to(DEV), x["start"].to(DEV), loc,
+                                      x["attn"].to(DEV, torch.float32), 1)
+    want = run_oracle(x)[0]
+    assert max_abs(out.double().cpu().numpy(), want) < 1e-3
+
+
+# ---- size-independent properties at BASELINE.json's full sizes (oracle would take minutes)
+FULL = [
+    ("cfg1", dict(B=2, H=8, D=32, Nq=1024, P=4, shapes=[(64, 64), (32, 32), (16, 16), (8, 8)]), torch.float32),
+    ("cfg2_northstar", dict(B=8, H=8, D=128, Nq=4096, P=4, shapes=[(64, 64), (32, 32), (16, 16), (8, 8)]), torch.bfloat16),
+    ("cfg5_llm_n4", dict(B=4, H=16, D=64, Nq=2048, P=8, shapes=[(32, 32), (16, 16), (8, 8)] * 4), torch.float16),
+]
+
+
+@pytest.mark.parametrize("name,cfg,dtype", FULL, ids=[f[0] for f in FULL])
+def test_full_size_properties(name, cfg, dtype):
+    from mmfs_amd.functions import MSDeformAttnFunction
+    g = torch.Generator(device=DEV).manual_seed(0)
+    sh, start = level_tables(cfg["shapes"], DEV)
+    B, H, D, Nq, P = cfg["B"], cfg["H"], cfg["D"], cfg["Nq"], cfg["P"]
+    S, L = int(sh.prod(1).sum()), sh.shape[0]
+    value = torch.rand(B, S, H, D, device=DEV, generator=g).to(dtype)
+    loc = (torch.rand(B, Nq, H, L, P, 2, device=DEV, generator=g) * 1.2 - 0.1).to(dtype)
+    attn = torch.rand(B, Nq, H, L, P, device=DEV, generator=g) + 1e-5
+    attn = (attn / attn.sum((-1, -2), keepdim=True)).to(dtype)
+    grad = torch.randn(B, Nq, H * D, device=DEV, generator=g).to(dtype)
+    v, l, a = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+    out = MSDeformAttnFunction.apply(v, sh, start, l, a, 1)
+    out.backward(grad)
+    assert torch.isfinite(out).all() and torch.isfinite(v.grad).all() and torch.isfinite(l.grad).all()
+    rel = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    # (1) out is linear in value and in attn  =>  <v, dL/dv> = <a, dL/da> = <out, g>   (Euler)
+    og = (out.double() * grad.double()).sum()
+    assert abs((v.grad.double() * value.double()).sum() - og) <= rel * abs(og) + rel
+    assert abs((a.grad.double() * attn.double()).sum() - og) <= rel * abs(og) + rel
+    # (2) convexity: weights sum to 1 over real points, values in [0,1)  =>  0 <= out < 1 (+rounding)
+    assert out.min() >= -1e-2 and out.max() <= 1.0 + 1e-2
+    # (3) a random slab of the batch agrees with the CPU oracle
+    qs = slice(5, 9)
+    x = dict(value=value[:1].double().cpu(), shapes=sh.cpu(), start=start.cpu(), loc=loc[:1, qs].double().cpu(),
+             attn=attn[:1, qs].double().cpu(), grad=grad[:1, qs].double().cpu())
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    assert max_abs(out[:1, qs].double().cpu().numpy(), want) <= TOL[dtype]
+    _, gl, ga = msda_oracle.backward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"], x["grad"])
+    assert max_abs(a.grad[:1, qs].double().cpu().numpy(), ga) <= TOL[dtype] * max(1.0, np.abs(ga).max())
+    assert max_abs(l.grad[:1, qs].double().cpu().numpy(), gl) <= TOL[dtype] * max(1.0, np.abs(gl).max())
+    # (4) determinism of the forward (no atomics there)
+    out2 = MSDeformAttnFunction.apply(value, sh, start, loc, attn, 1)
+    assert torch.equal(out2, out.detach())
