@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 1
+#define MMFS_MSDA_ABI_VERSION 2
 
 enum mmfs_dtype {
     MMFS_F32  = 0,
@@ -78,34 +78,76 @@ int mmfs_msda_forward(int dtype,
                       int64_t B, int64_t S, int64_t H, int64_t D,
                       int64_t L, int64_t Nq, int64_t P, void *stream);
 
+/* Flags of mmfs_msda_backward(). */
+#define MMFS_BWD_CANONICAL_LEVELS 1u
+/*   The caller guarantees the level table is the canonical packing the reference's
+ *   callers build (modeling_llama_mmfs.py:303-305, sd_mmfs.py:35-37):
+ *       start[l] == sum_{k<l} H_k*W_k   and   sum_l H_l*W_l == S.
+ *   (The table lives in device memory, so the library cannot check it without a
+ *   device->host sync.)  With the guarantee every grad_value pixel has one owner level
+ *   and the pixel-stationary kernel applies; without it the library falls back to
+ *   float-atomic accumulation, which is also correct for gapped or overlapping levels. */
+#define MMFS_BWD_FORCE_ATOMIC 2u      /* testing/measurement: always take the atomic path */
+
+/*
+ * Scratch the backward needs for these arguments (0 when none).  Host-only computation.
+ */
+int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                           int64_t L, int64_t Nq, int64_t P, unsigned flags);
+
 /*
  * Backward.  Replaces ``ms_deform_attn_backward`` of the reference extension
  *   src/vision.cpp:15 -> src/ms_deform_attn.h:42-61
  *   -> src/cuda/ms_deform_attn_cuda.cu:84-166
  *   -> kernels src/cuda/ms_deform_im2col_cuda.cuh:304-923.
  *
- *   grad_out        [B, Nq, H*D]          storage dtype
- *   grad_value_acc  [B, S, H, D]          fp32 (fp64 for MMFS_F64), MUST be zero-filled
- *                                         by the caller (the reference zero-fills with
- *                                         at::zeros, .cu:127); accumulated with hardware
- *                                         float atomics, exactly the reference's
- *                                         "accumulate in fp32, cast at the end" (.cu:122-165)
- *   grad_loc        [B, Nq, H, L, P, 2]   storage dtype, fully overwritten
- *   grad_attn       [B, Nq, H, L, P]      storage dtype, fully overwritten
+ *   grad_out    [B, Nq, H*D]          storage dtype
+ *   grad_value  [B, S, H, D]          storage dtype, fully overwritten (no pre-zeroing)
+ *   grad_loc    [B, Nq, H, L, P, 2]   storage dtype, fully overwritten
+ *   grad_attn   [B, Nq, H, L, P]      storage dtype, fully overwritten
+ *   workspace   device scratch of at least mmfs_msda_backward_workspace_bytes(...)
+ *               bytes (may be NULL when that is 0); contents irrelevant on entry
  *
- * For MMFS_F32 / MMFS_F64 ``grad_value_acc`` IS the final grad_value.  For 16-bit
- * storage the caller converts it with mmfs_msda_cast_from_f32().
+ * grad_value is accumulated in fp32 (fp64 for MMFS_F64) and rounded once at the end,
+ * the reference's semantics (ms_deform_attn_cuda.cu:122-129, 156-165).  Two
+ * implementations, chosen by the library (see flags):
+ *   pixel-stationary (no atomics; msda_bwd_value.hip) and float-atomic scatter
+ *   (msda_bwd.hip; zero-fills and casts through ``workspace`` itself).
  */
 int mmfs_msda_backward(int dtype,
                        const void *value, const int64_t *shapes, const int64_t *start,
                        const void *loc, const void *attn, const void *grad_out,
-                       void *grad_value_acc, void *grad_loc, void *grad_attn,
+                       void *grad_value, void *grad_loc, void *grad_attn,
+                       void *workspace, int64_t workspace_bytes,
                        int64_t B, int64_t S, int64_t H, int64_t D,
-                       int64_t L, int64_t Nq, int64_t P, void *stream);
+                       int64_t L, int64_t Nq, int64_t P, unsigned flags, void *stream);
+
+/*
+ * The two stages of the pixel-stationary backward as separate launches (what
+ * mmfs_msda_backward runs back to back when MMFS_BWD_CANONICAL_LEVELS applies); exported so
+ * a caller can time or overlap them.  Same tensors and conventions as above.
+ *   _taps  : grad_loc and grad_attn only (reads value)            -- kernel msda_bwd_vec<.., false>
+ *   _value : grad_value only, canonical level table REQUIRED      -- kernel msda_bwd_value_tiled
+ * Both return MMFS_E_UNSUPPORTED when the head width has no vector path
+ * (D*sizeof(dtype) must be 16 bytes * 2^k, k <= 6; MMFS_F64 never): use mmfs_msda_backward.
+ */
+int mmfs_msda_backward_taps(int dtype,
+                            const void *value, const int64_t *shapes, const int64_t *start,
+                            const void *loc, const void *attn, const void *grad_out,
+                            void *grad_loc, void *grad_attn,
+                            int64_t B, int64_t S, int64_t H, int64_t D,
+                            int64_t L, int64_t Nq, int64_t P, void *stream);
+int mmfs_msda_backward_value(int dtype,
+                             const int64_t *shapes, const int64_t *start,
+                             const void *loc, const void *attn, const void *grad_out,
+                             void *grad_value,
+                             int64_t B, int64_t S, int64_t H, int64_t D,
+                             int64_t L, int64_t Nq, int64_t P, void *stream);
 
 /*
  * dst[i] = (dtype) src[i], round-to-nearest-even.  Replaces the trailing
- * ``grad_value.to(torch::kHalf)`` of the reference backward (ms_deform_attn_cuda.cu:156-165).
+ * ``grad_value.to(torch::kHalf)`` of the reference backward (ms_deform_attn_cuda.cu:156-165);
+ * used internally by the atomic path and exported for callers that keep fp32 buffers.
  * ``dtype`` must be MMFS_F16 or MMFS_BF16 (MMFS_F32 copies).
  */
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream);

@@ -38,7 +38,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 1
+_ABI_VERSION = 2
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -50,7 +50,13 @@ _lib.mmfs_msda_status_string.argtypes = [_int]
 _lib.mmfs_msda_forward.restype = _int
 _lib.mmfs_msda_forward.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [_vp]
 _lib.mmfs_msda_backward.restype = _int
-_lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 9 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp]
+_lib.mmfs_msda_backward_workspace_bytes.restype = _i64
+_lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
+_lib.mmfs_msda_backward_taps.restype = _int
+_lib.mmfs_msda_backward_taps.argtypes = [_int] + [_vp] * 8 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_backward_value.restype = _int
+_lib.mmfs_msda_backward_value.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [_vp]
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
@@ -165,7 +171,41 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+# flags of mmfs_msda_backward (include/mmfs_msda.h)
+_BWD_CANONICAL_LEVELS = 1
+_BWD_FORCE_ATOMIC = 2
+_E_UNSUPPORTED = -5
+
+# tests / measurements: "auto" | "atomic" (force the float-atomic path)
+_bwd_algo = "auto"
+
+
+def levels_are_canonical(spatial_shapes, level_start_index, S):
+    """True when start[l] == sum_{k<l} H_k*W_k and sum_l H_l*W_l == S (the packing every
+    caller in the reference builds: modeling_llama_mmfs.py:303-305, sd_mmfs.py:35-37).
+
+    The tables live in device memory (reference API), so the first query for a given
+    pair of tensor objects costs one small device->host copy; the answer is cached on
+    the tensor object (keyed by the in-place version counters).  mmfs_amd's own callers
+    create their tables once with ``mmfs_amd.levels.make_level_tables`` which pre-seeds
+    the cache, so the training loop never syncs here."""
+    key = (spatial_shapes._version, level_start_index._version, level_start_index.data_ptr(), int(S))
+    cached = getattr(spatial_shapes, "_mmfs_canonical", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    sh = spatial_shapes.detach().cpu()
+    st = level_start_index.detach().cpu().reshape(-1)
+    px = sh[:, 0] * sh[:, 1]
+    canon = bool((sh >= 0).all()) and bool((sh < 65536).all()) and \
+        bool(torch.equal(st, px.cumsum(0) - px)) and int(px.sum()) == int(S)
+    try:
+        spatial_shapes._mmfs_canonical = (key, canon)
+    except Exception:
+        pass
+    return canon
+
+
+def ms_deform_attn_backward(def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step):
     """Reference: ms_deform_attn_cuda_backward, src/cuda/ms_deform_attn_cuda.cu:84-166.
     Returns [grad_value, grad_sampling_loc, grad_attn_weight] shaped and typed like the
@@ -185,26 +225,41 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     value, grad_output = _aligned(value), _aligned(grad_output)
 
     dt = value.dtype
-    acc_dtype = torch.float64 if dt == torch.float64 else torch.float32
-    grad_value_acc = torch.zeros(value.shape, dtype=acc_dtype, device=value.device)  # .cu:127
+    code = _DTYPE_CODE[dt]
+    dims = (B, S, H, D, L, Nq, P)
+    flags = 0
+    if _bwd_algo == "atomic":
+        flags |= _BWD_FORCE_ATOMIC
+    elif levels_are_canonical(spatial_shapes, level_start_index, S):
+        flags |= _BWD_CANONICAL_LEVELS
+    grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
     grad_loc = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
     grad_attn = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
     with torch.cuda.device(value.device):
         stream = _stream(value.device)
-        status = _launch(
-            "msda_bwd", value.device, _lib.mmfs_msda_backward, _DTYPE_CODE[dt], value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-            grad_value_acc.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-            B, S, H, D, L, Nq, P, stream)
+        status = _E_UNSUPPORTED
+        if flags & _BWD_CANONICAL_LEVELS:
+            # pixel-stationary backward, stage by stage (so each kernel can be timed)
+            status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
+                             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                             grad_loc.data_ptr(), grad_attn.data_ptr(), *dims, stream)
+            if status == 0:
+                status = _launch("msda_bwd_value", value.device, _lib.mmfs_msda_backward_value, code,
+                                 spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                 sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                 grad_value.data_ptr(), *dims, stream)
+        if status == _E_UNSUPPORTED:
+            # head width without a vector path, fp64, or a non-canonical level table:
+            # the library's float-atomic path (needs an fp32 scratch for 16-bit storage)
+            ws_bytes = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
+            status = _launch("msda_bwd_atomic", value.device, _lib.mmfs_msda_backward, code,
+                             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                             grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                             ws.data_ptr() if ws is not None else None, ws_bytes, *dims, flags, stream)
         _check(status, "ms_deform_attn_backward")
-        if dt in (torch.float16, torch.bfloat16):                    # .cu:156-165
-            grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
-            status = _launch("msda_cast", value.device, _lib.mmfs_msda_cast_from_f32,
-                             _DTYPE_CODE[dt], grad_value_acc.data_ptr(), grad_value.data_ptr(),
-                             grad_value_acc.numel(), stream)
-            _check(status, "ms_deform_attn_backward(cast)")
-        else:
-            grad_value = grad_value_acc
     if loc_dtype != dt:
         grad_loc = grad_loc.to(loc_dtype)
     if attn_dtype != dt:

@@ -35,7 +35,10 @@ constexpr int kUnroll = 2;
 template <typename A>
 __device__ __forceinline__ void atomic_add(A *p, A v)
 {
-    // relaxed, agent scope: the slice may be touched from any XCD
+    // relaxed, agent scope: the slice may be touched from any XCD.  Measured on MI355X:
+    // ~330 G float adds/s for the whole chip whatever the footprint or scope
+    // (tools/ubench/atomics.hip), i.e. one lane-add per L2 channel per clock -- which
+    // is why this path is only the fallback (see msda_bwd_value.hip).
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -47,7 +50,10 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
-template <typename T, int LPI>
+// SCATTER = true : also accumulates grad_value with global atomics (fallback path)
+// SCATTER = false: location / weight gradients only; grad_value comes from the
+//                  pixel-stationary kernel in msda_bwd_value.hip
+template <typename T, int LPI, bool SCATTER>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
@@ -75,14 +81,15 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 
     // upstream gradient of this query: contiguous map for the dots, interleaved for atomics
     float g[VEC], gat[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { g[j] = 0.f; gat[j] = 0.f; }
     if (q_ok) {
         const T *gp = grad_out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D;
         V::unpack(*reinterpret_cast<const uint4 *>(gp + lig * VEC), g);
+        if (SCATTER) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) gat[j] = to_f32(gp[j * LPI + lig]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { g[j] = 0.f; gat[j] = 0.f; }
+            for (int j = 0; j < VEC; ++j) gat[j] = to_f32(gp[j * LPI + lig]);
+        }
     }
 
     for (int k0 = 0; k0 < d.K; k0 += KC) {
@@ -155,7 +162,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        if (rows[u][c] >= 0) {
+                        if (SCATTER && rows[u][c] >= 0) {
                             const float coef = w[c] * a;
                             float *p = gvbase + (int64_t)rows[u][c] * HD;
 #pragma unroll
@@ -244,15 +251,20 @@ cast_kernel(const float *__restrict__ src, T *__restrict__ dst, const int64_t n)
 template <typename T, int LPI>
 static hipError_t launch_vec(const void *value, const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *go, void *gv, void *gl,
-                             void *ga, Dims d, hipStream_t st)
+                             void *ga, Dims d, bool scatter, hipStream_t st)
 {
     constexpr int QPB = kThreads / LPI;
     d.q_tiles = (d.Nq + QPB - 1) / QPB;
     const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_bwd_vec<T, LPI>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                       (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
-                       (float *)gv, (T *)gl, (T *)ga, d);
+    if (scatter)
+        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
+                           (float *)gv, (T *)gl, (T *)ga, d);
+    else
+        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
+                           (float *)nullptr, (T *)gl, (T *)ga, d);
     return hipGetLastError();
 }
 
@@ -272,12 +284,12 @@ static hipError_t launch_scalar(const void *value, const int64_t *shapes, const 
 template <typename T>
 static hipError_t dispatch_bwd(const void *value, const int64_t *shapes, const int64_t *start,
                                const void *loc, const void *attn, const void *go, void *gv, void *gl,
-                               void *ga, const Dims &d, hipStream_t st)
+                               void *ga, const Dims &d, bool scatter, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (d.D % VEC == 0) {
         switch (d.D / VEC) {
-#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, go, gv, gl, ga, d, st);
+#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, go, gv, gl, ga, d, scatter, st);
             MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
             default: break;
@@ -286,14 +298,26 @@ static hipError_t dispatch_bwd(const void *value, const int64_t *shapes, const i
     return launch_scalar<T>(value, shapes, start, loc, attn, go, gv, gl, ga, d, st);
 }
 
-hipError_t backward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
-                    const void *loc, const void *attn, const void *grad_out,
-                    void *gv, void *gl, void *ga, const Dims &d, hipStream_t st)
+bool bwd_has_vector_path(int dtype, const Dims &d)
 {
+    if (dtype == 3) return false;
+    const int vec = dtype == 0 ? 4 : 8;
+    if (d.D % vec) return false;
+    const int lpi = d.D / vec;
+    return lpi >= 1 && lpi <= 64 && (lpi & (lpi - 1)) == 0;
+}
+
+// scatter = true : grad_value accumulated here with atomics into the fp32/fp64 buffer gv
+// scatter = false: gv ignored (requires bwd_has_vector_path)
+hipError_t backward_taps(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                         const void *loc, const void *attn, const void *grad_out,
+                         void *gv, void *gl, void *ga, const Dims &d, bool scatter, hipStream_t st)
+{
+    if (!scatter && !bwd_has_vector_path(dtype, d)) return hipErrorInvalidValue;
     switch (dtype) {
-        case 0: return dispatch_bwd<float>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
-        case 1: return dispatch_bwd<half_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
-        case 2: return dispatch_bwd<bf16_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        case 0: return dispatch_bwd<float>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
+        case 1: return dispatch_bwd<half_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
+        case 2: return dispatch_bwd<bf16_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
         case 3: return launch_scalar<double>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
         default: return hipErrorInvalidValue;
     }

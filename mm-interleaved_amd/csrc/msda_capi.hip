@@ -88,11 +88,29 @@ int mmfs_msda_forward(int dtype, const void *value, const int64_t *shapes, const
     return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st);
 }
 
+static bool use_tiled(int dtype, const mmfs::Dims &d, unsigned flags)
+{
+    return (flags & MMFS_BWD_CANONICAL_LEVELS) && !(flags & MMFS_BWD_FORCE_ATOMIC) &&
+           mmfs::bwd_has_vector_path(dtype, d) && mmfs::bwd_value_tiled_supported(dtype, d);
+}
+
+int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                           int64_t L, int64_t Nq, int64_t P, unsigned flags)
+{
+    mmfs::Dims d;
+    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
+    if (use_tiled(dtype, d, flags)) return 0;
+    // atomic path: 16-bit storage accumulates into an fp32 image of grad_value
+    if (dtype == MMFS_F16 || dtype == MMFS_BF16) return B * S * H * D * 4;
+    return 0;
+}
+
 int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                        const void *loc, const void *attn, const void *grad_out,
-                       void *grad_value_acc, void *grad_loc, void *grad_attn,
+                       void *grad_value, void *grad_loc, void *grad_attn,
+                       void *workspace, int64_t workspace_bytes,
                        int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
-                       void *stream)
+                       unsigned flags, void *stream)
 {
     const int es = elem_size(dtype);
     if (!es) return MMFS_E_DTYPE;
@@ -101,22 +119,93 @@ int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_samples = B * Nq * H * L * P;
-    if (n_samples == 0) return MMFS_OK;              // grad_value_acc stays zero
-    if (!grad_loc || !grad_attn) return MMFS_E_NULLPTR;
-    if (S == 0 || D == 0) {
-        hipError_t e = hipMemsetAsync(grad_loc, 0, (size_t)n_samples * 2 * es, st);
-        if (e != hipSuccess) return (int)e;
-        return (int)hipMemsetAsync(grad_attn, 0, (size_t)n_samples * es, st);
+    const int64_t n_value = B * S * H * D;
+    if (n_value && !grad_value) return MMFS_E_NULLPTR;
+    if (n_samples == 0 || S == 0 || D == 0) {           // nothing flows: all gradients are zero
+        hipError_t e = hipSuccess;
+        if (n_value) e = hipMemsetAsync(grad_value, 0, (size_t)n_value * es, st);
+        if (e == hipSuccess && n_samples) {
+            if (!grad_loc || !grad_attn) return MMFS_E_NULLPTR;
+            e = hipMemsetAsync(grad_loc, 0, (size_t)n_samples * 2 * es, st);
+            if (e == hipSuccess) e = hipMemsetAsync(grad_attn, 0, (size_t)n_samples * es, st);
+        }
+        return (int)e;
     }
-    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value_acc)
+    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_loc || !grad_attn)
         return MMFS_E_NULLPTR;
     const int al = ((D * es) % 16 == 0) ? 16 : es;
-    if (misaligned(value, al) || misaligned(grad_out, al) || misaligned(loc, es) ||
-        misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es) ||
-        misaligned(grad_value_acc, dtype == MMFS_F64 ? 8 : 4))
+    if (misaligned(value, al) || misaligned(grad_out, al) || misaligned(grad_value, al) ||
+        misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es))
         return MMFS_E_ALIGN;
-    return (int)mmfs::backward(dtype, value, shapes, start, loc, attn, grad_out,
-                               grad_value_acc, grad_loc, grad_attn, d, st);
+
+    if (use_tiled(dtype, d, flags)) {
+        hipError_t e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out,
+                                           nullptr, grad_loc, grad_attn, d, false, st);
+        if (e != hipSuccess) return (int)e;
+        return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value, d, st);
+    }
+    // ---- float-atomic path
+    const bool narrow = (dtype == MMFS_F16 || dtype == MMFS_BF16);
+    void *acc = grad_value;
+    size_t acc_bytes = (size_t)n_value * es;
+    if (narrow) {
+        if (workspace_bytes < n_value * 4 || !workspace) return MMFS_E_NULLPTR;
+        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+        acc = workspace;
+        acc_bytes = (size_t)n_value * 4;
+    }
+    hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);              // reference: at::zeros, .cu:127
+    if (e != hipSuccess) return (int)e;
+    e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, acc, grad_loc, grad_attn,
+                            d, true, st);
+    if (e != hipSuccess) return (int)e;
+    if (narrow) e = mmfs::cast_from_f32(dtype, (const float *)acc, grad_value, n_value, st);   // .cu:156-165
+    return (int)e;
+}
+
+int mmfs_msda_backward_taps(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                            const void *loc, const void *attn, const void *grad_out,
+                            void *grad_loc, void *grad_attn,
+                            int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                            void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    if (B * Nq * H * L * P == 0) return MMFS_OK;
+    if (S == 0 || D == 0 || !mmfs::bwd_has_vector_path(dtype, d)) return MMFS_E_UNSUPPORTED;
+    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_loc || !grad_attn)
+        return MMFS_E_NULLPTR;
+    if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(loc, es) || misaligned(attn, es) ||
+        misaligned(grad_loc, es) || misaligned(grad_attn, es))
+        return MMFS_E_ALIGN;
+    return (int)mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc,
+                                    grad_attn, d, false, (hipStream_t)stream);
+}
+
+int mmfs_msda_backward_value(int dtype, const int64_t *shapes, const int64_t *start,
+                             const void *loc, const void *attn, const void *grad_out, void *grad_value,
+                             int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                             void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    const int64_t n_value = B * S * H * D;
+    if (n_value == 0) return MMFS_OK;
+    if (!grad_value) return MMFS_E_NULLPTR;
+    if (B * Nq * H * L * P == 0)
+        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
+    if (!mmfs::bwd_value_tiled_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    if (!shapes || !start || !loc || !attn || !grad_out) return MMFS_E_NULLPTR;
+    if (misaligned(grad_out, 16) || misaligned(grad_value, 16) || misaligned(loc, es) || misaligned(attn, es))
+        return MMFS_E_ALIGN;
+    return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value, d,
+                                           (hipStream_t)stream);
 }
 
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream)

@@ -122,10 +122,17 @@ __device__ __forceinline__ BlockCoord block_coord(const Dims &d, int queries_per
 {
     BlockCoord c;
     const int bid = blockIdx.x;
+#ifdef MMFS_LINEAR_MAP                 // experiment: (b, h, q-tile) order, q-tile fastest
+    c.q0 = (bid % d.q_tiles) * queries_per_block;
+    const int t = bid / d.q_tiles;
+    c.h = t % d.H;
+    c.b = t / d.H;
+#else
     c.h = bid % d.H;
     const int t = bid / d.H;
     c.q0 = (t % d.q_tiles) * queries_per_block;
     c.b = t / d.q_tiles;
+#endif
     return c;
 }
 

@@ -25,7 +25,10 @@ namespace mmfs {
 
 constexpr int kThreads = 256;
 constexpr int kRecsPerBlock = 512;      // tap records staged per chunk (16 KiB)
-constexpr int kUnroll = 4;              // taps in flight per lane (16 row reads)
+#ifndef MMFS_FWD_UNROLL
+#define MMFS_FWD_UNROLL 4
+#endif
+constexpr int kUnroll = MMFS_FWD_UNROLL;   // taps in flight per lane (4x row reads each)
 
 struct alignas(16) FwdRec {
     int row[4];

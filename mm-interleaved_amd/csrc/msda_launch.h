@@ -12,9 +12,21 @@ namespace mmfs {
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
 
-hipError_t backward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
-                    const void *loc, const void *attn, const void *grad_out,
-                    void *grad_value_acc, void *grad_loc, void *grad_attn, const Dims &d, hipStream_t st);
+// Location / attention-weight gradients (always) and, when scatter is true, grad_value
+// accumulated with global float atomics into the fp32 (fp64 for dtype 3) buffer gv_acc,
+// which the caller must have zero-filled.            [msda_bwd.hip]
+hipError_t backward_taps(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                         const void *loc, const void *attn, const void *grad_out,
+                         void *gv_acc, void *grad_loc, void *grad_attn, const Dims &d, bool scatter,
+                         hipStream_t st);
+bool bwd_has_vector_path(int dtype, const Dims &d);
+
+// grad_value by pixel-stationary tiles: no atomics, no fp32 buffer, every element of
+// grad_value (storage dtype) written exactly once.     [msda_bwd_value.hip]
+bool bwd_value_tiled_supported(int dtype, const Dims &d);
+hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
+                                const void *loc, const void *attn, const void *grad_out,
+                                void *grad_value, const Dims &d, hipStream_t st);
 
 hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st);
 

@@ -22,8 +22,9 @@ def declared_functions():
 
 def test_header_declares_the_path():
     names = declared_functions()
-    for n in ("mmfs_msda_forward", "mmfs_msda_backward", "mmfs_msda_cast_from_f32",
-              "mmfs_msda_abi_version", "mmfs_msda_status_string"):
+    for n in ("mmfs_msda_forward", "mmfs_msda_backward", "mmfs_msda_backward_taps",
+              "mmfs_msda_backward_value", "mmfs_msda_backward_workspace_bytes",
+              "mmfs_msda_cast_from_f32", "mmfs_msda_abi_version", "mmfs_msda_status_string"):
         assert n in names
 
 
@@ -33,7 +34,8 @@ def test_library_exports_every_declared_symbol():
     for n in declared_functions():
         assert hasattr(lib, n), f"{n} declared in include/mmfs_msda.h but not exported"
     lib.mmfs_msda_abi_version.restype = ctypes.c_int
-    assert lib.mmfs_msda_abi_version() == 1
+    want = int(re.search(r"#define\s+MMFS_MSDA_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.mmfs_msda_abi_version() == want
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -70,3 +72,28 @@ def test_autograd_function_surface():
     with pytest.raises(RuntimeError):
         ms_deform_attn_core_pytorch(torch.zeros(1, 4, 1, 8), [(2, 2)], torch.zeros(1, 1, 1, 1, 1, 2),
                                     torch.zeros(1, 1, 1, 1, 1))
+
+
+def test_backward_workspace_query_is_host_only():
+    lib = ctypes.CDLL(LIB)
+    i64 = ctypes.c_int64
+    f = lib.mmfs_msda_backward_workspace_bytes
+    f.restype = i64
+    f.argtypes = [ctypes.c_int] + [i64] * 7 + [ctypes.c_uint]
+    dims = (8, 5440, 8, 128, 4, 4096, 4)
+    assert f(2, *dims, 1) == 0                               # bf16, canonical levels: pixel-stationary
+    assert f(2, *dims, 0) == 8 * 5440 * 8 * 128 * 4          # unknown level table: fp32 image for atomics
+    assert f(2, *dims, 3) == 8 * 5440 * 8 * 128 * 4          # forced atomic
+    assert f(0, *dims, 0) == 0                               # fp32 accumulates in grad_value itself
+    assert f(2, 8, 5440, 8, 24, 4, 4096, 4, 1) > 0           # D=24: no vector path
+
+
+def test_canonical_level_table_detection_and_cache():
+    import MultiScaleDeformableAttention as MSDA
+    sh = torch.tensor([[4, 4], [2, 2]]); st = torch.tensor([0, 16])
+    assert MSDA.levels_are_canonical(sh, st, 20)
+    assert getattr(sh, "_mmfs_canonical")[1] is True
+    assert not MSDA.levels_are_canonical(sh, st, 21)          # S mismatch (gap at the end)
+    assert not MSDA.levels_are_canonical(sh, torch.tensor([0, 15]), 20)   # overlap
+    st[1] = 17                                               # in-place edit invalidates the cache
+    assert not MSDA.levels_are_canonical(sh, st, 20)

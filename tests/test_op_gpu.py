@@ -103,6 +103,47 @@ def test_hip_matches_oracle_seeded(case, dtype):
     check(run_hip(x, dtype), run_oracle(x), dtype, str(case[:5]))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES[:5], ids=[str(i) for i in range(5)])
+def test_atomic_backward_path_matches_oracle(case, dtype, monkeypatch):
+    """The float-atomic fallback (non-canonical level tables, odd head widths) stays correct."""
+    import MultiScaleDeformableAttention as MSDA
+    monkeypatch.setattr(MSDA, "_bwd_algo", "atomic")
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=9, loc_range=(-0.15, 1.15), dtype=dtype)
+    check(run_hip(x, dtype), run_oracle(x), dtype, "atomic " + str(case[:5]))
+
+
+def test_non_canonical_level_table_falls_back_and_is_right():
+    """Levels stored with a gap and in reverse order inside value: legal for the op
+    (it only reads start[l]); the pixel-stationary kernel must not be used."""
+    g = torch.Generator().manual_seed(3)
+    B, H, D, Nq, P = 2, 4, 32, 21, 4
+    shapes = torch.tensor([(4, 6), (3, 3)], dtype=torch.long)
+    start = torch.tensor([12, 0], dtype=torch.long)          # level 1 first (9 rows), gap 9..11, level 0 at 12
+    S = 12 + 24 + 5
+    rt = lambda t: t.double()
+    x = dict(value=rt(torch.rand(B, S, H, D, generator=g)), shapes=shapes, start=start,
+             loc=rt(torch.rand(B, Nq, H, 2, P, 2, generator=g) * 1.2 - 0.1),
+             attn=rt(torch.rand(B, Nq, H, 2, P, generator=g)), grad=rt(torch.randn(B, Nq, H * D, generator=g)))
+    got, want = run_hip(x, torch.float32), run_oracle(x)
+    check(got, want, torch.float32, "gapped levels")
+    assert not got[1][:, 9:12].any() and not got[1][:, 36:].any()      # untouched rows are zero
+
+
+def test_skewed_locations_overflow_the_tile_lists():
+    """All queries sample the same spot: one pixel receives Nq*P records, far more than a
+    workgroup's LDS list holds -> exercises the per-pixel query-range rounds."""
+    B, H, D, Nq, P = 1, 2, 128, 3000, 4
+    shapes = [(8, 8), (4, 4)]
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=13, dtype=torch.bfloat16)
+    x["loc"] = (x["loc"] * 0.02 + 0.40).to(torch.bfloat16).double()    # tight cluster
+    check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "skew")
+    x32 = make_inputs(B, H, 32, Nq, P, shapes, seed=14, dtype=torch.float32)
+    x32["loc"] = x32["loc"] * 0.0 + 0.3                                 # exactly one spot
+    check(run_hip(x32, torch.float32), run_oracle(x32), torch.float32, "skew32")
+
+
 def test_direct_extension_calls_match_autograd_path():
     x = make_inputs(2, 4, 32, 19, 4, [(6, 5), (3, 3)], seed=11, dtype=torch.float32)
     a = run_hip(x, torch.float32, use_autograd=True)
@@ -212,7 +253,7 @@ def test_full_size_properties(name, cfg, dtype):
     x = dict(value=value[:1].double().cpu(), shapes=sh.cpu(), start=start.cpu(), loc=loc[:1, qs].double().cpu(),
              attn=attn[:1, qs].double().cpu(), grad=grad[:1, qs].double().cpu())
     want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
-    assert max_abs(out[:1, qs].double().cpu().numpy(), want) <= TOL[dtype]
+    assert max_abs(out[:1, qs].detach().double().cpu().numpy(), want) <= TOL[dtype]
     _, gl, ga = msda_oracle.backward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"], x["grad"])
     assert max_abs(a.grad[:1, qs].double().cpu().numpy(), ga) <= TOL[dtype] * max(1.0, np.abs(ga).max())
     assert max_abs(l.grad[:1, qs].double().cpu().numpy(), gl) <= TOL[dtype] * max(1.0, np.abs(gl).max())

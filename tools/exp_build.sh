@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds experimental variants of libmmfs_msda.so into mm-interleaved_amd/csrc/build/exp/
+# usage: tools/exp_build.sh name "-DFLAG=1 -DOTHER=2"
+set -e
+cd "$(dirname "$0")/../mm-interleaved_amd/csrc"
+name=$1; flags=$2
+mkdir -p build/exp/$name
+for f in msda_fwd msda_bwd msda_capi; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function $flags -c $f.hip -o build/exp/$name/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/$name.so build/exp/$name/*.o
+echo built build/exp/$name.so
