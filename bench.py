@@ -63,7 +63,10 @@ def algorithmic_bytes(w, e):
     pts = B * Nq * H * Leff * P
     fwd = e * (B * S * C + 3 * pts + B * Nq * C)
     bwd = e * (2 * B * S * C + 6 * pts + B * Nq * C)
-    return dict(msda_fwd=fwd, msda_bwd=bwd, fwdbwd=fwd + bwd)
+    # the two-stage backward: each kernel priced on what IT must touch once
+    taps = e * (B * S * C + 6 * pts + B * Nq * C)       # value, loc, attn, grad_out -> grad_loc, grad_attn
+    val = e * (B * S * C + 3 * pts + B * Nq * C)        # loc, attn, grad_out -> grad_value
+    return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value=val, fwdbwd=fwd + bwd)
 
 
 def make_inputs(w, device, seed):

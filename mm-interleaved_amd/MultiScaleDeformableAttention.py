@@ -205,7 +205,7 @@ def levels_are_canonical(spatial_shapes, level_start_index, S):
     return canon
 
 
-def ms_deform_attn_backward(def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step):
     """Reference: ms_deform_attn_cuda_backward, src/cuda/ms_deform_attn_cuda.cu:84-166.
     Returns [grad_value, grad_sampling_loc, grad_attn_weight] shaped and typed like the
