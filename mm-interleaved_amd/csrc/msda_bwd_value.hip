@@ -34,15 +34,16 @@ namespace mmfs {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;          // one workgroup per CU: 16 waves share one big record list
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTilePx = 1024;        // pixels per tile (counter arrays: 2 x 4 KiB)
-constexpr int kListCap = 6144;          // {q, weight} records per round (48 KiB)
-constexpr int kUnroll = 8;              // records in flight per lane group
+constexpr int kListCap = 12288;         // {q, weight} records per round (96 KiB)
+constexpr int kUnroll = 8;              // grad_out rows in flight per lane group
+constexpr int kScanUnroll = 4;          // queries in flight per thread while scanning
 
 struct TileParams {
     int tiles_bound;   // host upper bound on tiles per (b, h) slice
-    int nt_min;        // minimum tiles per level (load balance)
+    int nt_min;        // minimum tiles per level (load balance, list capacity)
 };
 
 struct Tile {
@@ -85,16 +86,10 @@ __device__ Tile plan_tile(const int64_t *__restrict__ shapes, const int64_t *__r
 // Exclusive prefix sum over a[0..n) (n <= kMaxTilePx), total left in a[n].
 __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
 {
+    static_assert(kMaxTilePx == kThreads, "one counter per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = kMaxTilePx / kThreads;                   // 4 consecutive entries per thread
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid * PER + i;
-        v[i] = idx < n ? a[idx] : 0u;
-        sum += v[i];
-    }
-    uint32_t inc = sum;
+    const uint32_t v = tid < n ? a[tid] : 0u;
+    uint32_t inc = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off, 64);
@@ -104,116 +99,146 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    uint32_t run = base + inc - sum;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid * PER + i;
-        if (idx < n) a[idx] = run;
-        run += v[i];
-    }
-    if (tid == kThreads - 1) a[n] = run;
+    if (tid < n) a[tid] = base + inc - v;
+    if (tid == kThreads - 1) a[n] = base + inc;
     __syncthreads();
 }
 
 enum ScanMode { kCount = 0, kScatter = 1 };
 
-// Scan the sampling locations of queries [q_lo, q_hi) at the tile's level and, for every
-// tap corner that lands on a tile pixel in [p_lo, p_hi):
+// One sample against the tile: for every tap corner on a tile pixel in [p_lo, p_hi)
 //   kCount  : off[pixel] += 1
 //   kScatter: list[off[pixel] - base + cur[pixel]++] = {q, bilinear weight * attention}
-template <typename T, int MODE>
+template <int MODE>
+__device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q, const Tile &tl, int tw,
+                                             int p_lo, int p_hi, uint32_t base,
+                                             uint32_t *off, uint32_t *cur, uint2 *list)
+{
+    const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
+    const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
+    if (!inside) return;
+    const float yf = floorf(y), xf = floorf(x);
+    const int y0 = (int)yf, x0 = (int)xf;
+    // quick reject: the 2x2 footprint misses the tile
+    if (y0 + 1 < tl.ya || y0 >= tl.yb || x0 + 1 < tl.xa || x0 >= tl.xb) return;
+    const float fy = y - yf, fx = x - xf;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+        // a corner outside the map is also outside every tile
+        if (yy < tl.ya || yy >= tl.yb || xx < tl.xa || xx >= tl.xb) continue;
+        const int pl = (yy - tl.ya) * tw + (xx - tl.xa);
+        if (pl < p_lo || pl >= p_hi) continue;
+        if (MODE == kCount) {
+            atomicAdd(&off[pl], 1u);
+        } else {
+            const float wy = (c >> 1) ? fy : 1.f - fy, wx = (c & 1) ? fx : 1.f - fx;
+            const uint32_t slot = off[pl] - base + atomicAdd(&cur[pl], 1u);
+            list[slot] = make_uint2((uint32_t)q, __float_as_uint(wy * wx * a));
+        }
+    }
+}
+
+// Scan the sampling locations of queries [q_lo, q_hi) at the tile's level.
+// NV > 0: the P samples of one (b,q,h,level) are NV 16-byte vectors of locations (and NV
+//         8-byte vectors of weights); kScanUnroll queries are loaded before any is used.
+// NV = 0: any P, scalar loads.
+template <typename T, int MODE, int NV>
 __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T *__restrict__ attn,
                                              const Dims &d, const Tile &tl, int b, int h,
                                              int q_lo, int q_hi, int p_lo, int p_hi, uint32_t base,
                                              uint32_t *off, uint32_t *cur, uint2 *list)
 {
     const int tw = tl.xb - tl.xa;
-    for (int q = q_lo + (int)threadIdx.x; q < q_hi; q += kThreads) {
-        const int64_t s0 = ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + tl.level) * d.P;
-        for (int p = 0; p < d.P; ++p) {
-            const float lx = to_f32(loc[2 * (s0 + p)]), ly = to_f32(loc[2 * (s0 + p) + 1]);
-            const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
-            const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
-            if (!inside) continue;
-            const float yf = floorf(y), xf = floorf(x);
-            const int y0 = (int)yf, x0 = (int)xf;
-            // quick reject: the 2x2 footprint misses the tile
-            if (y0 + 1 < tl.ya || y0 >= tl.yb || x0 + 1 < tl.xa || x0 >= tl.xb) continue;
-            const float fy = y - yf, fx = x - xf;
-            float a = 0.f;
-            if (MODE == kScatter) a = to_f32(attn[s0 + p]);
+    const int64_t qstride = (int64_t)d.H * d.L * d.P;          // samples between consecutive queries
+    const int64_t s_first = (((int64_t)b * d.Nq * d.H + h) * d.L + tl.level) * d.P;
+    if (NV == 0) {
+        for (int q = q_lo + (int)threadIdx.x; q < q_hi; q += kThreads) {
+            const int64_t s0 = s_first + q * qstride;
+            for (int p = 0; p < d.P; ++p)
+                visit_sample<MODE>(to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]),
+                                   MODE == kScatter ? to_f32(attn[s0 + p]) : 0.f, q, tl, tw, p_lo, p_hi,
+                                   base, off, cur, list);
+        }
+        return;
+    }
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;                                  // location scalars per 16 bytes
+    constexpr int NVV = NV > 0 ? NV : 1;
+    for (int q0 = q_lo + (int)threadIdx.x; q0 < q_hi; q0 += kThreads * kScanUnroll) {
+        uint4 lraw[kScanUnroll][NVV];
+        uint2 araw[kScanUnroll][NVV];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-                // a corner outside the map is also outside every tile
-                if (yy < tl.ya || yy >= tl.yb || xx < tl.xa || xx >= tl.xb) continue;
-                const int pl = (yy - tl.ya) * tw + (xx - tl.xa);
-                if (pl < p_lo || pl >= p_hi) continue;
-                if (MODE == kCount) {
-                    atomicAdd(&off[pl], 1u);
-                } else {
-                    const float wy = (c >> 1) ? fy : 1.f - fy, wx = (c & 1) ? fx : 1.f - fx;
-                    const uint32_t slot = off[pl] - base + atomicAdd(&cur[pl], 1u);
-                    list[slot] = make_uint2((uint32_t)q, __float_as_uint(wy * wx * a));
-                }
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = q0 + u * kThreads;
+            const int64_t s0 = s_first + (int64_t)min(q, q_hi - 1) * qstride;
+#pragma unroll
+            for (int v = 0; v < NVV; ++v) {
+                lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
+                if (MODE == kScatter) araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
+                else araw[u][v] = make_uint2(0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = q0 + u * kThreads;
+            if (q >= q_hi) break;
+#pragma unroll
+            for (int v = 0; v < NVV; ++v) {
+                float l[VEC], a[VEC];
+                V::unpack(lraw[u][v], l);
+                V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);   // first VEC/2 valid
+#pragma unroll
+                for (int i = 0; i < VEC / 2; ++i)
+                    visit_sample<MODE>(l[2 * i], l[2 * i + 1], a[i], q, tl, tw, p_lo, p_hi, base, off, cur, list);
             }
         }
     }
 }
 
-template <typename T, int CPL> struct ChanVec;          // CPL channels of T <-> floats
-template <typename T, int CPL> struct ChanVec {
-    static __device__ __forceinline__ void load(const T *p, float (&o)[CPL]) {
-        T tmp[CPL];
-        __builtin_memcpy(tmp, __builtin_assume_aligned(p, sizeof(T) * CPL), sizeof(T) * CPL);
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) o[i] = to_f32(tmp[i]);
-    }
-    static __device__ __forceinline__ void store(T *p, const float (&v)[CPL]) {
-        T tmp[CPL];
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) tmp[i] = (T)v[i];
-        __builtin_memcpy(__builtin_assume_aligned(p, sizeof(T) * CPL), tmp, sizeof(T) * CPL);
-    }
-};
-
-// acc += sum over records first, first+step, ... (< end) of weight * grad_out[q, h, my channels]
-template <typename T, int CPL>
+// acc += sum over records first, first+step, ... (< end) of weight * grad_out[q, h, my 16 bytes]
+template <typename T>
 __device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int first, int end, int step,
-                                           const T *__restrict__ gslice, int64_t HD, float (&acc)[CPL])
+                                           int iters, const T *__restrict__ gslice, int64_t HD,
+                                           float (&acc)[Vec16<T>::N])
 {
-    for (int e = first; e < end; e += kUnroll * step) {
-        float g[kUnroll][CPL], w[kUnroll];
+    typedef Vec16<T> V;
+    int e = first;
+    for (int it = 0; it < iters; ++it, e += kUnroll * step) {
+        uint4 raw[kUnroll];
+        float w[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int ee = e + u * step;
             const bool ok = ee < end;
             const uint2 rec = list[ok ? ee : 0];
             w[u] = ok ? __uint_as_float(rec.y) : 0.f;
-            ChanVec<T, CPL>::load(gslice + (int64_t)(ok ? rec.x : 0u) * HD, g[u]);
-            if (!ok) {
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) g[u][i] = 0.f;
-            }
+            raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? rec.x : 0u) * HD);
+            if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);       // 0 * Inf must not leak
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
+        for (int u = 0; u < kUnroll; ++u) {
+            float g[V::N];
+            V::unpack(raw[u], g);
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) acc[i] = fmaf(w[u], g[u][i], acc[i]);
+            for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
+        }
     }
 }
 
-// LPS lanes own the D = LPS*CPL channels of one pixel; a wave works on 64/LPS pixels.
-template <typename T, int LPS, int CPL>
+// LPS lanes own the D = LPS*VEC channels of one pixel (16 bytes per lane, as in the forward).
+template <typename T, int LPS, int NV>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                      const T *__restrict__ loc, const T *__restrict__ attn,
                      const T *__restrict__ grad_out, T *__restrict__ grad_value,
                      const Dims d, const TileParams tp)
 {
-    constexpr int GPW = 64 / LPS;                   // pixel groups per wave
-    constexpr int GROUPS = kWaves * GPW;            // pixel groups per workgroup
-    constexpr int D = LPS * CPL;
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int GPW = 64 / LPS;                   // lane groups per wave
+    constexpr int GROUPS = kWaves * GPW;            // lane groups per workgroup
+    constexpr int D = LPS * VEC;
     static_assert(GROUPS * D * 4 <= kListCap * 8, "combine scratch must fit the record list");
     __shared__ uint32_t off[kMaxTilePx + 1];
     __shared__ uint32_t cur[kMaxTilePx];
@@ -230,14 +255,15 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     const int tid = threadIdx.x;
     const int tw = tl.xb - tl.xa;
     const int npx = (tl.yb - tl.ya) * tw;
-    const int gid = tid / LPS, lig = tid % LPS;     // pixel group of this lane, lane in group
+    const int gid = tid / LPS, lig = tid % LPS;     // lane group, lane in group
     const int64_t HD = (int64_t)d.H * d.D;
-    const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * CPL;
-    T *vslice = grad_value + ((int64_t)b * d.S * d.H + h) * d.D + lig * CPL;
+    const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
+    T *vslice = grad_value + ((int64_t)b * d.S * d.H + h) * d.D + lig * VEC;
+    float *scratch = reinterpret_cast<float *>(list);            // reused between rounds
 
     for (int i = tid; i < npx; i += kThreads) off[i] = 0u;
     __syncthreads();
-    scan_samples<T, kCount>(loc, attn, d, tl, b, h, 0, d.Nq, 0, npx, 0u, off, cur, list);
+    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, 0, d.Nq, 0, npx, 0u, off, cur, list);
     __syncthreads();
     block_exclusive_scan(off, npx, wave_tot);
 
@@ -250,161 +276,143 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
             const int mid = (lo + hi + 1) >> 1;
             if (off[mid] - base <= (uint32_t)kListCap) lo = mid; else hi = mid - 1;
         }
-        const int p_hi = lo;
-        if (p_hi > p_lo) {
-            // ---- a range of pixels whose records fit: sort them, one pixel per lane group
-            const uint32_t nrec = off[p_hi] - base;
-            if (nrec) {
-                for (int i = p_lo + tid; i < p_hi; i += kThreads) cur[i] = 0u;
-                __syncthreads();
-                scan_samples<T, kScatter>(loc, attn, d, tl, b, h, 0, d.Nq, p_lo, p_hi, base, off, cur, list);
-                __syncthreads();
-            }
-            for (int p0 = p_lo; p0 < p_hi; p0 += GROUPS) {
-                const int p = p0 + gid;
-                const bool act = p < p_hi;
-                const int first = act ? (int)(off[p] - base) : 0;
-                int n = act ? (int)(off[p + 1] - off[p]) : 0;
-                // groups of one wave iterate together: run to the longest list in the wave
-                int nmax = n;
-                if (GPW > 1) {
-#pragma unroll
-                    for (int o = LPS; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-                }
-                float acc[CPL];
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
-                if (GPW > 1) {
-                    // pad the shorter lists with zero-weight reads of their first record
-                    for (int e = 0; e < nmax; e += kUnroll) {
-                        float g[kUnroll][CPL], w[kUnroll];
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const bool ok = e + u < n;
-                            const uint2 rec = list[ok ? first + e + u : 0];
-                            w[u] = ok ? __uint_as_float(rec.y) : 0.f;
-                            ChanVec<T, CPL>::load(gslice + (int64_t)(ok ? rec.x : 0u) * HD, g[u]);
-                            if (!ok) {
-#pragma unroll
-                                for (int i = 0; i < CPL; ++i) g[u][i] = 0.f;
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-                            for (int i = 0; i < CPL; ++i) acc[i] = fmaf(w[u], g[u][i], acc[i]);
-                    }
-                } else {
-                    reduce_run<T, CPL>(list, first, first + n, 1, gslice, HD, acc);
-                }
-                if (act) {
-                    const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-                    ChanVec<T, CPL>::store(vslice + (int64_t)pg * HD, acc);
-                }
-            }
-            __syncthreads();                        // list and cur are reused by the next round
-            p_lo = p_hi;
-        } else {
-            // ---- one pixel with more records than the list holds: rounds over query ranges.
-            // A sample puts at most one corner on a given pixel, so qw queries give <= qw*P records.
-            const int qw = max(1, kListCap / max(1, d.P));
-            float acc[CPL];
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
-            for (int q0 = 0; q0 < d.Nq; q0 += qw) {
-                if (tid == 0) cur[p_lo] = 0u;
-                __syncthreads();
-                // records are placed at cur[] alone: pass base = off[p_lo] so slot = cur
-                scan_samples<T, kScatter>(loc, attn, d, tl, b, h, q0, min(d.Nq, q0 + qw), p_lo, p_lo + 1,
-                                          off[p_lo], off, cur, list);
-                __syncthreads();
-                const int n = (int)cur[p_lo];
-                // all lane groups share this pixel's records: group g takes g, g+GROUPS, ...
-                reduce_run<T, CPL>(list, gid, n, GROUPS, gslice, HD, acc);
-                __syncthreads();
-            }
-            // combine the GROUPS partial rows through LDS (the list is free now)
-            float *scratch = reinterpret_cast<float *>(list);
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) scratch[gid * D + lig * CPL + i] = acc[i];
-            __syncthreads();
-            if (gid == 0) {
-                float tot[CPL];
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) {
-                    tot[i] = 0.f;
-                    for (int g2 = 0; g2 < GROUPS; ++g2) tot[i] += scratch[g2 * D + lig * CPL + i];
-                }
-                const int p = p_lo;
-                const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-                ChanVec<T, CPL>::store(vslice + (int64_t)pg * HD, tot);
-            }
-            __syncthreads();
-            p_lo += 1;
-        }
-    }
-}
+        const int p_hi = max(lo, p_lo + 1);
+        const bool big = lo == p_lo;                 // one pixel alone overflows the list
+        const int np = p_hi - p_lo;
+        // k lane groups share a pixel when the round has fewer pixels than groups
+        const int k = np >= GROUPS ? 1 : GROUPS / np;
+        // a pixel that overflows the list is fed in query ranges: a sample puts at most one
+        // corner on a given pixel, so qw queries give at most qw*P records
+        const int qw = big ? max(1, kListCap / max(1, d.P)) : d.Nq;
 
-// lanes per pixel / channels per lane for a head width, or false
-bool lane_map(int dtype, int D, int *lps, int *cpl)
-{
-    const int es = dtype == 0 ? 4 : 2;
-    if (dtype != 0 && dtype != 1 && dtype != 2) return false;
-    if ((D * es) % 4) return false;
-    const int words = D * es / 4;                      // 4-byte words per pixel row
-    int l = words >= 64 ? 64 : words;
-    if (l < 4 || (l & (l - 1))) return false;
-    if (D % l) return false;
-    const int c = D / l;
-    if (c * es > 16 || (c & (c - 1))) return false;
-    *lps = l; *cpl = c;
-    return true;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        const int my_p = p_lo + gid / k, sub = gid % k;          // used when k > 1 (or np <= GROUPS)
+
+        for (int q0 = 0; q0 < d.Nq; q0 += qw) {
+            for (int i = p_lo + tid; i < p_hi; i += kThreads) cur[i] = 0u;
+            __syncthreads();
+            if (off[p_hi] - base)
+                scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, q0, min(d.Nq, q0 + qw), p_lo, p_hi,
+                                              base, off, cur, list);
+            __syncthreads();
+            if (k == 1 && np > GROUPS) {
+                // ---- many pixels: one lane group per pixel, several pixels in turn
+                for (int p0 = p_lo; p0 < p_hi; p0 += GROUPS) {
+                    const int p = p0 + gid;
+                    const bool act = p < p_hi;
+                    const int first = act ? (int)(off[p] - base) : 0;
+                    const int n = act ? (int)(off[p + 1] - off[p]) : 0;
+                    int iters = (n + kUnroll - 1) / kUnroll;
+#pragma unroll
+                    for (int o = LPS; o < 64; o <<= 1) iters = max(iters, __shfl_xor(iters, o, 64));
+                    float a2[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) a2[i] = 0.f;
+                    reduce_run<T>(list, first, first + n, 1, iters, gslice, HD, a2);
+                    if (act) {
+                        const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
+                        *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(a2);
+                    }
+                }
+            } else {
+                // ---- few pixels (coarse levels, hot spots): k groups stride through one pixel's run
+                const bool act = my_p < p_hi && gid < np * k;
+                const int first = act ? (int)(off[my_p] - base) : 0;
+                const int n = act ? (int)(big ? cur[my_p] : off[my_p + 1] - off[my_p]) : 0;
+                const int mine = n > sub ? (n - sub + k - 1) / k : 0;
+                int iters = (mine + kUnroll - 1) / kUnroll;
+#pragma unroll
+                for (int o = LPS; o < 64; o <<= 1) iters = max(iters, __shfl_xor(iters, o, 64));
+                reduce_run<T>(list, first + sub, first + n, k, iters, gslice, HD, acc);
+            }
+            __syncthreads();                         // list and cur are reused
+        }
+        if (!(k == 1 && np > GROUPS)) {
+            // combine the k partial rows of every pixel through LDS (the list is free now)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
+            __syncthreads();
+            if (sub == 0 && my_p < p_hi && gid < np * k) {
+                float tot[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    tot[i] = 0.f;
+                    for (int g2 = 0; g2 < k; ++g2) tot[i] += scratch[(gid + g2) * D + lig * VEC + i];
+                }
+                const int pg = tl.lstart + (tl.ya + my_p / tw) * tl.Wl + tl.xa + my_p % tw;
+                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(tot);
+            }
+            __syncthreads();
+        }
+        p_lo = p_hi;
+    }
 }
 
 TileParams make_params(const Dims &d)
 {
     TileParams tp;
-    // aim at >= 8 tiles per CU over the whole launch (256 CUs), at least 1 per level
+    // (1) balance: aim at >= 8 tiles per CU over the whole launch (256 CUs);
+    // (2) capacity: a level feeds Nq*P*4 records per (b, h); keep a tile's expected share
+    //     under ~85 % of the list so one scatter round usually suffices
     const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
-    int nt = (int)std::min<int64_t>(64, std::max<int64_t>(1, (2048 + slices - 1) / slices));
-    tp.nt_min = nt;
+    int64_t nt = std::max<int64_t>(1, (2048 + slices - 1) / slices);
+    const int64_t per_level = (int64_t)d.Nq * d.P * 4;
+    nt = std::max<int64_t>(nt, (per_level * 20 / 17 + kListCap - 1) / kListCap);
+    tp.nt_min = (int)std::min<int64_t>(nt, 256);
     // tiles per level <= 2*nt_l + 1 with nt_l <= nt_min + px_l/kMaxTilePx + 1 (see plan_tile)
-    const int64_t bound = 2LL * d.L * (nt + 1) + 2LL * ((d.S + kMaxTilePx - 1) / kMaxTilePx) + d.L;
+    const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((d.S + kMaxTilePx - 1) / kMaxTilePx) + d.L;
     tp.tiles_bound = (int)std::min<int64_t>(bound, 0x3fffffff);
     return tp;
 }
 
-template <typename T, int LPS, int CPL>
+template <typename T, int LPS, int NV>
 hipError_t launch(const int64_t *shapes, const int64_t *start, const void *loc, const void *attn,
                   const void *go, void *gv, const Dims &d, hipStream_t st)
 {
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, CPL>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
     return hipGetLastError();
 }
 
-template <typename T>
-hipError_t dispatch(int lps, int cpl, const int64_t *shapes, const int64_t *start, const void *loc,
-                    const void *attn, const void *go, void *gv, const Dims &d, hipStream_t st)
+template <typename T, int LPS>
+hipError_t dispatch_nv(int nv, const int64_t *shapes, const int64_t *start, const void *loc,
+                       const void *attn, const void *go, void *gv, const Dims &d, hipStream_t st)
 {
-    // 16-bit storage: 2 channels per 4-byte word, fp32: 1; wider per-lane vectors once D > 64 words
-    constexpr int C0 = 4 / (int)sizeof(T);
-#define MMFS_CASE(L_, C_) if (lps == L_ && cpl == C_) return launch<T, L_, C_>(shapes, start, loc, attn, go, gv, d, st);
-    MMFS_CASE(64, C0) MMFS_CASE(64, 2 * C0) MMFS_CASE(64, 4 * C0)
-    MMFS_CASE(32, C0) MMFS_CASE(16, C0) MMFS_CASE(8, C0) MMFS_CASE(4, C0)
+    switch (nv) {
+        case 1: return launch<T, LPS, 1>(shapes, start, loc, attn, go, gv, d, st);
+        case 2: return launch<T, LPS, 2>(shapes, start, loc, attn, go, gv, d, st);
+        default: return launch<T, LPS, 0>(shapes, start, loc, attn, go, gv, d, st);
+    }
+}
+
+template <typename T>
+hipError_t dispatch(const int64_t *shapes, const int64_t *start, const void *loc, const void *attn,
+                    const void *go, void *gv, const Dims &d, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    // vectorised scan when the P locations of a (b,q,h,level) are whole, aligned 16-byte vectors
+    const int loc_bytes = d.P * 2 * (int)sizeof(T);
+    int nv = 0;
+    if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2 && ((uintptr_t)loc % 16) == 0 && ((uintptr_t)attn % 8) == 0)
+        nv = loc_bytes / 16;
+    switch (d.D / VEC) {
+#define MMFS_CASE(n) case n: return dispatch_nv<T, n>(nv, shapes, start, loc, attn, go, gv, d, st);
+        MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
-    return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
 bool bwd_value_tiled_supported(int dtype, const Dims &d)
 {
-    int lps, cpl;
-    if (!lane_map(dtype, d.D, &lps, &cpl)) return false;
+    if (!bwd_has_vector_path(dtype, d)) return false;
     if (d.P > kListCap) return false;
     const TileParams tp = make_params(d);
     return (int64_t)d.B * d.H * tp.tiles_bound <= 0x7fffffffLL;
@@ -414,12 +422,11 @@ hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t 
                                 const void *loc, const void *attn, const void *grad_out,
                                 void *grad_value, const Dims &d, hipStream_t st)
 {
-    int lps, cpl;
-    if (!lane_map(dtype, d.D, &lps, &cpl)) return hipErrorInvalidValue;
+    if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     switch (dtype) {
-        case 0: return dispatch<float>(lps, cpl, shapes, start, loc, attn, grad_out, grad_value, d, st);
-        case 1: return dispatch<half_t>(lps, cpl, shapes, start, loc, attn, grad_out, grad_value, d, st);
-        case 2: return dispatch<bf16_t>(lps, cpl, shapes, start, loc, attn, grad_out, grad_value, d, st);
+        case 0: return dispatch<float>(shapes, start, loc, attn, grad_out, grad_value, d, st);
+        case 1: return dispatch<half_t>(shapes, start, loc, attn, grad_out, grad_value, d, st);
+        case 2: return dispatch<bf16_t>(shapes, start, loc, attn, grad_out, grad_value, d, st);
         default: return hipErrorInvalidValue;
     }
 }
