@@ -91,6 +91,8 @@ int mmfs_msda_forward(int dtype,
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.
+ * Pixel-stationary path: re-packed copies of loc/attn, 3*B*Nq*H*L*P elements; atomic path
+ * with 16-bit storage: an fp32 image of grad_value.
  */
 int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
                                            int64_t L, int64_t Nq, int64_t P, unsigned flags);
@@ -141,6 +143,7 @@ int mmfs_msda_backward_value(int dtype,
                              const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *grad_out,
                              void *grad_value,
+                             void *workspace, int64_t workspace_bytes,   /* as for mmfs_msda_backward */
                              int64_t B, int64_t S, int64_t H, int64_t D,
                              int64_t L, int64_t Nq, int64_t P, void *stream);
 

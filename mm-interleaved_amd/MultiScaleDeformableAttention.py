@@ -56,7 +56,7 @@ _lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes
 _lib.mmfs_msda_backward_taps.restype = _int
 _lib.mmfs_msda_backward_taps.argtypes = [_int] + [_vp] * 8 + [_i64] * 7 + [_vp]
 _lib.mmfs_msda_backward_value.restype = _int
-_lib.mmfs_msda_backward_value.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_backward_value.argtypes = [_int] + [_vp] * 7 + [_i64] * 8 + [_vp]
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
@@ -238,6 +238,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     with torch.cuda.device(value.device):
         stream = _stream(value.device)
         status = _E_UNSUPPORTED
+        ws_bytes = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
+        ws_ptr = ws.data_ptr() if ws is not None else None
         if flags & _BWD_CANONICAL_LEVELS:
             # pixel-stationary backward, stage by stage (so each kernel can be timed)
             status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
@@ -248,17 +251,15 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 status = _launch("msda_bwd_value", value.device, _lib.mmfs_msda_backward_value, code,
                                  spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                  sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-                                 grad_value.data_ptr(), *dims, stream)
+                                 grad_value.data_ptr(), ws_ptr, ws_bytes, *dims, stream)
         if status == _E_UNSUPPORTED:
             # head width without a vector path, fp64, or a non-canonical level table:
             # the library's float-atomic path (needs an fp32 scratch for 16-bit storage)
-            ws_bytes = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
             status = _launch("msda_bwd_atomic", value.device, _lib.mmfs_msda_backward, code,
                              value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                              sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                              grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                             ws.data_ptr() if ws is not None else None, ws_bytes, *dims, flags, stream)
+                             ws_ptr, ws_bytes, *dims, flags, stream)
         _check(status, "ms_deform_attn_backward")
     if loc_dtype != dt:
         grad_loc = grad_loc.to(loc_dtype)

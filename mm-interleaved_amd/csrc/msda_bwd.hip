@@ -30,7 +30,10 @@ namespace mmfs {
 
 constexpr int kThreads = 256;
 constexpr int kRecsPerBlock = 512;
-constexpr int kUnroll = 2;
+#ifndef MMFS_TAPS_UNROLL
+#define MMFS_TAPS_UNROLL 2
+#endif
+constexpr int kUnroll = MMFS_TAPS_UNROLL;
 
 template <typename A>
 __device__ __forceinline__ void atomic_add(A *p, A v)

@@ -99,7 +99,7 @@ int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int6
 {
     mmfs::Dims d;
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
-    if (use_tiled(dtype, d, flags)) return 0;
+    if (use_tiled(dtype, d, flags)) return mmfs::bwd_value_tiled_workspace_bytes(dtype, d);
     // atomic path: 16-bit storage accumulates into an fp32 image of grad_value
     if (dtype == MMFS_F16 || dtype == MMFS_BF16) return B * S * H * D * 4;
     return 0;
@@ -142,7 +142,10 @@ int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
         hipError_t e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out,
                                            nullptr, grad_loc, grad_attn, d, false, st);
         if (e != hipSuccess) return (int)e;
-        return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value, d, st);
+        if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+        return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value,
+                                               workspace, d, st);
     }
     // ---- float-atomic path
     const bool narrow = (dtype == MMFS_F16 || dtype == MMFS_BF16);
@@ -187,6 +190,7 @@ int mmfs_msda_backward_taps(int dtype, const void *value, const int64_t *shapes,
 
 int mmfs_msda_backward_value(int dtype, const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *grad_out, void *grad_value,
+                             void *workspace, int64_t workspace_bytes,
                              int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
                              void *stream)
 {
@@ -204,7 +208,9 @@ int mmfs_msda_backward_value(int dtype, const int64_t *shapes, const int64_t *st
     if (!shapes || !start || !loc || !attn || !grad_out) return MMFS_E_NULLPTR;
     if (misaligned(grad_out, 16) || misaligned(grad_value, 16) || misaligned(loc, es) || misaligned(attn, es))
         return MMFS_E_ALIGN;
-    return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value, d,
+    if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value, workspace, d,
                                            (hipStream_t)stream);
 }
 

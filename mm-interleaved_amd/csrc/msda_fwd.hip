@@ -26,7 +26,7 @@ namespace mmfs {
 constexpr int kThreads = 256;
 constexpr int kRecsPerBlock = 512;      // tap records staged per chunk (16 KiB)
 #ifndef MMFS_FWD_UNROLL
-#define MMFS_FWD_UNROLL 4
+#define MMFS_FWD_UNROLL 2      // measured on MI355X: 2 -> 183 us, 1 -> 198, 4 -> 235, 8 -> 231 (cfg2, bf16)
 #endif
 constexpr int kUnroll = MMFS_FWD_UNROLL;   // taps in flight per lane (4x row reads each)
 

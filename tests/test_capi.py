@@ -81,10 +81,11 @@ def test_backward_workspace_query_is_host_only():
     f.restype = i64
     f.argtypes = [ctypes.c_int] + [i64] * 7 + [ctypes.c_uint]
     dims = (8, 5440, 8, 128, 4, 4096, 4)
-    assert f(2, *dims, 1) == 0                               # bf16, canonical levels: pixel-stationary
+    pts = 8 * 4096 * 8 * 4 * 4
+    assert f(2, *dims, 1) == 3 * pts * 2                     # bf16, canonical levels: re-packed loc/attn
     assert f(2, *dims, 0) == 8 * 5440 * 8 * 128 * 4          # unknown level table: fp32 image for atomics
     assert f(2, *dims, 3) == 8 * 5440 * 8 * 128 * 4          # forced atomic
-    assert f(0, *dims, 0) == 0                               # fp32 accumulates in grad_value itself
+    assert f(0, *dims, 0) == 0                               # fp32 atomics accumulate in grad_value itself
     assert f(2, 8, 5440, 8, 24, 4, 4096, 4, 1) > 0           # D=24: no vector path
 
 
