@@ -37,15 +37,21 @@
 #include "msda_device.h"
 #include "msda_launch.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace mmfs {
 
 namespace {
 
-constexpr int kThreads = 1024;          // one workgroup per CU: 16 waves share one big record list
+#ifndef MMFS_VAL_THREADS
+#define MMFS_VAL_THREADS 1024
+#define MMFS_VAL_CAP 12288
+#define MMFS_VAL_TILEPX 4096
+#endif
+constexpr int kThreads = MMFS_VAL_THREADS;   // 1024: one workgroup per CU, 16 waves share one big record list
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxTilePx = 1024;        // pixels per tile (counter arrays: 2 x 4 KiB)
-constexpr int kListCap = 12288;         // {q, weight} records per round (96 KiB)
+constexpr int kMaxTilePx = MMFS_VAL_TILEPX;  // pixels per tile (counter arrays: 2 x 4 B each)
+constexpr int kListCap = MMFS_VAL_CAP;       // {q, weight} records per round (8 B each)
 #ifndef MMFS_VAL_UNROLL
 #define MMFS_VAL_UNROLL 8
 #endif
@@ -97,9 +103,14 @@ __device__ Tile plan_tile(const int64_t *__restrict__ shapes, const int64_t *__r
 // Exclusive prefix sum over a[0..n) (n <= kMaxTilePx), total left in a[n].
 __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
 {
-    static_assert(kMaxTilePx == kThreads, "one counter per thread");
+    constexpr int PER = kMaxTilePx / kThreads;                   // consecutive counters per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t v = tid < n ? a[tid] : 0u;
+    uint32_t c[PER], v = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        c[i] = tid * PER + i < n ? a[tid * PER + i] : 0u;
+        v += c[i];
+    }
     uint32_t inc = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -110,8 +121,13 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    if (tid < n) a[tid] = base + inc - v;
-    if (tid == kThreads - 1) a[n] = base + inc;
+    uint32_t run = base + inc - v;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (tid * PER + i < n) a[tid * PER + i] = run;
+        run += c[i];
+    }
+    if (tid == kThreads - 1) a[n] = run;
     __syncthreads();
 }
 
@@ -411,13 +427,13 @@ static hipError_t repack(const void *src, void *dst, const Dims &d, int chunk_by
 TileParams make_params(const Dims &d)
 {
     TileParams tp;
-    // (1) balance: aim at >= 8 tiles per CU over the whole launch (256 CUs);
-    // (2) capacity: a level feeds Nq*P*4 records per (b, h); keep a tile's expected share
-    //     under ~85 % of the list so one scatter round usually suffices
+    // Tiles are big (a whole level when it has <= kMaxTilePx pixels): a workgroup counts its
+    // tile once, then works through it in list-sized rounds, so the per-tile fixed costs
+    // (launch, plan, count scan, barriers) are paid few times.  nt_min only spreads the work
+    // when there are few (b, h, level) slices: aim at ~3 workgroups per CU (256 CUs).
     const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
-    int64_t nt = std::max<int64_t>(1, (2048 + slices - 1) / slices);
-    const int64_t per_level = (int64_t)d.Nq * d.P * 4;
-    nt = std::max<int64_t>(nt, (per_level * 20 / 17 + kListCap - 1) / kListCap);
+    int64_t nt = std::max<int64_t>(1, (768 + slices - 1) / slices);
+    if (const char *e = getenv("MMFS_NT_MIN")) nt = std::max(1, atoi(e));      // tuning knob
     tp.nt_min = (int)std::min<int64_t>(nt, 256);
     // tiles per level <= 2*nt_l + 1 with nt_l <= nt_min + px_l/kMaxTilePx + 1 (see plan_tile)
     const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((d.S + kMaxTilePx - 1) / kMaxTilePx) + d.L;

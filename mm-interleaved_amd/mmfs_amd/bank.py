@@ -1,0 +1,123 @@
+"""Multi-image feature bank: what feeds ``input_flatten`` / ``attention_mask`` of MMFS.
+
+Restates, without Python loops over the batch and without device->host syncs, the two
+builders of the reference's top-level model
+  * ``_prepare_mmfs_features_for_mm_decoder``    mm_interleaved/models/mm_interleaved.py:185-252
+  * ``_prepare_mmfs_features_for_image_decoder`` mm_interleaved/models/mm_interleaved.py:306-340
+and adds the one exchange step of the multi-GPU path: when the image
+encoder is balanced per image rather than per sequence, a sequence's context images may
+have been encoded on other ranks; ``all_gather_image_features`` brings the per-image
+multiscale features together with ONE all_gather_into_tensor (RCCL over xGMI; the
+reference has no counterpart, its ranks never exchange features) and the builders then
+index into the gathered tensor exactly as they would on a single rank.
+"""
+import torch
+
+
+# ------------------------------------------------------------------ LLM side
+def llm_cross_attention_mask(text_ids, max_num_image, bos_token_id, soi_token_id):
+    """[B, L, N] float mask: image k of a sequence is visible to token t iff the token after
+    its <soi> is at or before t and after the nearest <bos> at or before t
+    (mm_interleaved.py:199-221).  ``max_num_image`` is a host int (the collator knows it)."""
+    B, L = text_ids.shape
+    pos = torch.arange(L, device=text_ids.device)
+    is_soi = text_ids == soi_token_id
+    k_of = is_soi.long().cumsum(1) - 1                                   # image index at each <soi>
+    # image_token_pos[b, k] = position of <soi> k + 1, or -1
+    tab = torch.full((B, max_num_image + 1), -1, dtype=torch.long, device=text_ids.device)
+    slot = torch.where(is_soi & (k_of < max_num_image), k_of, torch.full_like(k_of, max_num_image))
+    tab.scatter_(1, slot, (pos + 1).expand(B, L))
+    tab[:, max_num_image] = -1                                           # the dump slot
+    img_pos = tab[:, :max_num_image]                                     # [B, N]
+    nearest_bos = torch.where(text_ids == bos_token_id, pos.expand(B, L), torch.full_like(text_ids, -1))
+    nearest_bos = nearest_bos.cummax(dim=1).values                       # [B, L]
+    vis = (img_pos[:, None, :] > nearest_bos[:, :, None]) & (img_pos[:, None, :] <= pos[None, :, None]) \
+        & (img_pos[:, None, :] != -1)
+    return vis.float()
+
+
+def pack_image_levels(multiscale_features, spatial_sides=None):
+    """List of per-level [N_img, C, h, w] -> [N_img, sum_l h*w, C] (levels in list order).
+    ``spatial_sides``: keep only levels whose side is listed (mm_interleaved.py:223-227)."""
+    keep = [f for f in multiscale_features if spatial_sides is None or int(f.shape[-1]) in spatial_sides]
+    return torch.cat([f.flatten(2).transpose(1, 2) for f in keep], dim=1)
+
+
+def llm_feature_bank(packed, num_image_per_seq, max_num_image):
+    """packed [N_img, hw, C] (images of all sequences, in order) -> [B, N, hw, C], each
+    sequence's images first, zero padded (mm_interleaved.py:228-250)."""
+    num = num_image_per_seq.to(packed.device).long()
+    first = num.cumsum(0) - num                                          # [B]
+    k = torch.arange(max_num_image, device=packed.device)
+    valid = k[None, :] < num[:, None]                                    # [B, N]
+    src = (first[:, None] + k[None, :]).clamp_(max=max(packed.shape[0] - 1, 0))
+    bank = packed.index_select(0, src.reshape(-1)).reshape(num.shape[0], max_num_image, *packed.shape[1:])
+    return bank * valid[:, :, None, None].to(bank.dtype)
+
+
+def prepare_mmfs_features_for_mm_decoder(text_ids, num_image_per_seq, multiscale_features, *,
+                                         bos_token_id, soi_token_id, spatial_shapes, max_num_image=None):
+    """Drop-in for the reference method: returns {'cross_attention_mask', 'mmfs_features_mm'}."""
+    if max_num_image is None:
+        max_num_image = int(num_image_per_seq.max())                     # sync; pass it to avoid
+    mask = llm_cross_attention_mask(text_ids, max_num_image, bos_token_id, soi_token_id)
+    bank = llm_feature_bank(pack_image_levels(multiscale_features, spatial_shapes), num_image_per_seq,
+                            max_num_image)
+    return {"cross_attention_mask": mask, "mmfs_features_mm": bank}
+
+
+# ------------------------------------------------------------------ image-decoder side
+def prepare_mmfs_features_for_image_decoder(multiscale_features, text_ids, nearest_bos_idxs=None,
+                                            num_image_per_seq=None, *, soi_token_id):
+    """For target image i the bank holds only the image just before it in the same document
+    (sub-diagonal of the context mask, mm_interleaved.py:326-338).
+    Returns (list of per-level [B_I, 1, C, h, w], mask [B_I, 1] long)."""
+    B_I = multiscale_features[0].shape[0]
+    L = text_ids.shape[1]
+    is_soi = (text_ids == soi_token_id).flatten()
+    flat = torch.arange(is_soi.numel(), device=text_ids.device)
+    big = is_soi.numel()
+    start = torch.where(is_soi, flat, torch.full_like(flat, big)).sort().values[:B_I]   # x*L + y, in order
+    row = start // L
+    nearest = torch.zeros_like(start) if nearest_bos_idxs is None else nearest_bos_idxs.to(start.device)
+    nearest = row * L + nearest
+    prev_start = torch.roll(start, 1)
+    has_ctx = (nearest <= prev_start)
+    has_ctx[0] = False
+    feats = []
+    for f in multiscale_features:
+        prev = torch.roll(f, 1, dims=0)
+        feats.append((prev * has_ctx.view(-1, 1, 1, 1).to(f.dtype))[:, None])
+    return feats, has_ctx.long()[:, None]
+
+
+# ------------------------------------------------------------------ multi-GPU exchange
+def image_owner_layout(n_images_total, world_size):
+    """Images are encoded round-robin: image g lives on rank g % world at local slot g // world."""
+    per_rank = (n_images_total + world_size - 1) // world_size
+    return per_rank
+
+
+def all_gather_image_features(local_packed, n_images_total, group=None):
+    """local_packed [n_local, hw, C]: this rank's images (global ids rank, rank+W, rank+2W, ...).
+    Returns [n_images_total, hw, C] in global image order, identical on every rank.
+    One collective; each peer's shard travels over its own xGMI link on a full mesh."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_packed[:n_images_total]
+    per_rank = image_owner_layout(n_images_total, world)
+    shard = local_packed.new_zeros((per_rank,) + tuple(local_packed.shape[1:]))
+    shard[: local_packed.shape[0]] = local_packed
+    gathered = local_packed.new_empty((world * per_rank,) + tuple(local_packed.shape[1:]))
+    dist.all_gather_into_tensor(gathered, shard.contiguous(), group=group)
+    # gathered[r*per_rank + s] is global image s*world + r  ->  reorder to global ids
+    g = torch.arange(n_images_total, device=local_packed.device)
+    return gathered.index_select(0, (g % world) * per_rank + g // world)
+
+
+def shard_batch(n_items, rank, world_size):
+    """Contiguous, balanced split of the batch axis (the path's only partitioning)."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,39 @@
+"""Level tables (``spatial_shapes`` / ``level_start_index``) for the MMFS callers.
+
+The reference rebuilds both tensors from Python lists on every forward
+(modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41): a host->device copy per call.  Here
+they are built once per (shapes, n_images, device) and cached; the tensors carry the
+"canonical packing" mark the op shim looks for
+(``MultiScaleDeformableAttention.levels_are_canonical``), so the backward never has to
+copy them back to the host to choose its algorithm.
+"""
+import torch
+
+_cache = {}
+
+
+def make_level_tables(shapes_per_image, n_images, device):
+    """shapes_per_image: [(H, W), ...] of one image; the op sees them repeated n_images
+    times ("multiple images are extra levels").
+    Returns (spatial_shapes [n*L, 2] int64, level_start_index [n*L] int64, S)."""
+    key = (tuple((int(h), int(w)) for h, w in shapes_per_image), int(n_images), str(torch.device(device)))
+    hit = _cache.get(key)
+    if hit is not None:
+        return hit
+    host = torch.tensor(list(key[0]) * int(n_images), dtype=torch.long).reshape(-1, 2)
+    px = host[:, 0] * host[:, 1]
+    start_host = px.cumsum(0) - px
+    S = int(px.sum())
+    shapes = host.to(device)
+    start = start_host.to(device)
+    # pre-seed the shim's cache: (versions, start ptr, S) -> canonical
+    shapes._mmfs_canonical = ((shapes._version, start._version, start.data_ptr(), S), True)
+    shapes._mmfs_host = host
+    out = (shapes, start, S)
+    _cache[key] = out
+    return out
+
+
+def host_shapes(spatial_shapes):
+    """Host copy of a level table if it was built here, else None (no sync is forced)."""
+    return getattr(spatial_shapes, "_mmfs_host", None)

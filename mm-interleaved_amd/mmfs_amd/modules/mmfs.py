@@ -1,0 +1,185 @@
+"""MMFS -- Multi-image Multi-scale Feature Synchronizer, host side.
+
+Same constructor, parameters (names and shapes -> checkpoint compatible),
+``forward`` signature and results as the reference module
+(mm_interleaved/models/utils/ops/modules/mmfs.py:26-276).  The sampling itself runs in
+the gfx950 kernels (``MSDeformAttnFunction``); the dense projections go to hipBLASLt via
+``F.linear`` (MFMA) -- they are plain contractions.
+
+What is organised differently from the reference forward, with identical mathematics:
+
+* the reference repeats the query ``n_images`` times and pushes the copies through the
+  d_query x d_query ``dynamic_offset_mask`` GEMM (mmfs.py:174-175); the only per-image
+  term is the additive ``query_relpos`` row (mmfs.py:177-179), and the two heads that
+  follow are linear, so
+      head(W q + r_k) = head(W q) + (head.weight @ r_k)
+  -> one GEMM on the un-repeated query plus a [max_images, out] table lookup;
+* no device->host synchronisation: the reference's three asserts on device tensors and
+  its ``torch.nonzero`` (mmfs.py:147-149, 177, 209-211 / 220-222) each stall the stream;
+  the nonzero only feeds a write that line 225 overwrites;
+* the sink ("ignore") slot is handled as the constant logit it is (mmfs.py:225).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+from ..levels import host_shapes
+
+
+class MMFS(nn.Module):
+    def __init__(
+        self,
+        layer_idx=0,
+        d_model=256,
+        d_query=-1,
+        d_value=256,
+        d_out=-1,
+        n_levels=4,
+        n_heads=8,
+        n_points=8,
+        ratio=1.0,
+        offset_init_magnitude=3,
+        spatial_shapes=[16],
+        base_spatial_shape=16,
+        max_num_image_per_seq=50,
+    ):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        d_query = d_model if d_query < 0 else d_query
+        d_out = d_model if d_out < 0 else d_out
+        if len(spatial_shapes) != n_levels:
+            raise AssertionError("one spatial shape per level")
+
+        self.layer_idx = layer_idx
+        self.im2col_step = 1                      # kept for API fidelity; the HIP op ignores it
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+        self.ratio = ratio
+        self.offset_init_magnitude = offset_init_magnitude
+        self.max_num_image_per_seq = max_num_image_per_seq
+        d_inner = int(d_model * ratio)
+        self.d_inner = d_inner
+
+        self.register_buffer("scale_ratios",
+                             torch.tensor([s / base_spatial_shape for s in spatial_shapes]),
+                             persistent=False)
+        # parameter names/shapes as mmfs.py:85-96
+        self.sampling_offsets = nn.Linear(d_query, n_heads * n_points * 2)
+        self.ignore_token = nn.Parameter(torch.zeros(1, 1, 1, d_inner), requires_grad=False)
+        self.dynamic_offset_mask = nn.Linear(d_query, d_query)
+        self.attention_weights = nn.Linear(d_query, n_heads * n_levels * (n_points + 1))
+        self.value_proj = nn.Linear(d_value, d_inner)
+        self.output_proj = nn.Linear(d_inner, d_out)
+        self.query_relpos = nn.Embedding(max_num_image_per_seq, d_query)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """Initialisation of mmfs.py:102-118 (called again by the model builders)."""
+        m = self.offset_init_magnitude
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            self.sampling_offsets.bias.copy_(
+                torch.empty(self.n_heads * self.n_points * 2).uniform_(-m, m))
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+            self.dynamic_offset_mask.bias.zero_()
+            nn.init.trunc_normal_(self.query_relpos.weight, std=0.02)
+
+    # ------------------------------------------------------------------ pieces
+    def _image_relpos(self, attention_mask, Lq):
+        """Newest visible image -> 1, older -> 2, 3, ...; invisible -> 0 (mmfs.py:154-163).
+        Returns [N, 1 or Lq, n] (long)."""
+        m = attention_mask.long()
+        relpos = (m.sum(-1, keepdim=True) + 1 - m.cumsum(-1)) * m
+        if relpos.dim() == 2:
+            return relpos[:, None, :]
+        if relpos.shape[1] != Lq:                 # decode step: mask still has the whole history
+            relpos = relpos[:, -1:, :]
+        return relpos
+
+    def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images):
+        """Everything between the query and the op: sampling locations [N,Lq,H,n*L,P,2],
+        attention weights over the real points [N,Lq,H,n*L,P], and the sink weights
+        [N,Lq,H,n*L] (mmfs.py:154-163, 174-265)."""
+        N, Lq, _ = query.shape
+        H, L, P, n = self.n_heads, self.n_levels, self.n_points, n_images
+        nL = n * L
+        assert attention_mask.dim() in (2, 3) and attention_mask.shape[-1] == n
+
+        relpos = self._image_relpos(attention_mask, Lq)                       # [N, 1|Lq, n]
+        if n >= self.max_num_image_per_seq:       # only then can an index leave the table
+            assert int(relpos.max()) < self.max_num_image_per_seq
+
+        q = self.dynamic_offset_mask(query)                                   # one GEMM, not n
+        table = self.query_relpos.weight                                      # [max_img, d_query]
+        off_tab = F.linear(table, self.sampling_offsets.weight)               # [max_img, H*P*2]
+        att_tab = F.linear(table, self.attention_weights.weight)              # [max_img, H*L*(P+1)]
+
+        # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
+        offsets = self.sampling_offsets(q)[:, :, None, :] + off_tab[relpos]
+        offsets = offsets.view(N, Lq, n, H, 1, P, 2) * self.scale_ratios.view(1, 1, 1, 1, L, 1, 1).to(offsets.dtype)
+        offsets = offsets.permute(0, 1, 3, 2, 4, 5, 6).reshape(N, Lq, H, nL, P, 2)
+
+        logits = self.attention_weights(q)[:, :, None, :] + att_tab[relpos]   # [N, Lq, n, H*L*(P+1)]
+        logits = logits.view(N, Lq, n, H, L, P + 1).permute(0, 1, 3, 2, 4, 5)  # [N, Lq, H, n, L, P+1]
+        # invisible images get -10000 on every point logit (mmfs.py:203-207, 213-218) ...
+        am = attention_mask
+        if am.dim() == 3 and am.shape[1] != Lq:
+            am = am[:, -1:, :]
+        penalty = (1.0 - am.to(logits.dtype)) * -10000.0
+        penalty = penalty[:, None, None, :] if am.dim() == 2 else penalty[:, :, None, :]
+        points = logits[..., :P] + penalty[..., None, None]
+        # ... and every level's sink slot is the constant -log(n*L) (mmfs.py:225)
+        sink = points.new_full((N, Lq, H, n, L, 1), -math.log(nL))
+        probs = F.softmax(torch.cat((points, sink), -1).reshape(N, Lq, H, nL * (P + 1)), -1)
+        probs = probs.view(N, Lq, H, nL, P + 1)
+        attn, sink_w = probs[..., :P].contiguous(), probs[..., P]
+
+        if reference_points.shape[-1] == 2:
+            wh = torch.stack((input_spatial_shapes[:, 1], input_spatial_shapes[:, 0]), -1)
+            loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = reference_points[:, :, None, :, None, :2] + \
+                offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(
+                f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+        return loc, attn, sink_w
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None, attention_mask=None):
+        """Arguments and result as mmfs.py:120-141:
+        query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
+        input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
+        input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
+        attention_mask [N, n] or [N, Lq, n]  ->  [N, Lq, d_out]."""
+        N, Lq, _ = query.shape
+        N, n, hw, _ = input_flatten.shape
+        host = host_shapes(input_spatial_shapes)
+        if host is not None:                      # the reference checks this on the device (sync)
+            assert int((host[:, 0] * host[:, 1]).sum()) == n * hw, (host.tolist(), n * hw)
+        assert input_spatial_shapes.shape[0] == n * self.n_levels
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.reshape(N, n * hw, self.n_heads, self.d_inner // self.n_heads).contiguous()
+
+        loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes,
+                                               attention_mask, n)
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                         loc.to(value.dtype).contiguous(), attn, self.im2col_step)
+        # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
+        tok = self.ignore_token.view(1, 1, self.n_heads, -1)
+        out = out + (tok * sink_w.sum(-1, keepdim=True).to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
+        return self.output_proj(out)

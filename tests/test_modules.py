@@ -1,0 +1,234 @@
+"""Module-level parity on CPU: the product's MMFS / blocks / bank builders (host logic)
+against golden vectors captured from the reference (tests/golden/make_golden.py), with the
+CPU oracle standing in for the HIP op (tests may use the oracle; the product never does).
+The same checks run on the GPU with the real op in test_modules_gpu.py."""
+import ast
+import contextlib
+import io
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle.msda_oracle import OracleMSDAFunction
+
+
+@pytest.fixture()
+def oracle_op(monkeypatch):
+    import mmfs_amd.modules.mmfs as m1
+    import mmfs_amd.modules.ms_deform_attn as m2
+    monkeypatch.setattr(m1, "MSDeformAttnFunction", OracleMSDAFunction)
+    monkeypatch.setattr(m2, "MSDeformAttnFunction", OracleMSDAFunction)
+
+
+def T(a, dtype=torch.float64):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dtype) if t.is_floating_point() else t
+
+
+def load_params(module, z, dtype=torch.float64):
+    sd = {k[len("param."):]: T(v, dtype) for k, v in z.items() if k.startswith("param.")}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected                       # reference keys all exist here
+    assert all(k.endswith("scale_ratios") for k in missing), missing
+    return module
+
+
+def close(a, b, tol):
+    a = a.detach().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b.reshape(a.shape)).max() if a.size else 0.0
+    assert err <= tol * max(1.0, np.abs(b).max()), f"max err {err:.3e}"
+
+
+MMFS_CASES = ["mmfs_llm_mask3d", "mmfs_llm_decode", "mmfs_llm_n1", "mmfs_sd_mask2d"]
+
+
+def build_mmfs(z, dtype=torch.float64):
+    from mmfs_amd.modules import MMFS
+    cfg = ast.literal_eval(str(z["cfg"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MMFS(**cfg).to(dtype)
+    return load_params(m, z, dtype), cfg
+
+
+@pytest.mark.parametrize("name", MMFS_CASES)
+def test_mmfs_forward_backward_matches_reference(name, oracle_op):
+    z = load_golden(name)
+    m, cfg = build_mmfs(z)
+    q = T(z["query"]).requires_grad_(True)
+    f = T(z["feat"]).requires_grad_(True)
+    out = m(q, T(z["reference_points"]), f, T(z["spatial_shapes"]), T(z["level_start_index"]), None,
+            T(z["attention_mask"], torch.float32) if z["attention_mask"].dtype.kind == "f" else T(z["attention_mask"]))
+    close(out, z["out"], 1e-10)
+    out.backward(T(z["grad_out"]))
+    close(q.grad, z["grad_query"], 1e-9)
+    close(f.grad, z["grad_feat"], 1e-9)
+    for k, p in m.named_parameters():
+        if "grad." + k in z:
+            close(p.grad, z["grad." + k], 1e-9)
+        else:
+            assert p.grad is None or not p.grad.any(), k   # e.g. frozen ignore_token
+
+
+def test_mmfs_fp32_within_1e5(oracle_op):
+    z = load_golden("mmfs_llm_mask3d_f32")
+    m, _ = build_mmfs(z, torch.float32)
+    out = m(T(z["query"], torch.float32), T(z["reference_points"], torch.float32), T(z["feat"], torch.float32),
+            T(z["spatial_shapes"]), T(z["level_start_index"]), None, T(z["attention_mask"], torch.float32))
+    close(out, load_golden("mmfs_llm_mask3d")["out"], 1e-5)    # vs the fp64 reference run
+
+
+def test_mmfs_state_dict_keys_are_the_references():
+    from mmfs_amd.modules import MMFS
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MMFS(d_model=32, d_query=16, d_value=8, d_out=16, n_levels=2, n_heads=4, n_points=2,
+                 spatial_shapes=[4, 2], base_spatial_shape=4, max_num_image_per_seq=5)
+    assert sorted(m.state_dict()) == sorted([
+        "sampling_offsets.weight", "sampling_offsets.bias", "ignore_token",
+        "dynamic_offset_mask.weight", "dynamic_offset_mask.bias", "attention_weights.weight",
+        "attention_weights.bias", "value_proj.weight", "value_proj.bias", "output_proj.weight",
+        "output_proj.bias", "query_relpos.weight"])
+    assert not m.ignore_token.requires_grad and m.sampling_offsets.weight.abs().sum() == 0
+    assert m.sampling_offsets.bias.abs().max() <= 3 and m.im2col_step == 1
+
+
+def test_mmfs_known_answers(oracle_op):
+    """all images masked -> output == output_proj.bias; masked images get zero
+    attention; attention over real points sums to < 1 (the sinks keep the rest)."""
+    z = load_golden("mmfs_sd_mask2d")
+    m, cfg = build_mmfs(z)
+    q, f = T(z["query"]), T(z["feat"])
+    mask = torch.zeros(q.shape[0], f.shape[1], dtype=torch.long)
+    with torch.no_grad():
+        m.ignore_token.zero_()
+        out = m(q, T(z["reference_points"]), f, T(z["spatial_shapes"]), T(z["level_start_index"]), None, mask)
+        assert torch.allclose(out, m.output_proj.bias.expand_as(out), atol=1e-12)
+        loc, attn, sink = m.sampling_plan(q, T(z["reference_points"]), T(z["spatial_shapes"]),
+                                          T(z["attention_mask"]), f.shape[1])
+    L = cfg["n_levels"]
+    am = T(z["attention_mask"]).bool()                    # [B, n]
+    per_image = attn.reshape(*attn.shape[:3], f.shape[1], L, -1).sum((-1, -2))   # [B, Lq, H, n]
+    assert (per_image[~am[:, None, None, :].expand_as(per_image)] < 1e-300).all()
+    total = attn.sum((-1, -2)) + sink.sum(-1)
+    assert torch.allclose(total, torch.ones_like(total)) and (attn.sum((-1, -2)) < 1).all()
+    # the normalised location is the same at every level of one image (scale_ratios cancel)
+    loc5 = loc.reshape(*loc.shape[:3], f.shape[1], L, *loc.shape[4:])
+    assert torch.allclose(loc5, loc5[:, :, :, :, :1].expand_as(loc5), atol=1e-12)
+
+
+def test_llama_mmfs_attention_matches_reference(oracle_op):
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    z = load_golden("block_llama_mmfs_attention")
+    cfg = types.SimpleNamespace(hidden_size=64, num_attention_heads=4, rms_norm_eps=1e-6,
+                                max_position_embeddings=64, image_embed_dim=32, spatial_shapes=[8, 4, 2])
+    with contextlib.redirect_stdout(io.StringIO()):
+        att = load_params(LlamaMMFSAttention(cfg, layer_idx=0).double(), z)
+    assert sorted(k.split(".")[0] for k in att.state_dict()) .count("attn") == 12
+    h = T(z["hidden"]).requires_grad_(True)
+    f = T(z["feats"]).requires_grad_(True)
+    out = att(h, f, T(z["mask"], torch.float32))
+    close(out, z["out"], 1e-10)
+    out.backward(T(z["grad_out"]))
+    close(h.grad, z["grad_hidden"], 1e-9)
+    close(f.grad, z["grad_feats"], 1e-9)
+    for k, p in att.named_parameters():
+        if "grad." + k in z:
+            close(p.grad, z["grad." + k], 1e-9)
+
+
+def test_sd_mmfs_block_matches_reference(oracle_op):
+    from mmfs_amd.blocks import MMFSBlock
+    z = load_golden("block_sd_mmfs_block")
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = MMFSBlock(attn_dim=32, query_dim=16, feat_dim=32, num_heads=4, n_points=2, n_levels=3,
+                        gradient_checkpointing=False, grid_size=8, spatial_shapes=[8, 4, 2],
+                        base_spatial_shape=4, max_num_image_per_seq=5).double()
+    # the sin-cos table built here equals the reference's (stored in the fixture)
+    close(blk.pos_embed, z["param.pos_embed"], 1e-6)
+    load_params(blk, z)
+    s = T(z["sample"]).requires_grad_(True)
+    f = T(z["ms_feat"]).requires_grad_(True)
+    out = blk(s, f, T(z["ms_mask"]), [(8, 8), (4, 4), (2, 2)])
+    close(out, z["out"], 1e-10)
+    out.backward(T(z["grad_out"]))
+    close(s.grad, z["grad_sample"], 1e-9)
+    close(f.grad, z["grad_ms_feat"], 1e-9)
+    for k, p in blk.named_parameters():
+        if "grad." + k in z:
+            close(p.grad, z["grad." + k], 1e-9)
+
+
+def test_sd_mmfs_net_matches_reference(oracle_op):
+    from mmfs_amd.blocks import MMFSNet
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                      downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                      spatial_shapes=[64, 32, 16]).double()
+    assert len(net.mmfs_down_blocks) == 6
+    ref_keys = sorted(k[len("param."):] for k in z if k.startswith("param."))
+    assert sorted(net.state_dict()) == ref_keys               # checkpoint compatible
+    load_params(net, z)
+    res = [T(z[f"res.{i}"]) for i in range(6)]
+    feats = [T(z[f"feat.{i}"]) for i in range(3)]
+    with torch.no_grad():
+        mid, new_res = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    close(mid, z["new_mid"], 1e-10)
+    for i, r in enumerate(new_res):
+        close(r, z[f"new_res.{i}"], 1e-10)
+
+
+def test_ms_deform_attn_module(oracle_op):
+    """Encoder twin: shapes, init (directional bias, zero weights) and agreement with a
+    by-hand evaluation through the oracle."""
+    from mmfs_amd.modules import MSDeformAttn
+    torch.manual_seed(0)
+    m = MSDeformAttn(d_model=32, n_levels=2, n_heads=4, n_points=2, ratio=0.5).double()
+    assert sorted(m.state_dict()) == sorted([
+        "sampling_offsets.weight", "sampling_offsets.bias", "attention_weights.weight",
+        "attention_weights.bias", "value_proj.weight", "value_proj.bias", "output_proj.weight", "output_proj.bias"])
+    b = m.sampling_offsets.bias.view(4, 2, 2, 2)
+    assert torch.allclose(b[0, 0, 0], torch.tensor([1.0, 0.0], dtype=torch.float64))
+    assert torch.allclose(b[1, :, 1], torch.tensor([0.0, 2.0], dtype=torch.float64).expand(2, 2), atol=1e-6)
+    sh = torch.tensor([[4, 4], [2, 2]]); st = torch.tensor([0, 16])
+    q = torch.randn(2, 5, 32, dtype=torch.float64); x = torch.randn(2, 20, 32, dtype=torch.float64)
+    ref = torch.rand(2, 5, 2, 2, dtype=torch.float64)
+    out = m(q, ref, x, sh, st)
+    assert out.shape == (2, 5, 32)
+    # zero attention weights -> uniform average of the 4 taps per head
+    v = m.value_proj(x).view(2, 20, 4, 4)
+    loc = ref[:, :, None, :, None, :] + m.sampling_offsets.bias.view(1, 1, 4, 2, 2, 2) / \
+        torch.tensor([[4.0, 4.0], [2.0, 2.0]], dtype=torch.float64)[None, None, None, :, None, :]
+    want = m.output_proj(OracleMSDAFunction.apply(v.contiguous(), sh, st, loc.expand(2, 5, 4, 2, 2, 2).contiguous(),
+                                                  torch.full((2, 5, 4, 2, 2), 0.25, dtype=torch.float64), 1))
+    assert torch.allclose(out, want, atol=1e-12)
+
+
+# ------------------------------------------------------------------ bank builders
+def test_bank_builders_match_reference():
+    from mmfs_amd import bank
+    z = load_golden("bank_builders")
+    text_ids = T(z["text_ids"]); num = T(z["num_image_per_seq"])
+    ms = [T(z[f"ms.{i}"], torch.float32) for i in range(4)]
+    out = bank.prepare_mmfs_features_for_mm_decoder(text_ids, num, ms, bos_token_id=1, soi_token_id=32000,
+                                                    spatial_shapes=[8, 4, 2], max_num_image=3)
+    assert torch.equal(out["cross_attention_mask"], T(z["cross_attention_mask"], torch.float32))
+    assert torch.equal(out["mmfs_features_mm"], T(z["mmfs_features_mm"], torch.float32))
+    feats, mask = bank.prepare_mmfs_features_for_image_decoder(ms[1:], text_ids, T(z["nearest_bos_idxs"]), num,
+                                                               soi_token_id=32000)
+    assert torch.equal(mask, T(z["img_mask"]))
+    for i, f in enumerate(feats):
+        assert torch.equal(f, T(z[f"img_feat.{i}"], torch.float32))
+
+
+def test_level_tables_are_cached_and_marked_canonical():
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.levels import make_level_tables
+    a = make_level_tables([(8, 8), (4, 4)], 3, "cpu")
+    b = make_level_tables([(8, 8), (4, 4)], 3, "cpu")
+    assert a[0] is b[0] and a[2] == 240
+    assert a[0].tolist() == [[8, 8], [4, 4]] * 3 and a[1].tolist() == [0, 64, 80, 144, 160, 224]
+    assert MSDA.levels_are_canonical(a[0], a[1], 240)
