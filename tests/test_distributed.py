@@ -1,0 +1,65 @@
+"""world_size-2 gloo tests (CPU): the batch-sharded multi-GPU path and its one exchange
+step, the all-gather of per-image features.  Acceptance: the bank built
+after the all-gather is bit-identical to the single-rank bank."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "mm-interleaved_amd")]
+    from mmfs_amd import bank
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)                     # same data on every rank
+        num = torch.tensor([3, 1, 2, 0, 1])                      # images per sequence, 5 sequences
+        n_img = int(num.sum())
+        levels = [torch.randn(n_img, 6, s, s, generator=g) for s in (8, 4, 2)]
+        packed = bank.pack_image_levels(levels)                  # [7, 84, 6] -- the single-rank truth
+        want_bank = bank.llm_feature_bank(packed, num, 3)
+
+        # each rank "encodes" only its round-robin share of the images ...
+        mine = packed[rank::world].contiguous()
+        gathered = bank.all_gather_image_features(mine, n_img)
+        assert torch.equal(gathered, packed), "gathered features differ from the single-rank tensor"
+        # ... and builds the bank of its own batch shard from the gathered tensor
+        lo, hi = bank.shard_batch(num.numel(), rank, world)
+        first = int(num[:lo].sum())
+        local = bank.llm_feature_bank(gathered[first:first + int(num[lo:hi].sum())], num[lo:hi], 3)
+        assert torch.equal(local, want_bank[lo:hi])
+        # every sequence is processed by exactly one rank
+        counts = torch.zeros(num.numel())
+        counts[lo:hi] = 1
+        dist.all_reduce(counts)
+        assert torch.equal(counts, torch.ones(num.numel()))
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_all_gather_and_batch_sharding_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_shard_batch_is_a_partition():
+    from mmfs_amd.bank import shard_batch
+    for n in (0, 1, 7, 8, 13):
+        for w in (1, 2, 4, 8):
+            spans = [shard_batch(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1

@@ -1,0 +1,125 @@
+"""GPU: the product modules with the real HIP op against the reference goldens
+(fp32 bar 1e-5 relative to the fp64 golden; fp16/bf16 reported bars)."""
+import ast
+import contextlib
+import io
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a, dtype):
+    t = torch.from_numpy(np.asarray(a))
+    return (t.to(dtype) if t.is_floating_point() else t).to(DEV)
+
+
+def load_params(module, z):
+    sd = {k[len("param."):]: torch.from_numpy(np.asarray(v)) for k, v in z.items() if k.startswith("param.")}
+    module.load_state_dict(sd, strict=False)
+    return module
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu().numpy(); b = np.asarray(b, np.float64).reshape(a.shape)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("name", ["mmfs_llm_mask3d", "mmfs_llm_decode", "mmfs_llm_n1", "mmfs_sd_mask2d"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 5e-3), (torch.bfloat16, 4e-2)])
+def test_mmfs_on_gpu_matches_reference(name, dtype, tol):
+    from mmfs_amd.modules import MMFS
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = load_params(MMFS(**cfg), z).to(DEV, dtype)
+    q = T(z["query"], dtype).requires_grad_(True)
+    f = T(z["feat"], dtype).requires_grad_(True)
+    mask = T(z["attention_mask"], torch.float32)
+    out = m(q, T(z["reference_points"], dtype), f, T(z["spatial_shapes"], None), T(z["level_start_index"], None), None, mask)
+    assert out.dtype == dtype
+    assert rel_err(out, z["out"]) <= tol
+    out.backward(T(z["grad_out"], dtype))
+    assert rel_err(q.grad, z["grad_query"]) <= tol * 4
+    assert rel_err(f.grad, z["grad_feat"]) <= tol * 4
+    if dtype == torch.float32:
+        for k, p in m.named_parameters():
+            if "grad." + k in z:
+                assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
+
+
+def test_blocks_on_gpu_match_reference():
+    from mmfs_amd.blocks import LlamaMMFSAttention, MMFSBlock, MMFSNet
+    z = load_golden("block_llama_mmfs_attention")
+    cfg = types.SimpleNamespace(hidden_size=64, num_attention_heads=4, rms_norm_eps=1e-6,
+                                max_position_embeddings=64, image_embed_dim=32, spatial_shapes=[8, 4, 2])
+    with contextlib.redirect_stdout(io.StringIO()):
+        att = load_params(LlamaMMFSAttention(cfg, 0), z).to(DEV)
+    h = T(z["hidden"], torch.float32).requires_grad_(True)
+    f = T(z["feats"], torch.float32).requires_grad_(True)
+    out = att(h, f, T(z["mask"], torch.float32))
+    assert rel_err(out, z["out"]) <= 2e-5
+    out.backward(T(z["grad_out"], torch.float32))
+    assert rel_err(h.grad, z["grad_hidden"]) <= 1e-4 and rel_err(f.grad, z["grad_feats"]) <= 1e-4
+
+    z = load_golden("block_sd_mmfs_block")
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = load_params(MMFSBlock(attn_dim=32, query_dim=16, feat_dim=32, num_heads=4, n_points=2, n_levels=3,
+                                    gradient_checkpointing=True, grid_size=8, spatial_shapes=[8, 4, 2],
+                                    base_spatial_shape=4, max_num_image_per_seq=5), z).to(DEV)
+    blk.train()                                  # exercises checkpoint: the op's forward re-runs in backward
+    s = T(z["sample"], torch.float32).requires_grad_(True)
+    f = T(z["ms_feat"], torch.float32).requires_grad_(True)
+    out = blk(s, f, T(z["ms_mask"], None), [(8, 8), (4, 4), (2, 2)])
+    assert rel_err(out, z["out"]) <= 2e-5
+    out.backward(T(z["grad_out"], torch.float32))
+    assert rel_err(s.grad, z["grad_sample"]) <= 1e-4 and rel_err(f.grad, z["grad_ms_feat"]) <= 1e-4
+
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV)
+    with torch.no_grad():
+        mid, res = net(T(z["mid"], torch.float32), [T(z[f"res.{i}"], torch.float32) for i in range(6)],
+                       [T(z[f"feat.{i}"], torch.float32) for i in range(3)], T(z["ms_mask"], None))
+    assert rel_err(mid, z["new_mid"]) <= 2e-5
+    for i, r in enumerate(res):
+        assert rel_err(r, z[f"new_res.{i}"]) <= 2e-5
+
+
+def test_mmfs_forward_issues_no_host_sync():
+    """The reference stalls the stream >= 4 times per MMFS call; this one must not."""
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    cfg = types.SimpleNamespace(hidden_size=256, num_attention_heads=4, rms_norm_eps=1e-6,
+                                max_position_embeddings=64, image_embed_dim=128, spatial_shapes=[8, 4, 2])
+    with contextlib.redirect_stdout(io.StringIO()):
+        att = LlamaMMFSAttention(cfg, 0).to(DEV, torch.bfloat16)
+    h = torch.randn(2, 16, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    f = torch.randn(2, 3, 84, 128, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    mask = torch.ones(2, 16, 3, device=DEV)
+    att(h, f, mask).sum().backward()             # warm-up: builds the cached level tables
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        att(h, f, mask).sum().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+
+
+def test_bank_builders_on_gpu():
+    from mmfs_amd import bank
+    z = load_golden("bank_builders")
+    ms = [T(z[f"ms.{i}"], torch.float32) for i in range(4)]
+    out = bank.prepare_mmfs_features_for_mm_decoder(T(z["text_ids"], None), T(z["num_image_per_seq"], None), ms,
+                                                    bos_token_id=1, soi_token_id=32000, spatial_shapes=[8, 4, 2],
+                                                    max_num_image=3)
+    assert torch.equal(out["cross_attention_mask"].cpu(), torch.from_numpy(z["cross_attention_mask"]))
+    assert torch.equal(out["mmfs_features_mm"].cpu(), torch.from_numpy(z["mmfs_features_mm"]))
