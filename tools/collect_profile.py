@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of a tools/prof.sh run (gpurun_out/prof_<tag>/) into profiles/
+and derives profiles/pmc_traffic.json (HBM bytes per launch per kernel, read by bench.py).
+
+  python tools/collect_profile.py <tag> <round-prefix> [workload]
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE shows half of a
+wide coalesced read stream (MI355X_MICROARCH.md section HBM) -> doubled here, as the guide says.
+"""
+import csv, glob, json, os, re, shutil, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, prefix = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2_northstar"
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(dst, f"{prefix}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in rows[:16]:
+            w.writerow(r)
+shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(dst, f"{prefix}_pmc_summary.txt"))
+
+names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_tiled": "msda_bwd_value",
+         "msda_bwd_vecI": "msda_bwd_taps", "repack_kernel": "repack"}
+traffic = {}
+for line in open(os.path.join(src, "pmc_summary.txt")):
+    kern, _, rest = line.partition(": ")
+    vals = dict(kv.split("=") for kv in rest.strip().split(", ") if "=" in kv)
+    if "FETCH_SIZE" not in vals:
+        continue
+    for pat, short in names.items():
+        if pat in kern:
+            if short == "msda_bwd_taps" and "ELb1E" in kern:
+                short = "msda_bwd_atomic"
+            rd = float(vals["FETCH_SIZE"]) * 1024 * 2          # gfx950 correction
+            wr = float(vals.get("WRITE_SIZE", 0)) * 1024
+            traffic[short] = int(rd + wr)
+path = os.path.join(dst, "pmc_traffic.json")
+allw = json.load(open(path)) if os.path.exists(path) else {}
+allw[workload] = traffic
+allw["_source"] = f"profiles/{prefix}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)"
+json.dump(allw, open(path, "w"), indent=1)
+print(json.dumps(allw, indent=1))
