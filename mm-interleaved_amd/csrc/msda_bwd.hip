@@ -56,7 +56,8 @@ __device__ __forceinline__ float group_sum(float v)
 // SCATTER = true : also accumulates grad_value with global atomics (fallback path)
 // SCATTER = false: location / weight gradients only; grad_value comes from the
 //                  pixel-stationary kernel in msda_bwd_value.hip
-template <typename T, int LPI, bool SCATTER>
+// BUF: value rows through a buffer descriptor (see msda_device.h); only without SCATTER
+template <typename T, int LPI, bool SCATTER, bool BUF>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
@@ -81,6 +82,10 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t slice = ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;
     const T *vbase = value + slice + lig * VEC;
     float *gvbase = grad_value + slice + lig;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    __amdgpu_buffer_rsrc_t rsrc;
+    if (BUF) rsrc = make_slab_rsrc(value + slice, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
 
     // upstream gradient of this query: contiguous map for the dots, interleaved for atomics
     float g[VEC], gat[VEC];
@@ -136,8 +141,13 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     meta[u] = recs[2 * (kk + u) + 1];
                     rows[u][0] = (int)rr.x; rows[u][1] = (int)rr.y; rows[u][2] = (int)rr.z; rows[u][3] = (int)rr.w;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        raw[u][c] = *reinterpret_cast<const uint4 *>(vbase + (int64_t)max(rows[u][c], 0) * HD);
+                    for (int c = 0; c < 4; ++c) {
+                        if (BUF)      // a corner outside the map reads as zeros -> its dot is 0
+                            raw[u][c] = buffer_load16(rsrc, rows[u][c] >= 0 ? (uint32_t)rows[u][c] * row_bytes + lane_off
+                                                                           : kOobOffset);
+                        else
+                            raw[u][c] = *reinterpret_cast<const uint4 *>(vbase + (int64_t)max(rows[u][c], 0) * HD);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
@@ -149,7 +159,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                         float acc = 0.f;
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) acc = fmaf(g[i], v[i], acc);
-                        dot[c] = group_sum<LPI>(rows[u][c] >= 0 ? acc : 0.f);
+                        dot[c] = group_sum<LPI>((BUF || rows[u][c] >= 0) ? acc : 0.f);
                     }
                     const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
                     const float a = __uint_as_float(meta[u].z);
@@ -260,12 +270,17 @@ static hipError_t launch_vec(const void *value, const int64_t *shapes, const int
     d.q_tiles = (d.Nq + QPB - 1) / QPB;
     const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const bool buf = (int64_t)d.S * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes;
     if (scatter)
-        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, true, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
                            (float *)gv, (T *)gl, (T *)ga, d);
+    else if (buf)
+        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
+                           (float *)nullptr, (T *)gl, (T *)ga, d);
     else
-        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
                            (float *)nullptr, (T *)gl, (T *)ga, d);
     return hipGetLastError();

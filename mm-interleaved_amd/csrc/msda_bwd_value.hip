@@ -225,9 +225,11 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
 }
 
 // acc += sum over records first, first+step, ... (< end) of weight * grad_out[q, h, my 16 bytes]
-template <typename T>
+// BUF: grad_out rows through a buffer descriptor; past-the-end slots read "outside" = zeros.
+template <typename T, bool BUF>
 __device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int first, int end, int step,
                                            int iters, const T *__restrict__ gslice, int64_t HD,
+                                           __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
                                            float (&acc)[Vec16<T>::N])
 {
     typedef Vec16<T> V;
@@ -240,9 +242,13 @@ __device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int f
             const int ee = e + u * step;
             const bool ok = ee < end;
             const uint2 rec = list[ok ? ee : 0];
-            w[u] = ok ? __uint_as_float(rec.y) : 0.f;
-            raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? rec.x : 0u) * HD);
-            if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);       // 0 * Inf must not leak
+            w[u] = __uint_as_float(rec.y);
+            if (BUF) {
+                raw[u] = buffer_load16(rsrc, ok ? rec.x * row_bytes + lane_off : kOobOffset);
+            } else {
+                raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? rec.x : 0u) * HD);
+                if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
+            }
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -255,7 +261,7 @@ __device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int f
 }
 
 // LPS lanes own the D = LPS*VEC channels of one pixel (16 bytes per lane, as in the forward).
-template <typename T, int LPS, int NV>
+template <typename T, int LPS, int NV, bool BUF>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                      const T *__restrict__ loc, const T *__restrict__ attn,
@@ -288,6 +294,11 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
     T *vslice = grad_value + ((int64_t)b * d.S * d.H + h) * d.D + lig * VEC;
     float *scratch = reinterpret_cast<float *>(list);            // reused between rounds
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    __amdgpu_buffer_rsrc_t rsrc;
+    if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
+                                   ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
 
     for (int i = tid; i < npx; i += kThreads) off[i] = 0u;
     __syncthreads();
@@ -344,7 +355,7 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
                     float a2[VEC];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) a2[i] = 0.f;
-                    reduce_run<T>(list, first, first + n, 1, iters, gslice, HD, a2);
+                    reduce_run<T, BUF>(list, first, first + n, 1, iters, gslice, HD, rsrc, row_bytes, lane_off, a2);
                     if (act) {
                         const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
                         *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(a2);
@@ -359,7 +370,7 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
                 int iters = (mine + kUnroll - 1) / kUnroll;
 #pragma unroll
                 for (int o = LPS; o < 64; o <<= 1) iters = max(iters, __shfl_xor(iters, o, 64));
-                reduce_run<T>(list, first + sub, first + n, k, iters, gslice, HD, acc);
+                reduce_run<T, BUF>(list, first + sub, first + n, k, iters, gslice, HD, rsrc, row_bytes, lane_off, acc);
             }
             __syncthreads();                         // list and cur are reused
         }
@@ -448,8 +459,12 @@ hipError_t launch(const int64_t *shapes, const int64_t *start, const void *loc, 
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                       shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
+    if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
+        hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
+    else
+        hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
     return hipGetLastError();
 }
 

@@ -112,6 +112,35 @@ __device__ __forceinline__ Tap<A> locate(A lx, A ly, int Hl, int Wl, int level_s
     return t;
 }
 
+// ---------------------------------------------------------------- buffer addressing
+// Row gathers go through a buffer descriptor (SRD) whose base is the workgroup's
+// (batch, head) slab: the per-lane address is a 32-bit byte offset, and an offset at or
+// beyond num_records makes the hardware return zeros WITHOUT touching memory -- exactly
+// the reference's "corner outside the map reads 0" (cuh:58-81), with no select and no
+// clamped dummy read.  Needs the slab to be < 2 GiB; the launchers fall back to the
+// flat-address kernels otherwise.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOobOffset = 0x80000000u;
+constexpr int64_t kMaxSlabBytes = 0x7fffffffLL;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_slab_rsrc(const void *base, int64_t bytes)
+{
+    // make wave-uniformity provable (cdna_hip_programming.md T20): rebuild the pointer
+    // from readfirstlane'd halves
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+    void *p = (void *)(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)n, 0x00020000);
+}
+
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_offset, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // Workgroup -> (b, h, first query).  Blocks are dealt to XCDs round-robin
 // (block i -> XCD i % 8, observed, MI355X_MICROARCH.md "Workgroup dispatch"), so
 // taking h = block % H pins every head's value slice [S, D] of a sample to one

@@ -35,7 +35,10 @@ struct alignas(16) FwdRec {
     float w[4];
 };
 
-template <typename T, int LPI>
+// BUF = true : row reads through a buffer descriptor (32-bit offsets, hardware zero for
+//              corners outside the map)               -- slabs < 2 GiB, the normal case
+// BUF = false: 64-bit flat addresses, clamped read + select
+template <typename T, int LPI, bool BUF>
 __global__ void __launch_bounds__(kThreads)
 msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
@@ -55,7 +58,12 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const bool q_ok = q < d.Nq;
 
     const int64_t HD = (int64_t)d.H * d.D;
-    const T *vbase = value + ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D + lig * VEC;
+    const T *slab = value + ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;   // this (b, h)
+    const T *vbase = slab + lig * VEC;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    __amdgpu_buffer_rsrc_t rsrc;
+    if (BUF) rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
 
     float acc[VEC];
 #pragma unroll
@@ -87,6 +95,11 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 rec.w[2] = t.fy * gx * a; rec.w[3] = t.fy * t.fx * a;
             }
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
+            if (BUF) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)      // pixel row -> byte offset in the slab, or "outside"
+                    rec.row[c] = rec.row[c] >= 0 ? (int)((uint32_t)rec.row[c] * row_bytes) : (int)kOobOffset;
+            }
             dst[0] = make_uint4(rec.row[0], rec.row[1], rec.row[2], rec.row[3]);
             dst[1] = make_uint4(__float_as_uint(rec.w[0]), __float_as_uint(rec.w[1]),
                                 __float_as_uint(rec.w[2]), __float_as_uint(rec.w[3]));
@@ -108,9 +121,14 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     w[u][2] = __uint_as_float(ww.z); w[u][3] = __uint_as_float(ww.w);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        ok[u][c] = rows[c] >= 0;
-                        const int64_t off = (int64_t)max(rows[c], 0) * HD;
-                        raw[u][c] = *reinterpret_cast<const uint4 *>(vbase + off);
+                        if (BUF) {
+                            ok[u][c] = true;
+                            raw[u][c] = buffer_load16(rsrc, (uint32_t)rows[c] + lane_off);
+                        } else {
+                            ok[u][c] = rows[c] >= 0;
+                            const int64_t off = (int64_t)max(rows[c], 0) * HD;
+                            raw[u][c] = *reinterpret_cast<const uint4 *>(vbase + off);
+                        }
                     }
                 }
 #pragma unroll
@@ -122,7 +140,7 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                         const float wc = w[u][c];
 #pragma unroll
                         for (int i = 0; i < VEC; ++i)
-                            acc[i] = fmaf(wc, ok[u][c] ? v[i] : 0.f, acc[i]);
+                            acc[i] = fmaf(wc, (BUF || ok[u][c]) ? v[i] : 0.f, acc[i]);
                     }
                 }
             }
@@ -178,8 +196,14 @@ static hipError_t launch_vec(const void *value, const int64_t *shapes, const int
     d.q_tiles = (d.Nq + QPB - 1) / QPB;
     const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_fwd_vec<T, LPI>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                       (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d);
+    // one (batch) slab of value must be addressable with 31-bit byte offsets for the buffer path
+    const bool buf = (int64_t)d.S * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes;
+    if (buf)
+        hipLaunchKernelGGL((msda_fwd_vec<T, LPI, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d);
+    else
+        hipLaunchKernelGGL((msda_fwd_vec<T, LPI, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d);
     return hipGetLastError();
 }
 
