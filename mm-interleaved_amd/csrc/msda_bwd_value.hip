@@ -5,35 +5,36 @@
 // On MI355X global float atomics retire at ~330 G adds/s for the whole chip -- one
 // lane-add per L2 channel per clock, independent of footprint and scope -- and LDS
 // float atomics (ds_add_f32) at 0.33 lane-adds/clk/CU, while LDS *integer* atomics run
-// at ~4.5 lane-ops/clk/CU (tools/ubench/, gpurun_out logs quoted in DESIGN.md).  The
-// 2.1e9 adds of the north-star shape cost 6.1 ms that way.  So this kernel turns the
-// scatter into a gather:
+// at ~4.5 lane-ops/clk/CU (tools/ubench/, logs quoted in DESIGN.md).  The 2.1e9 adds of
+// the north-star shape cost 6.1 ms that way.  So this kernel turns the scatter into a
+// gather:
 //
 //   * a workgroup owns a rectangular tile of one level's pixels for one (batch, head):
 //     every pixel of grad_value has exactly ONE owner, so it is written once, with a
 //     plain store, directly in the storage dtype (fp32 accumulation in registers,
 //     rounded once at the end == the reference's "accumulate in fp32, cast at the end",
-//     ms_deform_attn_cuda.cu:122-165).  No fp32 buffer, no memset, no cast pass;
-//   * the workgroup scans the level's sampling locations of its (b, h) (coalesced
-//     16-byte reads), re-derives the taps and counting-sorts the contributions that land
-//     in its tile by pixel, in LDS, with integer atomics: count -> prefix -> scatter of
-//     {query, weight} records;
-//   * then the lanes of a wave own the D channels of one pixel: walk the pixel's record
-//     run (LDS broadcast reads), gather the grad_out rows (coalesced D*sizeof(T) bytes,
-//     L2-resident: the head's rows of one sample), FMA into registers, store the row.
+//     ms_deform_attn_cuda.cu:122-165).  No fp32 image, no memset, no cast pass;
+//   * the workgroup scans the level's sampling locations of its (b, h) twice: the first
+//     scan counts, per tile pixel, the tap corners that land on it (LDS integer atomics),
+//     a prefix sum turns counts into offsets, the second scan writes each contribution's
+//     {query, weight} record to its sorted position in a scratch list in global memory
+//     (exactly Nq*P*4 records per (b, h, level): no capacity limit, no overflow rounds);
+//   * then the lanes of a group own the D channels of one pixel: they read the pixel's
+//     run of records (coalesced, one record per lane, handed round with wave shuffles),
+//     gather the grad_out rows through a buffer descriptor (D*sizeof(T) contiguous
+//     bytes, L2-resident: one head's rows of one sample), FMA into registers and store
+//     the row.  When a tile has fewer pixels than the workgroup has lane groups (coarse
+//     levels), several groups share a pixel's run and combine through LDS.
 //
 // The sampling locations arrive as [B, Nq, H, L, P, 2]: for one (b, h, level) the P*2
 // scalars of consecutive queries are H*L*P*2 elements apart, so scanning them straight
-// from there wastes 7/8 of every cache line (measured: the two scans cost 310 us of a
-// 570 us kernel).  A small pre-pass therefore re-packs loc/attn into [B, H, L, Nq, P(,2)]
-// in the caller-provided workspace (3 * B*Nq*H*L*P elements); the scans then read
-// 16 contiguous bytes per lane.
+// from there wastes 7/8 of every cache line.  A small pre-pass re-packs loc/attn into
+// [B, H, L, Nq, P(,2)] in the caller-provided workspace; the scans then read 16
+// contiguous bytes per lane.
 //
 // Tiles are planned on the device from the level table (it lives in device memory, as
 // in the reference API), identically by every workgroup; the host only supplies an upper
-// bound on the tile count.  Records that do not fit the LDS list are handled in rounds
-// over pixel ranges (re-scan), and a single pixel that alone overflows it in rounds
-// over query ranges, so any distribution of sampling locations is handled.
+// bound on the tile count.
 #include "msda_device.h"
 #include "msda_launch.h"
 #include <type_traits>
@@ -43,24 +44,15 @@ namespace mmfs {
 
 namespace {
 
-#ifndef MMFS_VAL_THREADS
-#define MMFS_VAL_THREADS 1024
-#define MMFS_VAL_CAP 12288
-#define MMFS_VAL_TILEPX 4096
-#endif
-constexpr int kThreads = MMFS_VAL_THREADS;   // 1024: one workgroup per CU, 16 waves share one big record list
+constexpr int kThreads = 1024;          // 16 waves per workgroup
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxTilePx = MMFS_VAL_TILEPX;  // pixels per tile (counter arrays: 2 x 4 B each)
-constexpr int kListCap = MMFS_VAL_CAP;       // {q, weight} records per round (8 B each)
-#ifndef MMFS_VAL_UNROLL
-#define MMFS_VAL_UNROLL 8
-#endif
-constexpr int kUnroll = MMFS_VAL_UNROLL;   // grad_out rows in flight per lane group
+constexpr int kMaxTilePx = 4096;        // pixels per tile (two counter arrays of 16 KiB)
+constexpr int kUnroll = 8;              // grad_out rows in flight per lane group
 constexpr int kScanUnroll = 4;          // queries in flight per thread while scanning
 
 struct TileParams {
     int tiles_bound;   // host upper bound on tiles per (b, h) slice
-    int nt_min;        // minimum tiles per level (load balance, list capacity)
+    int nt_min;        // minimum tiles per level (load balance)
 };
 
 struct Tile {
@@ -133,13 +125,12 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
 
 enum ScanMode { kCount = 0, kScatter = 1 };
 
-// One sample against the tile: for every tap corner on a tile pixel in [p_lo, p_hi)
+// One sample against the tile: for every tap corner on a tile pixel
 //   kCount  : off[pixel] += 1
-//   kScatter: list[off[pixel] - base + cur[pixel]++] = {q, bilinear weight * attention}
+//   kScatter: list[off[pixel] + cur[pixel]++] = {q, bilinear weight * attention}
 template <int MODE>
 __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q, const Tile &tl, int tw,
-                                             int p_lo, int p_hi, uint32_t base,
-                                             uint32_t *off, uint32_t *cur, uint2 *list)
+                                             uint32_t *off, uint32_t *cur, uint2 *__restrict__ list)
 {
     const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
     const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
@@ -155,51 +146,47 @@ __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q,
         // a corner outside the map is also outside every tile
         if (yy < tl.ya || yy >= tl.yb || xx < tl.xa || xx >= tl.xb) continue;
         const int pl = (yy - tl.ya) * tw + (xx - tl.xa);
-        if (pl < p_lo || pl >= p_hi) continue;
         if (MODE == kCount) {
             atomicAdd(&off[pl], 1u);
         } else {
             const float wy = (c >> 1) ? fy : 1.f - fy, wx = (c & 1) ? fx : 1.f - fx;
-            const uint32_t slot = off[pl] - base + atomicAdd(&cur[pl], 1u);
+            const uint32_t slot = off[pl] + atomicAdd(&cur[pl], 1u);
             list[slot] = make_uint2((uint32_t)q, __float_as_uint(wy * wx * a));
         }
     }
 }
 
-// Scan the sampling locations of queries [q_lo, q_hi) at the tile's level.
-// NV > 0: the P samples of one (b,q,h,level) are NV 16-byte vectors of locations (and NV
+// Scan the sampling locations of all queries at the tile's level (re-packed copies).
+// NV > 0: the P samples of one (b,h,level,q) are NV 16-byte vectors of locations (and NV
 //         8-byte vectors of weights); kScanUnroll queries are loaded before any is used.
 // NV = 0: any P, scalar loads.
 template <typename T, int MODE, int NV>
 __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T *__restrict__ attn,
                                              const Dims &d, const Tile &tl, int b, int h,
-                                             int q_lo, int q_hi, int p_lo, int p_hi, uint32_t base,
-                                             uint32_t *off, uint32_t *cur, uint2 *list)
+                                             uint32_t *off, uint32_t *cur, uint2 *__restrict__ list)
 {
     const int tw = tl.xb - tl.xa;
-    // loc / attn are the re-packed copies [B, H, L, Nq, P(,2)]
     const int64_t qstride = d.P;                               // samples between consecutive queries
     const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
     if (NV == 0) {
-        for (int q = q_lo + (int)threadIdx.x; q < q_hi; q += kThreads) {
+        for (int q = (int)threadIdx.x; q < d.Nq; q += kThreads) {
             const int64_t s0 = s_first + q * qstride;
             for (int p = 0; p < d.P; ++p)
                 visit_sample<MODE>(to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]),
-                                   MODE == kScatter ? to_f32(attn[s0 + p]) : 0.f, q, tl, tw, p_lo, p_hi,
-                                   base, off, cur, list);
+                                   MODE == kScatter ? to_f32(attn[s0 + p]) : 0.f, q, tl, tw, off, cur, list);
         }
         return;
     }
     typedef Vec16<T> V;
     constexpr int VEC = V::N;                                  // location scalars per 16 bytes
     constexpr int NVV = NV > 0 ? NV : 1;
-    for (int q0 = q_lo + (int)threadIdx.x; q0 < q_hi; q0 += kThreads * kScanUnroll) {
+    for (int q0 = (int)threadIdx.x; q0 < d.Nq; q0 += kThreads * kScanUnroll) {
         uint4 lraw[kScanUnroll][NVV];
         uint2 araw[kScanUnroll][NVV];
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const int q = q0 + u * kThreads;
-            const int64_t s0 = s_first + (int64_t)min(q, q_hi - 1) * qstride;
+            const int64_t s0 = s_first + (int64_t)min(q, d.Nq - 1) * qstride;
 #pragma unroll
             for (int v = 0; v < NVV; ++v) {
                 lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
@@ -210,7 +197,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const int q = q0 + u * kThreads;
-            if (q >= q_hi) break;
+            if (q >= d.Nq) break;
 #pragma unroll
             for (int v = 0; v < NVV; ++v) {
                 float l[VEC], a[VEC];
@@ -218,44 +205,53 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
                 V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);   // first VEC/2 valid
 #pragma unroll
                 for (int i = 0; i < VEC / 2; ++i)
-                    visit_sample<MODE>(l[2 * i], l[2 * i + 1], a[i], q, tl, tw, p_lo, p_hi, base, off, cur, list);
+                    visit_sample<MODE>(l[2 * i], l[2 * i + 1], a[i], q, tl, tw, off, cur, list);
             }
         }
     }
 }
 
-// acc += sum over records first, first+step, ... (< end) of weight * grad_out[q, h, my 16 bytes]
-// BUF: grad_out rows through a buffer descriptor; past-the-end slots read "outside" = zeros.
-template <typename T, bool BUF>
-__device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int first, int end, int step,
-                                           int iters, const T *__restrict__ gslice, int64_t HD,
+// acc += sum over the records [first, end) taken in batches of LPS: batch j of the run is
+// handled by the group when j % k == sub (k groups share one pixel's run; k = 1: all of it).
+// Each lane of the group fetches ONE record of the batch (a coalesced LPS*8-byte read), then
+// the records are handed round the group with wave shuffles, kUnroll row gathers in flight.
+template <typename T, int LPS, bool BUF>
+__device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int first, int end, int k, int sub,
+                                           int n_batches, int lig, const T *__restrict__ gslice, int64_t HD,
                                            __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
                                            float (&acc)[Vec16<T>::N])
 {
     typedef Vec16<T> V;
-    int e = first;
-    for (int it = 0; it < iters; ++it, e += kUnroll * step) {
-        uint4 raw[kUnroll];
-        float w[kUnroll];
+    constexpr int U = LPS < kUnroll ? LPS : kUnroll;
+    for (int j = 0; j < n_batches; ++j) {
+        const int e0 = first + (sub + j * k) * LPS;
+        const int mine = e0 + lig;
+        uint2 rec = make_uint2(0u, 0u);
+        if (mine < end) rec = list[mine];
+        const uint32_t my_off = mine < end ? rec.x * row_bytes : kOobOffset;   // past the end: "outside" = zeros
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int ee = e + u * step;
-            const bool ok = ee < end;
-            const uint2 rec = list[ok ? ee : 0];
-            w[u] = __uint_as_float(rec.y);
-            if (BUF) {
-                raw[u] = buffer_load16(rsrc, ok ? rec.x * row_bytes + lane_off : kOobOffset);
-            } else {
-                raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? rec.x : 0u) * HD);
-                if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
+        for (int u0 = 0; u0 < LPS; u0 += U) {
+            uint4 raw[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t o = (uint32_t)__shfl((int)my_off, u0 + u, LPS);
+                w[u] = __shfl(__uint_as_float(rec.y), u0 + u, LPS);
+                if (BUF) {
+                    raw[u] = buffer_load16(rsrc, o + lane_off);
+                } else {
+                    const bool ok = o != kOobOffset;
+                    raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? o / row_bytes : 0u) * HD);
+                    if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            float g[V::N];
-            V::unpack(raw[u], g);
+            for (int u = 0; u < U; ++u) {
+                float g[V::N];
+                V::unpack(raw[u], g);
 #pragma unroll
-            for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
+                for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
+            }
         }
     }
 }
@@ -266,6 +262,7 @@ __global__ void __launch_bounds__(kThreads)
 msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                      const T *__restrict__ loc, const T *__restrict__ attn,
                      const T *__restrict__ grad_out, T *__restrict__ grad_value,
+                     uint2 *__restrict__ records, uint32_t *__restrict__ level_cursor,
                      const Dims d, const TileParams tp)
 {
     typedef Vec16<T> V;
@@ -273,11 +270,11 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     constexpr int GPW = 64 / LPS;                   // lane groups per wave
     constexpr int GROUPS = kWaves * GPW;            // lane groups per workgroup
     constexpr int D = LPS * VEC;
-    static_assert(GROUPS * D * 4 <= kListCap * 8, "combine scratch must fit the record list");
     __shared__ uint32_t off[kMaxTilePx + 1];
     __shared__ uint32_t cur[kMaxTilePx];
-    __shared__ uint2 list[kListCap];
     __shared__ uint32_t wave_tot[kWaves];
+    __shared__ uint32_t region;
+    __shared__ float scratch[GROUPS * D];           // partial rows when groups share a pixel
 
     const int bid = blockIdx.x;
     const int h = bid % d.H;
@@ -293,105 +290,74 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     const int64_t HD = (int64_t)d.H * d.D;
     const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
     T *vslice = grad_value + ((int64_t)b * d.S * d.H + h) * d.D + lig * VEC;
-    float *scratch = reinterpret_cast<float *>(list);            // reused between rounds
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const uint32_t lane_off = (uint32_t)(lig * 16);
     __amdgpu_buffer_rsrc_t rsrc;
     if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
                                    ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
 
-    for (int i = tid; i < npx; i += kThreads) off[i] = 0u;
+    // ---- count the tap corners per tile pixel, prefix-sum into offsets
+    for (int i = tid; i < npx; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
     __syncthreads();
-    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, 0, d.Nq, 0, npx, 0u, off, cur, list);
+    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
     block_exclusive_scan(off, npx, wave_tot);
-#if defined(MMFS_VAL_ABLATE) && MMFS_VAL_ABLATE == 1
-    return;
-#endif
+    const uint32_t total = off[npx];
+    // ---- this tile's slice of the (b, h, level) record area: the level's tiles share
+    //      Nq*P*4 slots (every tap corner lands in exactly one tile)
+    const int64_t slot = ((int64_t)b * d.H + h) * d.L + tl.level;
+    if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
+    __syncthreads();
+    uint2 *list = records + slot * ((int64_t)d.Nq * d.P * 4) + region;
+    if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, list);
+    __syncthreads();            // workgroup-scope release/acquire: the records were written by this CU
 
-    int p_lo = 0;
-    while (p_lo < npx) {
-        const uint32_t base = off[p_lo];
-        // largest p_hi in (p_lo, npx] whose records fit the list
-        int lo = p_lo, hi = npx;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (off[mid] - base <= (uint32_t)kListCap) lo = mid; else hi = mid - 1;
+    // ---- reduce: k lane groups per pixel (k = 1 when the tile has at least GROUPS pixels)
+    const int k = npx >= GROUPS ? 1 : GROUPS / npx;
+    if (k == 1) {
+        for (int p0 = 0; p0 < npx; p0 += GROUPS) {
+            const int p = p0 + gid;
+            const bool act = p < npx;
+            const int first = act ? (int)off[p] : 0;
+            const int end = act ? (int)off[p + 1] : 0;
+            int nb = (end - first + LPS - 1) / LPS;
+#pragma unroll
+            for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            reduce_run<T, LPS, BUF>(list, first, end, 1, 0, nb, lig, gslice, HD, rsrc, row_bytes, lane_off, acc);
+            if (act) {
+                const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
+                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(acc);
+            }
         }
-        const int p_hi = max(lo, p_lo + 1);
-        const bool big = lo == p_lo;                 // one pixel alone overflows the list
-        const int np = p_hi - p_lo;
-        // k lane groups share a pixel when the round has fewer pixels than groups
-        const int k = np >= GROUPS ? 1 : GROUPS / np;
-        // a pixel that overflows the list is fed in query ranges: a sample puts at most one
-        // corner on a given pixel, so qw queries give at most qw*P records
-        const int qw = big ? max(1, kListCap / max(1, d.P)) : d.Nq;
-
+    } else {
+        const int p = gid / k, sub = gid % k;
+        const bool act = p < npx;
+        const int first = act ? (int)off[p] : 0;
+        const int end = act ? (int)off[p + 1] : 0;
+        const int batches = (end - first + LPS - 1) / LPS;
+        int nb = batches > sub ? (batches - sub + k - 1) / k : 0;
+#pragma unroll
+        for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        const int my_p = p_lo + gid / k, sub = gid % k;          // used when k > 1 (or np <= GROUPS)
-
-        for (int q0 = 0; q0 < d.Nq; q0 += qw) {
-            for (int i = p_lo + tid; i < p_hi; i += kThreads) cur[i] = 0u;
-            __syncthreads();
-            if (off[p_hi] - base)
-                scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, q0, min(d.Nq, q0 + qw), p_lo, p_hi,
-                                              base, off, cur, list);
-            __syncthreads();
-#if defined(MMFS_VAL_ABLATE) && MMFS_VAL_ABLATE == 2
-            continue;
-#endif
-            if (k == 1 && np > GROUPS) {
-                // ---- many pixels: one lane group per pixel, several pixels in turn
-                for (int p0 = p_lo; p0 < p_hi; p0 += GROUPS) {
-                    const int p = p0 + gid;
-                    const bool act = p < p_hi;
-                    const int first = act ? (int)(off[p] - base) : 0;
-                    const int n = act ? (int)(off[p + 1] - off[p]) : 0;
-                    int iters = (n + kUnroll - 1) / kUnroll;
+        reduce_run<T, LPS, BUF>(list, first, end, k, sub, nb, lig, gslice, HD, rsrc, row_bytes, lane_off, acc);
 #pragma unroll
-                    for (int o = LPS; o < 64; o <<= 1) iters = max(iters, __shfl_xor(iters, o, 64));
-                    float a2[VEC];
+        for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
+        __syncthreads();
+        if (act && sub == 0) {
+            float tot[VEC];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) a2[i] = 0.f;
-                    reduce_run<T, BUF>(list, first, first + n, 1, iters, gslice, HD, rsrc, row_bytes, lane_off, a2);
-                    if (act) {
-                        const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-                        *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(a2);
-                    }
-                }
-            } else {
-                // ---- few pixels (coarse levels, hot spots): k groups stride through one pixel's run
-                const bool act = my_p < p_hi && gid < np * k;
-                const int first = act ? (int)(off[my_p] - base) : 0;
-                const int n = act ? (int)(big ? cur[my_p] : off[my_p + 1] - off[my_p]) : 0;
-                const int mine = n > sub ? (n - sub + k - 1) / k : 0;
-                int iters = (mine + kUnroll - 1) / kUnroll;
-#pragma unroll
-                for (int o = LPS; o < 64; o <<= 1) iters = max(iters, __shfl_xor(iters, o, 64));
-                reduce_run<T, BUF>(list, first + sub, first + n, k, iters, gslice, HD, rsrc, row_bytes, lane_off, acc);
+            for (int i = 0; i < VEC; ++i) {
+                tot[i] = 0.f;
+                for (int g2 = 0; g2 < k; ++g2) tot[i] += scratch[(gid + g2) * D + lig * VEC + i];
             }
-            __syncthreads();                         // list and cur are reused
+            const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
+            *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(tot);
         }
-        if (!(k == 1 && np > GROUPS)) {
-            // combine the k partial rows of every pixel through LDS (the list is free now)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
-            __syncthreads();
-            if (sub == 0 && my_p < p_hi && gid < np * k) {
-                float tot[VEC];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    tot[i] = 0.f;
-                    for (int g2 = 0; g2 < k; ++g2) tot[i] += scratch[(gid + g2) * D + lig * VEC + i];
-                }
-                const int pg = tl.lstart + (tl.ya + my_p / tw) * tl.Wl + tl.xa + my_p % tw;
-                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(tot);
-            }
-            __syncthreads();
-        }
-        p_lo = p_hi;
     }
 }
 
@@ -438,9 +404,8 @@ static hipError_t repack(const void *src, void *dst, const Dims &d, int chunk_by
 TileParams make_params(const Dims &d)
 {
     TileParams tp;
-    // Tiles are big (a whole level when it has <= kMaxTilePx pixels): a workgroup counts its
-    // tile once, then works through it in list-sized rounds, so the per-tile fixed costs
-    // (launch, plan, count scan, barriers) are paid few times.  nt_min only spreads the work
+    // Tiles are big (a whole level when it has <= kMaxTilePx pixels): the per-tile fixed costs
+    // (launch, plan, two scans, barriers) are paid few times.  nt_min only spreads the work
     // when there are few (b, h, level) slices: aim at ~3 workgroups per CU (256 CUs).
     const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
     int64_t nt = std::max<int64_t>(1, (768 + slices - 1) / slices);
@@ -452,45 +417,68 @@ TileParams make_params(const Dims &d)
     return tp;
 }
 
+struct Scratch {           // carved from the caller's workspace, 16-byte aligned pieces
+    char *loc_t, *attn_t;
+    uint32_t *cursor;
+    uint2 *records;
+    int64_t cursor_bytes, total;
+};
+
+Scratch carve(void *workspace, int dtype, const Dims &d)
+{
+    const int64_t es = dtype == 0 ? 4 : 2;
+    const int64_t pts = (int64_t)d.B * d.Nq * d.H * d.L * d.P;
+    auto up = [](int64_t v) { return (v + 15) / 16 * 16; };
+    Scratch s;
+    char *p = (char *)workspace;
+    s.loc_t = p;                 p += up(pts * 2 * es);
+    s.attn_t = p;                p += up(pts * es);
+    s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.records = (uint2 *)p;      p += up(pts * 4 * 8);
+    s.total = p - (char *)workspace;
+    return s;
+}
+
 template <typename T, int LPS, int NV>
-hipError_t launch(const int64_t *shapes, const int64_t *start, const void *loc, const void *attn,
-                  const void *go, void *gv, const Dims &d, hipStream_t st)
+hipError_t launch(const int64_t *shapes, const int64_t *start, const Scratch &sc, const void *go, void *gv,
+                  const Dims &d, hipStream_t st)
 {
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
         hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
+                           shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, (const T *)go, (T *)gv,
+                           sc.records, sc.cursor, d, tp);
     else
         hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gv, d, tp);
+                           shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, (const T *)go, (T *)gv,
+                           sc.records, sc.cursor, d, tp);
     return hipGetLastError();
 }
 
 template <typename T, int LPS>
-hipError_t dispatch_nv(int nv, const int64_t *shapes, const int64_t *start, const void *loc,
-                       const void *attn, const void *go, void *gv, const Dims &d, hipStream_t st)
+hipError_t dispatch_nv(int nv, const int64_t *shapes, const int64_t *start, const Scratch &sc,
+                       const void *go, void *gv, const Dims &d, hipStream_t st)
 {
     switch (nv) {
-        case 1: return launch<T, LPS, 1>(shapes, start, loc, attn, go, gv, d, st);
-        case 2: return launch<T, LPS, 2>(shapes, start, loc, attn, go, gv, d, st);
-        default: return launch<T, LPS, 0>(shapes, start, loc, attn, go, gv, d, st);
+        case 1: return launch<T, LPS, 1>(shapes, start, sc, go, gv, d, st);
+        case 2: return launch<T, LPS, 2>(shapes, start, sc, go, gv, d, st);
+        default: return launch<T, LPS, 0>(shapes, start, sc, go, gv, d, st);
     }
 }
 
 template <typename T>
-hipError_t dispatch(const int64_t *shapes, const int64_t *start, const void *loc, const void *attn,
-                    const void *go, void *gv, const Dims &d, hipStream_t st)
+hipError_t dispatch(const int64_t *shapes, const int64_t *start, const Scratch &sc, const void *go, void *gv,
+                    const Dims &d, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    // vectorised scan when the P locations of a (b,q,h,level) are whole, aligned 16-byte vectors
+    // vectorised scan when the P locations of a (b,h,level,q) are whole, aligned 16-byte vectors
     const int loc_bytes = d.P * 2 * (int)sizeof(T);
     int nv = 0;
-    if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2 && ((uintptr_t)loc % 16) == 0 && ((uintptr_t)attn % 8) == 0)
-        nv = loc_bytes / 16;
+    if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
     switch (d.D / VEC) {
-#define MMFS_CASE(n) case n: return dispatch_nv<T, n>(nv, shapes, start, loc, attn, go, gv, d, st);
+#define MMFS_CASE(n) case n: return dispatch_nv<T, n>(nv, shapes, start, sc, go, gv, d, st);
         MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
         default: return hipErrorInvalidValue;
@@ -502,16 +490,14 @@ hipError_t dispatch(const int64_t *shapes, const int64_t *start, const void *loc
 bool bwd_value_tiled_supported(int dtype, const Dims &d)
 {
     if (!bwd_has_vector_path(dtype, d)) return false;
-    if (d.P > kListCap) return false;
+    if ((int64_t)d.Nq * d.P * 4 > 0x7fffffffLL) return false;       // record offsets are 32-bit per level
     const TileParams tp = make_params(d);
     return (int64_t)d.B * d.H * tp.tiles_bound <= 0x7fffffffLL;
 }
 
 int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d)
 {
-    const int64_t es = dtype == 0 ? 4 : 2;
-    const int64_t pts = (int64_t)d.B * d.Nq * d.H * d.L * d.P;
-    return (pts * 2 * es + 15) / 16 * 16 + (pts * es + 15) / 16 * 16;
+    return carve(nullptr, dtype, d).total;
 }
 
 hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
@@ -520,17 +506,17 @@ hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t 
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     const int es = dtype == 0 ? 4 : 2;
-    const int64_t pts = (int64_t)d.B * d.Nq * d.H * d.L * d.P;
-    char *loc_t = (char *)workspace;
-    char *attn_t = loc_t + (pts * 2 * es + 15) / 16 * 16;
-    hipError_t e = repack(loc, loc_t, d, d.P * 2 * es, st);
+    const Scratch sc = carve(workspace, dtype, d);
+    hipError_t e = hipMemsetAsync(sc.cursor, 0, (size_t)sc.cursor_bytes, st);
     if (e != hipSuccess) return e;
-    e = repack(attn, attn_t, d, d.P * es, st);
+    e = repack(loc, sc.loc_t, d, d.P * 2 * es, st);
+    if (e != hipSuccess) return e;
+    e = repack(attn, sc.attn_t, d, d.P * es, st);
     if (e != hipSuccess) return e;
     switch (dtype) {
-        case 0: return dispatch<float>(shapes, start, loc_t, attn_t, grad_out, grad_value, d, st);
-        case 1: return dispatch<half_t>(shapes, start, loc_t, attn_t, grad_out, grad_value, d, st);
-        case 2: return dispatch<bf16_t>(shapes, start, loc_t, attn_t, grad_out, grad_value, d, st);
+        case 0: return dispatch<float>(shapes, start, sc, grad_out, grad_value, d, st);
+        case 1: return dispatch<half_t>(shapes, start, sc, grad_out, grad_value, d, st);
+        case 2: return dispatch<bf16_t>(shapes, start, sc, grad_out, grad_value, d, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -237,6 +237,9 @@ static hipError_t dispatch_fwd(const void *value, const int64_t *shapes, const i
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st)
 {
+    int qpb = 0;
+    if (forward_cached_applicable(dtype, d, &qpb))
+        return forward_cached(dtype, value, shapes, start, loc, attn, out, d, qpb, st);
     switch (dtype) {
         case 0: return dispatch_fwd<float>(value, shapes, start, loc, attn, out, d, st);
         case 1: return dispatch_fwd<half_t>(value, shapes, start, loc, attn, out, d, st);

@@ -12,6 +12,12 @@ namespace mmfs {
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
 
+// Forward with the coarse levels of the (b, h) slice held in LDS   [msda_fwd_cached.hip]
+bool forward_cached_applicable(int dtype, const Dims &d, int *q_per_block);
+hipError_t forward_cached(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                          const void *loc, const void *attn, void *out, const Dims &d, int q_per_block,
+                          hipStream_t st);
+
 // Location / attention-weight gradients (always) and, when scatter is true, grad_value
 // accumulated with global float atomics into the fp32 (fp64 for dtype 3) buffer gv_acc,
 // which the caller must have zero-filled.            [msda_bwd.hip]
