@@ -47,7 +47,7 @@ namespace {
 constexpr int kThreads = 1024;          // 16 waves per workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTilePx = 4096;        // pixels per tile (two counter arrays of 16 KiB)
-constexpr int kUnroll = 8;              // grad_out rows in flight per lane group
+constexpr int kUnroll = 16;             // grad_out rows in flight per lane group
 constexpr int kScanUnroll = 4;          // queries in flight per thread while scanning
 
 struct TileParams {
@@ -211,47 +211,53 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
     }
 }
 
-// acc += sum over the records [first, end) taken in batches of LPS: batch j of the run is
-// handled by the group when j % k == sub (k groups share one pixel's run; k = 1: all of it).
-// Each lane of the group fetches ONE record of the batch (a coalesced LPS*8-byte read), then
-// the records are handed round the group with wave shuffles, kUnroll row gathers in flight.
+// One lane's view of a batch of LPS records: the record this lane fetched (coalesced
+// LPS*8-byte read) turned into a row offset ("outside" past the end of the run) and a weight.
+struct BatchRec { uint32_t off; float w; };
+
+__device__ __forceinline__ BatchRec fetch_batch(const uint2 *__restrict__ list, int e, int end, uint32_t row_bytes)
+{
+    BatchRec r;
+    r.off = kOobOffset; r.w = 0.f;
+    if (e < end) {
+        const uint2 rec = list[e];
+        r.off = rec.x * row_bytes;
+        r.w = __uint_as_float(rec.y);
+    }
+    return r;
+}
+
+// acc += sum over one batch: the LPS records are handed round the group with wave shuffles and
+// all LPS grad_out rows are requested before the first is used.
 template <typename T, int LPS, bool BUF>
-__device__ __forceinline__ void reduce_run(const uint2 *__restrict__ list, int first, int end, int k, int sub,
-                                           int n_batches, int lig, const T *__restrict__ gslice, int64_t HD,
-                                           __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
-                                           float (&acc)[Vec16<T>::N])
+__device__ __forceinline__ void consume_batch(const BatchRec &mine, const T *__restrict__ gslice, int64_t HD,
+                                              __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
+                                              float (&acc)[Vec16<T>::N])
 {
     typedef Vec16<T> V;
     constexpr int U = LPS < kUnroll ? LPS : kUnroll;
-    for (int j = 0; j < n_batches; ++j) {
-        const int e0 = first + (sub + j * k) * LPS;
-        const int mine = e0 + lig;
-        uint2 rec = make_uint2(0u, 0u);
-        if (mine < end) rec = list[mine];
-        const uint32_t my_off = mine < end ? rec.x * row_bytes : kOobOffset;   // past the end: "outside" = zeros
 #pragma unroll
-        for (int u0 = 0; u0 < LPS; u0 += U) {
-            uint4 raw[U];
-            float w[U];
+    for (int u0 = 0; u0 < LPS; u0 += U) {
+        uint4 raw[U];
+        float w[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t o = (uint32_t)__shfl((int)my_off, u0 + u, LPS);
-                w[u] = __shfl(__uint_as_float(rec.y), u0 + u, LPS);
-                if (BUF) {
-                    raw[u] = buffer_load16(rsrc, o + lane_off);
-                } else {
-                    const bool ok = o != kOobOffset;
-                    raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? o / row_bytes : 0u) * HD);
-                    if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
-                }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t o = (uint32_t)__shfl((int)mine.off, u0 + u, LPS);
+            w[u] = __shfl(mine.w, u0 + u, LPS);
+            if (BUF) {
+                raw[u] = buffer_load16(rsrc, o + lane_off);
+            } else {
+                const bool ok = o != kOobOffset;
+                raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? o / row_bytes : 0u) * HD);
+                if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
             }
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float g[V::N];
-                V::unpack(raw[u], g);
+        for (int u = 0; u < U; ++u) {
+            float g[V::N];
+            V::unpack(raw[u], g);
 #pragma unroll
-                for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
-            }
+            for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
         }
     }
 }
@@ -282,6 +288,13 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     const int b = (bid / d.H) / tp.tiles_bound;
     const Tile tl = plan_tile(shapes, start, d.L, t, tp.nt_min);
     if (!tl.valid) return;
+#ifdef MMFS_VAL_TIMING      // experiments: per-phase shader-clock stamps of every workgroup
+    long long *stamps = reinterpret_cast<long long *>(level_cursor + MMFS_VAL_TIMING) + (size_t)blockIdx.x * 8;
+#define MMFS_STAMP(i) do { if (threadIdx.x == 0) stamps[i] = clock64(); } while (0)
+#else
+#define MMFS_STAMP(i) do { } while (0)
+#endif
+    MMFS_STAMP(0);
 
     const int tid = threadIdx.x;
     const int tw = tl.xb - tl.xa;
@@ -299,9 +312,12 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     // ---- count the tap corners per tile pixel, prefix-sum into offsets
     for (int i = tid; i < npx; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
     __syncthreads();
+    MMFS_STAMP(1);
     scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
+    MMFS_STAMP(2);
     block_exclusive_scan(off, npx, wave_tot);
+    MMFS_STAMP(3);
     const uint32_t total = off[npx];
     // ---- this tile's slice of the (b, h, level) record area: the level's tiles share
     //      Nq*P*4 slots (every tap corner lands in exactly one tile)
@@ -311,44 +327,61 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     uint2 *list = records + slot * ((int64_t)d.Nq * d.P * 4) + region;
     if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, list);
     __syncthreads();            // workgroup-scope release/acquire: the records were written by this CU
+    MMFS_STAMP(4);
 
-    // ---- reduce: k lane groups per pixel (k = 1 when the tile has at least GROUPS pixels)
+    // ---- reduce.  Lane group gid walks pixels p = gid / k, + GROUPS / k, ... (k groups share a
+    //      pixel's run when the tile has fewer pixels than the workgroup has groups); batch j of
+    //      a run belongs to sub-group j % k.  The records of the NEXT batch (possibly of the next
+    //      pixel) are requested before the current batch's rows, so the two dependent memory
+    //      latencies (record -> row) overlap across batches.
     const int k = npx >= GROUPS ? 1 : GROUPS / npx;
-    if (k == 1) {
-        for (int p0 = 0; p0 < npx; p0 += GROUPS) {
-            const int p = p0 + gid;
-            const bool act = p < npx;
-            const int first = act ? (int)off[p] : 0;
-            const int end = act ? (int)off[p + 1] : 0;
-            int nb = (end - first + LPS - 1) / LPS;
-#pragma unroll
-            for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
-            float acc[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-            reduce_run<T, LPS, BUF>(list, first, end, 1, 0, nb, lig, gslice, HD, rsrc, row_bytes, lane_off, acc);
-            if (act) {
-                const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(acc);
-            }
-        }
-    } else {
-        const int p = gid / k, sub = gid % k;
-        const bool act = p < npx;
-        const int first = act ? (int)off[p] : 0;
+    const int sub = gid % k;
+    const int pstep = GROUPS / k;
+    auto run_of = [&](int p, int &first, int &nb) {       // this sub-group's share of pixel p's run
+        const bool act = p < npx && (k == 1 || gid < npx * k);
+        first = act ? (int)off[p] : 0;
         const int end = act ? (int)off[p + 1] : 0;
         const int batches = (end - first + LPS - 1) / LPS;
-        int nb = batches > sub ? (batches - sub + k - 1) / k : 0;
+        nb = batches > sub ? (batches - sub + k - 1) / k : 0;
 #pragma unroll
-        for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
+        for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));   // wave-uniform trip count
+        return end;
+    };
+    int p = gid / k;
+    int first, nb;
+    int end = run_of(p, first, nb);
+    BatchRec pre = fetch_batch(list, first + sub * LPS + lig, end, row_bytes);
+    // a wave's groups advance together: loop while ANY group of the wave still has a pixel
+    for (;;) {
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        reduce_run<T, LPS, BUF>(list, first, end, k, sub, nb, lig, gslice, HD, rsrc, row_bytes, lane_off, acc);
+        const int pn = p + pstep;
+        int first_n = 0, nb_n = 0, end_n = 0;
+        const bool more = __any(pn < npx) && k == 1;      // wave-uniform (k > 1: one pixel per group)
+        if (more) end_n = run_of(pn, first_n, nb_n);
+        for (int j = 0; j < nb; ++j) {
+            const BatchRec cur_rec = pre;
+            if (j + 1 < nb) pre = fetch_batch(list, first + (sub + (j + 1) * k) * LPS + lig, end, row_bytes);
+            else if (more) pre = fetch_batch(list, first_n + sub * LPS + lig, end_n, row_bytes);
+            consume_batch<T, LPS, BUF>(cur_rec, gslice, HD, rsrc, row_bytes, lane_off, acc);
+        }
+        if (nb == 0 && more) pre = fetch_batch(list, first_n + sub * LPS + lig, end_n, row_bytes);
+        if (k == 1) {
+            if (p < npx) {
+                const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
+                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(acc);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
+            for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
+        }
+        if (!more) break;
+        p = pn; first = first_n; nb = nb_n; end = end_n;
+    }
+    if (k > 1) {
         __syncthreads();
-        if (act && sub == 0) {
+        if (sub == 0 && p < npx && gid < npx * k) {
             float tot[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -359,6 +392,12 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
             *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(tot);
         }
     }
+    __syncthreads();
+    MMFS_STAMP(5);
+    if (threadIdx.x == 0) { (void)npx; }
+#ifdef MMFS_VAL_TIMING
+    if (threadIdx.x == 0) { stamps[6] = total; stamps[7] = npx; }
+#endif
 }
 
 // [B, Nq, H, L, chunk] -> [B, H, L, Nq, chunk], chunk = P*2 (loc) or P (attn) elements,
