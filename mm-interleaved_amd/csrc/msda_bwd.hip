@@ -45,11 +45,25 @@ __device__ __forceinline__ void atomic_add(A *p, A v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum over the LPI lanes of a query's lane group; every lane gets the total.
+// Within a 16-lane DPP row this is pure VALU (v_add_f32 with a DPP operand: quad swaps,
+// half-row and row mirrors) -- no LDS crossbar traffic; wider groups finish with wave shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(moved);
+}
+
 template <int LPI>
 __device__ __forceinline__ float group_sum(float v)
 {
+    if (LPI >= 2) v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]  : lane ^ 1
+    if (LPI >= 4) v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]  : lane ^ 2
+    if (LPI >= 8) v = dpp_add<0x141>(v);     // row_half_mirror      : 7 - lane within 8
+    if (LPI >= 16) v = dpp_add<0x140>(v);    // row_mirror           : 15 - lane within 16
 #pragma unroll
-    for (int off = LPI / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 16; off < LPI; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
