@@ -349,7 +349,18 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
         for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));   // wave-uniform trip count
         return end;
     };
-    int p = gid / k;
+    // Walk order (k == 1): two pixel rows at a time, vertically adjacent pixels on adjacent lane
+    // groups, so the four pixels a sample touches are reduced by neighbouring groups at about
+    // the same time and three of its four grad_out row reads hit in L1 / merge in flight.
+    const int th = tl.yb - tl.ya;
+    auto pixel_of = [&](int i) {
+        if (k != 1 || i >= npx) return i;
+        const int band = i / (2 * tw), within = i - band * 2 * tw;
+        if (2 * band + 1 < th) return (2 * band + (within & 1)) * tw + (within >> 1);
+        return 2 * band * tw + within;                   // odd last row
+    };
+    int it = gid / k;
+    int p = pixel_of(it);
     int first, nb;
     int end = run_of(p, first, nb);
     BatchRec pre = fetch_batch(list, first + sub * LPS + lig, end, row_bytes);
@@ -358,9 +369,10 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        const int pn = p + pstep;
+        const int itn = it + pstep;
+        const int pn = pixel_of(itn);
         int first_n = 0, nb_n = 0, end_n = 0;
-        const bool more = __any(pn < npx) && k == 1;      // wave-uniform (k > 1: one pixel per group)
+        const bool more = __any(itn < npx) && k == 1;     // wave-uniform (k > 1: one pixel per group)
         if (more) end_n = run_of(pn, first_n, nb_n);
         for (int j = 0; j < nb; ++j) {
             const BatchRec cur_rec = pre;
@@ -379,7 +391,7 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
             for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
         }
         if (!more) break;
-        p = pn; first = first_n; nb = nb_n; end = end_n;
+        it = itn; p = pn; first = first_n; nb = nb_n; end = end_n;
     }
     if (k > 1) {
         __syncthreads();

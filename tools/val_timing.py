@@ -40,5 +40,10 @@ names = ["setup+zero", "count scan", "prefix", "alloc+scatter scan", "reduce"]
 for i, n in enumerate(names):
     print(f"  {n:20s} mean {d[:, i].mean() / 1e3:8.1f} kclk   max {d[:, i].max() / 1e3:8.1f}")
 print("  total per WG mean kclk", (st[:, 5] - st[:, 0]).double().mean().item() / 1e3, " records/WG", st[:, 6].double().mean().item(), "px/WG", st[:, 7].double().mean().item())
+for npx in sorted(set(st[:, 7].tolist())):
+    m = st[:, 7] == npx
+    dd = d[m]
+    print(f"  tiles with {int(npx):5d} px: n={int(m.sum()):4d} records/WG {st[m, 6].double().mean():9.0f}  "
+          + "  ".join(f"{n.split()[0]} {dd[:, i].mean() / 1e3:7.1f}" for i, n in enumerate(names)))
 span = (st[:, 5].max() - st[:, 0].min()).item()
 print("  first start -> last end:", span / 1e3, "kclk")
