@@ -148,6 +148,19 @@ int mmfs_msda_backward_value(int dtype,
                              int64_t B, int64_t S, int64_t H, int64_t D,
                              int64_t L, int64_t Nq, int64_t P, void *stream);
 
+/* mmfs_msda_backward_value == _prepare (re-pack loc/attn into the workspace, clear the level
+ * cursors) followed by _run (the pixel-stationary kernel); exported separately so the kernel
+ * proper can be timed / profiled on its own. */
+int mmfs_msda_backward_value_prepare(int dtype, const void *loc, const void *attn,
+                                     void *workspace, int64_t workspace_bytes,
+                                     int64_t B, int64_t S, int64_t H, int64_t D,
+                                     int64_t L, int64_t Nq, int64_t P, void *stream);
+int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
+                                 const void *grad_out, void *grad_value,
+                                 void *workspace, int64_t workspace_bytes,
+                                 int64_t B, int64_t S, int64_t H, int64_t D,
+                                 int64_t L, int64_t Nq, int64_t P, void *stream);
+
 /*
  * dst[i] = (dtype) src[i], round-to-nearest-even.  Replaces the trailing
  * ``grad_value.to(torch::kHalf)`` of the reference backward (ms_deform_attn_cuda.cu:156-165);

@@ -553,9 +553,9 @@ int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d)
     return carve(nullptr, dtype, d).total;
 }
 
-hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
-                                const void *loc, const void *attn, const void *grad_out,
-                                void *grad_value, void *workspace, const Dims &d, hipStream_t st)
+// Stage 2a: re-pack loc/attn into the workspace and clear the per-level cursors.
+hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, void *workspace,
+                                  const Dims &d, hipStream_t st)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     const int es = dtype == 0 ? 4 : 2;
@@ -564,14 +564,31 @@ hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t 
     if (e != hipSuccess) return e;
     e = repack(loc, sc.loc_t, d, d.P * 2 * es, st);
     if (e != hipSuccess) return e;
-    e = repack(attn, sc.attn_t, d, d.P * es, st);
-    if (e != hipSuccess) return e;
+    return repack(attn, sc.attn_t, d, d.P * es, st);
+}
+
+// Stage 2b: the pixel-stationary kernel on a prepared workspace.
+hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
+                              const void *grad_out, void *grad_value, void *workspace, const Dims &d,
+                              hipStream_t st)
+{
+    if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
+    const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
         case 0: return dispatch<float>(shapes, start, sc, grad_out, grad_value, d, st);
         case 1: return dispatch<half_t>(shapes, start, sc, grad_out, grad_value, d, st);
         case 2: return dispatch<bf16_t>(shapes, start, sc, grad_out, grad_value, d, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
+                                const void *loc, const void *attn, const void *grad_out,
+                                void *grad_value, void *workspace, const Dims &d, hipStream_t st)
+{
+    const hipError_t e = backward_value_prepare(dtype, loc, attn, workspace, d, st);
+    if (e != hipSuccess) return e;
+    return backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st);
 }
 
 }  // namespace mmfs

@@ -214,6 +214,51 @@ int mmfs_msda_backward_value(int dtype, const int64_t *shapes, const int64_t *st
                                            (hipStream_t)stream);
 }
 
+// The two halves of mmfs_msda_backward_value (so the kernel proper can be timed on its own).
+int mmfs_msda_backward_value_prepare(int dtype, const void *loc, const void *attn,
+                                     void *workspace, int64_t workspace_bytes,
+                                     int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                                     void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    if (B * Nq * H * L * P == 0 || B * S * H * D == 0) return MMFS_OK;
+    if (!mmfs::bwd_value_tiled_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    if (!loc || !attn) return MMFS_E_NULLPTR;
+    if (misaligned(loc, es) || misaligned(attn, es)) return MMFS_E_ALIGN;
+    if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    return (int)mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, (hipStream_t)stream);
+}
+
+int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
+                                 const void *grad_out, void *grad_value,
+                                 void *workspace, int64_t workspace_bytes,
+                                 int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                                 void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    const int64_t n_value = B * S * H * D;
+    if (n_value == 0) return MMFS_OK;
+    if (!grad_value) return MMFS_E_NULLPTR;
+    if (B * Nq * H * L * P == 0)
+        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
+    if (!mmfs::bwd_value_tiled_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    if (!shapes || !start || !grad_out) return MMFS_E_NULLPTR;
+    if (misaligned(grad_out, 16) || misaligned(grad_value, 16)) return MMFS_E_ALIGN;
+    if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    return (int)mmfs::backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d,
+                                         (hipStream_t)stream);
+}
+
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream)
 {
     if (dtype != MMFS_F32 && dtype != MMFS_F16 && dtype != MMFS_BF16) return MMFS_E_DTYPE;

@@ -31,6 +31,11 @@ bool bwd_has_vector_path(int dtype, const Dims &d);
 // grad_value (storage dtype) written exactly once.     [msda_bwd_value.hip]
 bool bwd_value_tiled_supported(int dtype, const Dims &d);
 int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d);   // re-packed loc/attn copies
+hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, void *workspace,
+                                  const Dims &d, hipStream_t st);
+hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
+                              const void *grad_out, void *grad_value, void *workspace, const Dims &d,
+                              hipStream_t st);
 hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
                                 const void *loc, const void *attn, const void *grad_out,
                                 void *grad_value, void *workspace, const Dims &d, hipStream_t st);

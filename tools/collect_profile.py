@@ -36,8 +36,9 @@ for line in open(os.path.join(src, "pmc_summary.txt")):
         continue
     for pat, short in names.items():
         if pat in kern:
-            if short == "msda_bwd_taps" and "ELb1E" in kern:
-                short = "msda_bwd_atomic"
+            m = re.search(r"msda_bwd_vecI\w+?Li\d+ELb(\d)E", kern)
+            if short == "msda_bwd_taps" and m and m.group(1) == "1":
+                short = "msda_bwd_atomic"          # first bool template argument = SCATTER
             rd = float(vals["FETCH_SIZE"]) * 1024 * 2          # gfx950 correction
             wr = float(vals.get("WRITE_SIZE", 0)) * 1024
             traffic[short] = int(rd + wr)
