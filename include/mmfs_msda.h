@@ -92,7 +92,8 @@ int mmfs_msda_forward(int dtype,
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.
  * Pixel-stationary path: re-packed copies of loc/attn (3*pts elements, pts = B*Nq*H*L*P), one
- * cursor per (b, h, level) and the pixel-sorted {query, weight} records (4*pts * 8 bytes);
+ * cursor per (b, h, level), a {first, count} run table per (b, h, pixel) and the pixel-sorted
+ * {query, weight} records (4*pts * 8 bytes);
  * atomic path with 16-bit storage: an fp32 image of grad_value.
  */
 int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,

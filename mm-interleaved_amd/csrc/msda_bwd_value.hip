@@ -19,12 +19,13 @@
 //     a prefix sum turns counts into offsets, the second scan writes each contribution's
 //     {query, weight} record to its sorted position in a scratch list in global memory
 //     (exactly Nq*P*4 records per (b, h, level): no capacity limit, no overflow rounds);
-//   * then the lanes of a group own the D channels of one pixel: they read the pixel's
-//     run of records (coalesced, one record per lane, handed round with wave shuffles),
-//     gather the grad_out rows through a buffer descriptor (D*sizeof(T) contiguous
-//     bytes, L2-resident: one head's rows of one sample), FMA into registers and store
-//     the row.  When a tile has fewer pixels than the workgroup has lane groups (coarse
-//     levels), several groups share a pixel's run and combine through LDS.
+//   * a second kernel of many small workgroups then streams over the pixels in (b, pixel, h)
+//     order: the lanes of a group own the D channels of one pixel, read the pixel's run of
+//     records (coalesced, one record per lane, handed round with wave shuffles), gather the
+//     grad_out rows through a buffer descriptor (D*sizeof(T) contiguous bytes, L2-resident:
+//     one head's rows of one sample), FMA into registers and store the row.  Runs longer than
+//     16 batches (coarse levels, hot spots) are finished by all groups of the workgroup
+//     together, combined through LDS.
 //
 // The sampling locations arrive as [B, Nq, H, L, P, 2]: for one (b, h, level) the P*2
 // scalars of consecutive queries are H*L*P*2 elements apart, so scanning them straight
@@ -47,7 +48,10 @@ namespace {
 constexpr int kThreads = 1024;          // 16 waves per workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTilePx = 4096;        // pixels per tile (two counter arrays of 16 KiB)
-constexpr int kUnroll = 16;             // grad_out rows in flight per lane group
+#ifndef MMFS_VAL_UNROLL
+#define MMFS_VAL_UNROLL 16
+#endif
+constexpr int kUnroll = MMFS_VAL_UNROLL;   // grad_out rows in flight per lane group
 constexpr int kScanUnroll = 4;          // queries in flight per thread while scanning
 
 struct TileParams {
@@ -222,9 +226,14 @@ __device__ __forceinline__ BatchRec fetch_batch(const uint2 *__restrict__ list, 
     BatchRec r;
     r.off = kOobOffset; r.w = 0.f;
     if (e < end) {
+#ifdef MMFS_VAL_FAKE_RECORDS     // experiment: how much of the reduce is record-fetch / row latency?
+        r.off = MMFS_VAL_FAKE_RECORDS == 2 ? 0u : ((uint32_t)e * 2654435761u >> 20) * row_bytes;
+        r.w = 1.f;
+#else
         const uint2 rec = list[e];
         r.off = rec.x * row_bytes;
         r.w = __uint_as_float(rec.y);
+#endif
     }
     return r;
 }
@@ -264,25 +273,20 @@ __device__ __forceinline__ void consume_batch(const BatchRec &mine, const T *__r
     }
 }
 
-// LPS lanes own the D = LPS*VEC channels of one pixel (16 bytes per lane, as in the forward).
-template <typename T, int LPS, int NV, bool BUF>
+// ---------------------------------------------------------------- kernel A: sort
+// One 1024-lane workgroup per tile: count -> prefix -> scatter, then publish for every tile
+// pixel where its run of records lives: pixtab[(b*H + h)*S + pixel] = {first record, count}.
+template <typename T, int NV>
 __global__ void __launch_bounds__(kThreads)
-msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                     const T *__restrict__ loc, const T *__restrict__ attn,
-                     const T *__restrict__ grad_out, T *__restrict__ grad_value,
-                     uint2 *__restrict__ records, uint32_t *__restrict__ level_cursor,
-                     const Dims d, const TileParams tp)
+msda_bwd_value_sort(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                    const T *__restrict__ loc, const T *__restrict__ attn,
+                    uint2 *__restrict__ records, uint32_t *__restrict__ level_cursor,
+                    uint2 *__restrict__ pixtab, const Dims d, const TileParams tp)
 {
-    typedef Vec16<T> V;
-    constexpr int VEC = V::N;
-    constexpr int GPW = 64 / LPS;                   // lane groups per wave
-    constexpr int GROUPS = kWaves * GPW;            // lane groups per workgroup
-    constexpr int D = LPS * VEC;
     __shared__ uint32_t off[kMaxTilePx + 1];
     __shared__ uint32_t cur[kMaxTilePx];
     __shared__ uint32_t wave_tot[kWaves];
     __shared__ uint32_t region;
-    __shared__ float scratch[GROUPS * D];           // partial rows when groups share a pixel
 
     const int bid = blockIdx.x;
     const int h = bid % d.H;
@@ -290,128 +294,127 @@ msda_bwd_value_tiled(const int64_t *__restrict__ shapes, const int64_t *__restri
     const int b = (bid / d.H) / tp.tiles_bound;
     const Tile tl = plan_tile(shapes, start, d.L, t, tp.nt_min);
     if (!tl.valid) return;
-#ifdef MMFS_VAL_TIMING      // experiments: per-phase shader-clock stamps of every workgroup
-    long long *stamps = reinterpret_cast<long long *>(level_cursor + MMFS_VAL_TIMING) + (size_t)blockIdx.x * 8;
-#define MMFS_STAMP(i) do { if (threadIdx.x == 0) stamps[i] = clock64(); } while (0)
-#else
-#define MMFS_STAMP(i) do { } while (0)
-#endif
-    MMFS_STAMP(0);
 
     const int tid = threadIdx.x;
     const int tw = tl.xb - tl.xa;
     const int npx = (tl.yb - tl.ya) * tw;
-    const int gid = tid / LPS, lig = tid % LPS;     // lane group, lane in group
+
+    for (int i = tid; i < npx; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
+    __syncthreads();
+    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
+    __syncthreads();
+    block_exclusive_scan(off, npx, wave_tot);
+    const uint32_t total = off[npx];
+    // this tile's slice of the (b, h, level) record area: the level's tiles share Nq*P*4 slots
+    // (every tap corner lands in exactly one tile)
+    const int64_t slot = ((int64_t)b * d.H + h) * d.L + tl.level;
+    if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
+    __syncthreads();
+    const int64_t base = slot * ((int64_t)d.Nq * d.P * 4) + region;      // absolute record index
+    if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, records + base);
+    uint2 *tab = pixtab + ((int64_t)b * d.H + h) * d.S;
+    for (int p = tid; p < npx; p += kThreads) {
+        const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
+        tab[pg] = make_uint2((uint32_t)(base + off[p]), off[p + 1] - off[p]);
+    }
+}
+
+// ---------------------------------------------------------------- kernel B: reduce
+// Many small workgroups stream over the pixels in (b, pixel, h) order, like the forward streams
+// over queries -- the grad_out rows of few (b, h) slices are live in an XCD's L2 at a time.
+// A lane group (LPS lanes x 16 B) owns one pixel: it walks the pixel's run of records in
+// batches of LPS (one coalesced record per lane, handed round with wave shuffles, all LPS
+// grad_out rows requested before the first is used) and stores the row once.
+// Runs longer than kOwnBatches batches (coarse levels, hot spots) are finished co-operatively:
+// all groups of the workgroup split the remainder and combine through LDS.
+constexpr int kRThreads = 256;
+#ifndef MMFS_VAL_OWN
+#define MMFS_VAL_OWN 16     // measured: 4 -> 473 us, 16 -> 449 us (cfg2); unroll 4/8/16 makes no difference
+#endif
+constexpr int kOwnBatches = MMFS_VAL_OWN;
+
+template <typename T, int LPS, bool BUF>
+__global__ void __launch_bounds__(kRThreads)
+msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
+                      const uint2 *__restrict__ records, const uint2 *__restrict__ pixtab,
+                      const Dims d, const int chunks)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int GROUPS = kRThreads / LPS;          // pixels per workgroup
+    constexpr int D = LPS * VEC;
+    __shared__ uint2 rest[GROUPS];                   // {first record, count} left after phase 1
+    __shared__ float scratch[GROUPS * D];
+
+    const int bid = blockIdx.x;
+    const int h = bid % d.H;
+    const int chunk = (bid / d.H) % chunks;
+    const int b = (bid / d.H) / chunks;
+    const int tid = threadIdx.x;
+    const int gid = tid / LPS, lig = tid % LPS;
+    const int pg = chunk * GROUPS + gid;             // pixel on the S axis
+    const bool act = pg < d.S;
+
     const int64_t HD = (int64_t)d.H * d.D;
     const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
-    T *vslice = grad_value + ((int64_t)b * d.S * d.H + h) * d.D + lig * VEC;
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const uint32_t lane_off = (uint32_t)(lig * 16);
     __amdgpu_buffer_rsrc_t rsrc;
     if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
                                    ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
 
-    // ---- count the tap corners per tile pixel, prefix-sum into offsets
-    for (int i = tid; i < npx; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
-    __syncthreads();
-    MMFS_STAMP(1);
-    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
-    __syncthreads();
-    MMFS_STAMP(2);
-    block_exclusive_scan(off, npx, wave_tot);
-    MMFS_STAMP(3);
-    const uint32_t total = off[npx];
-    // ---- this tile's slice of the (b, h, level) record area: the level's tiles share
-    //      Nq*P*4 slots (every tap corner lands in exactly one tile)
-    const int64_t slot = ((int64_t)b * d.H + h) * d.L + tl.level;
-    if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
-    __syncthreads();
-    uint2 *list = records + slot * ((int64_t)d.Nq * d.P * 4) + region;
-    if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, list);
-    __syncthreads();            // workgroup-scope release/acquire: the records were written by this CU
-    MMFS_STAMP(4);
+    uint2 run = make_uint2(0u, 0u);
+    if (act) run = pixtab[((int64_t)b * d.H + h) * d.S + pg];
+    const uint2 *list = records + run.x;
+    const int n = (int)run.y;
+    const int own = min(n, kOwnBatches * LPS);
 
-    // ---- reduce.  Lane group gid walks pixels p = gid / k, + GROUPS / k, ... (k groups share a
-    //      pixel's run when the tile has fewer pixels than the workgroup has groups); batch j of
-    //      a run belongs to sub-group j % k.  The records of the NEXT batch (possibly of the next
-    //      pixel) are requested before the current batch's rows, so the two dependent memory
-    //      latencies (record -> row) overlap across batches.
-    const int k = npx >= GROUPS ? 1 : GROUPS / npx;
-    const int sub = gid % k;
-    const int pstep = GROUPS / k;
-    auto run_of = [&](int p, int &first, int &nb) {       // this sub-group's share of pixel p's run
-        const bool act = p < npx && (k == 1 || gid < npx * k);
-        first = act ? (int)off[p] : 0;
-        const int end = act ? (int)off[p + 1] : 0;
-        const int batches = (end - first + LPS - 1) / LPS;
-        nb = batches > sub ? (batches - sub + k - 1) / k : 0;
+    float acc[VEC];
 #pragma unroll
-        for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));   // wave-uniform trip count
-        return end;
-    };
-    // Walk order (k == 1): two pixel rows at a time, vertically adjacent pixels on adjacent lane
-    // groups, so the four pixels a sample touches are reduced by neighbouring groups at about
-    // the same time and three of its four grad_out row reads hit in L1 / merge in flight.
-    const int th = tl.yb - tl.ya;
-    auto pixel_of = [&](int i) {
-        if (k != 1 || i >= npx) return i;
-        const int band = i / (2 * tw), within = i - band * 2 * tw;
-        if (2 * band + 1 < th) return (2 * band + (within & 1)) * tw + (within >> 1);
-        return 2 * band * tw + within;                   // odd last row
-    };
-    int it = gid / k;
-    int p = pixel_of(it);
-    int first, nb;
-    int end = run_of(p, first, nb);
-    BatchRec pre = fetch_batch(list, first + sub * LPS + lig, end, row_bytes);
-    // a wave's groups advance together: loop while ANY group of the wave still has a pixel
-    for (;;) {
-        float acc[VEC];
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    // ---- phase 1: the group's own pixel, up to kOwnBatches batches
+    int nb = (own + LPS - 1) / LPS;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        const int itn = it + pstep;
-        const int pn = pixel_of(itn);
-        int first_n = 0, nb_n = 0, end_n = 0;
-        const bool more = __any(itn < npx) && k == 1;     // wave-uniform (k > 1: one pixel per group)
-        if (more) end_n = run_of(pn, first_n, nb_n);
-        for (int j = 0; j < nb; ++j) {
-            const BatchRec cur_rec = pre;
-            if (j + 1 < nb) pre = fetch_batch(list, first + (sub + (j + 1) * k) * LPS + lig, end, row_bytes);
-            else if (more) pre = fetch_batch(list, first_n + sub * LPS + lig, end_n, row_bytes);
-            consume_batch<T, LPS, BUF>(cur_rec, gslice, HD, rsrc, row_bytes, lane_off, acc);
-        }
-        if (nb == 0 && more) pre = fetch_batch(list, first_n + sub * LPS + lig, end_n, row_bytes);
-        if (k == 1) {
-            if (p < npx) {
-                const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-                *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(acc);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = acc[i];
-        }
-        if (!more) break;
-        it = itn; p = pn; first = first_n; nb = nb_n; end = end_n;
+    for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));    // wave-uniform trip count
+    BatchRec pre = fetch_batch(list, lig, own, row_bytes);
+    for (int j = 0; j < nb; ++j) {
+        const BatchRec cur_rec = pre;
+        if (j + 1 < nb) pre = fetch_batch(list, (j + 1) * LPS + lig, own, row_bytes);
+        consume_batch<T, LPS, BUF>(cur_rec, gslice, HD, rsrc, row_bytes, lane_off, acc);
     }
-    if (k > 1) {
+    // ---- phase 2: long runs, pixel by pixel, all groups together
+    if (lig == 0) rest[gid] = make_uint2(run.x + (uint32_t)own, (uint32_t)(n - own));
+    __syncthreads();
+    for (int g = 0; g < GROUPS; ++g) {
+        const uint2 r = rest[g];                      // uniform over the workgroup
+        if (r.y == 0u) continue;
+        const uint2 *rl = records + r.x;
+        const int rn = (int)r.y;
+        const int batches = (rn + LPS - 1) / LPS;
+        float part[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) part[i] = 0.f;
+        for (int j = gid; j < batches; j += GROUPS) {
+            const BatchRec br = fetch_batch(rl, j * LPS + lig, rn, row_bytes);
+            consume_batch<T, LPS, BUF>(br, gslice, HD, rsrc, row_bytes, lane_off, part);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = part[i];
         __syncthreads();
-        if (sub == 0 && p < npx && gid < npx * k) {
-            float tot[VEC];
+        if (gid == g) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                tot[i] = 0.f;
-                for (int g2 = 0; g2 < k; ++g2) tot[i] += scratch[(gid + g2) * D + lig * VEC + i];
+                float t2 = 0.f;
+                for (int g2 = 0; g2 < GROUPS; ++g2) t2 += scratch[g2 * D + lig * VEC + i];
+                acc[i] += t2;
             }
-            const int pg = tl.lstart + (tl.ya + p / tw) * tl.Wl + tl.xa + p % tw;
-            *reinterpret_cast<uint4 *>(vslice + (int64_t)pg * HD) = V::pack(tot);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    MMFS_STAMP(5);
-    if (threadIdx.x == 0) { (void)npx; }
-#ifdef MMFS_VAL_TIMING
-    if (threadIdx.x == 0) { stamps[6] = total; stamps[7] = npx; }
-#endif
+    if (act) {
+        T *o = grad_value + (((int64_t)b * d.S + pg) * d.H + h) * d.D + lig * VEC;
+        *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+    }
 }
 
 // [B, Nq, H, L, chunk] -> [B, H, L, Nq, chunk], chunk = P*2 (loc) or P (attn) elements,
@@ -473,7 +476,8 @@ TileParams make_params(const Dims &d)
 struct Scratch {           // carved from the caller's workspace, 16-byte aligned pieces
     char *loc_t, *attn_t;
     uint32_t *cursor;
-    uint2 *records;
+    uint2 *pixtab;         // [B, H, S] {first record, count}
+    uint2 *records;        // [B, H, L, Nq*P*4] {query, weight}, pixel-sorted inside each tile
     int64_t cursor_bytes, total;
 };
 
@@ -487,38 +491,39 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     s.loc_t = p;                 p += up(pts * 2 * es);
     s.attn_t = p;                p += up(pts * es);
     s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.pixtab = (uint2 *)p;       p += up((int64_t)d.B * d.H * d.S * 8);
     s.records = (uint2 *)p;      p += up(pts * 4 * 8);
     s.total = p - (char *)workspace;
     return s;
 }
 
-template <typename T, int LPS, int NV>
-hipError_t launch(const int64_t *shapes, const int64_t *start, const Scratch &sc, const void *go, void *gv,
-                  const Dims &d, hipStream_t st)
+template <typename T, int NV>
+hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d,
+                       hipStream_t st)
 {
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
-        hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, (const T *)go, (T *)gv,
-                           sc.records, sc.cursor, d, tp);
-    else
-        hipLaunchKernelGGL((msda_bwd_value_tiled<T, LPS, NV, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, (const T *)go, (T *)gv,
-                           sc.records, sc.cursor, d, tp);
+    hipLaunchKernelGGL((msda_bwd_value_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                       shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor,
+                       sc.pixtab, d, tp);
     return hipGetLastError();
 }
 
 template <typename T, int LPS>
-hipError_t dispatch_nv(int nv, const int64_t *shapes, const int64_t *start, const Scratch &sc,
-                       const void *go, void *gv, const Dims &d, hipStream_t st)
+hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims &d, hipStream_t st)
 {
-    switch (nv) {
-        case 1: return launch<T, LPS, 1>(shapes, start, sc, go, gv, d, st);
-        case 2: return launch<T, LPS, 2>(shapes, start, sc, go, gv, d, st);
-        default: return launch<T, LPS, 0>(shapes, start, sc, go, gv, d, st);
-    }
+    constexpr int GROUPS = kRThreads / LPS;
+    const int chunks = (d.S + GROUPS - 1) / GROUPS;
+    const int64_t blocks = (int64_t)d.B * d.H * chunks;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
+        hipLaunchKernelGGL((msda_bwd_value_reduce<T, LPS, true>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.pixtab, d, chunks);
+    else
+        hipLaunchKernelGGL((msda_bwd_value_reduce<T, LPS, false>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.pixtab, d, chunks);
+    return hipGetLastError();
 }
 
 template <typename T>
@@ -530,8 +535,15 @@ hipError_t dispatch(const int64_t *shapes, const int64_t *start, const Scratch &
     const int loc_bytes = d.P * 2 * (int)sizeof(T);
     int nv = 0;
     if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
+    hipError_t e;
+    switch (nv) {
+        case 1: e = launch_sort<T, 1>(shapes, start, sc, d, st); break;
+        case 2: e = launch_sort<T, 2>(shapes, start, sc, d, st); break;
+        default: e = launch_sort<T, 0>(shapes, start, sc, d, st); break;
+    }
+    if (e != hipSuccess) return e;
     switch (d.D / VEC) {
-#define MMFS_CASE(n) case n: return dispatch_nv<T, n>(nv, shapes, start, sc, go, gv, d, st);
+#define MMFS_CASE(n) case n: return launch_reduce<T, n>(sc, go, gv, d, st);
         MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
         default: return hipErrorInvalidValue;
@@ -543,7 +555,7 @@ hipError_t dispatch(const int64_t *shapes, const int64_t *start, const Scratch &
 bool bwd_value_tiled_supported(int dtype, const Dims &d)
 {
     if (!bwd_has_vector_path(dtype, d)) return false;
-    if ((int64_t)d.Nq * d.P * 4 > 0x7fffffffLL) return false;       // record offsets are 32-bit per level
+    if ((int64_t)d.B * d.H * d.L * d.Nq * d.P * 4 > 0xffffffffLL) return false;   // 32-bit record indices
     const TileParams tp = make_params(d);
     return (int64_t)d.B * d.H * tp.tiles_bound <= 0x7fffffffLL;
 }
