@@ -63,10 +63,12 @@ def algorithmic_bytes(w, e):
     pts = B * Nq * H * Leff * P
     fwd = e * (B * S * C + 3 * pts + B * Nq * C)
     bwd = e * (2 * B * S * C + 6 * pts + B * Nq * C)
-    # the two-stage backward: each kernel priced on what IT must touch once
+    # the staged backward: each kernel priced on the tensors IT must touch once (scratch excluded)
     taps = e * (B * S * C + 6 * pts + B * Nq * C)       # value, loc, attn, grad_out -> grad_loc, grad_attn
-    val = e * (B * S * C + 3 * pts + B * Nq * C)        # loc, attn, grad_out -> grad_value
-    return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value=val, fwdbwd=fwd + bwd)
+    sort = e * 3 * pts                                  # loc, attn -> (scratch)
+    red = e * (B * S * C + B * Nq * C)                  # grad_out -> grad_value
+    return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value_sort=sort,
+                msda_bwd_value_reduce=red, fwdbwd=fwd + bwd)
 
 
 def make_inputs(w, device, seed):

@@ -150,12 +150,22 @@ int mmfs_msda_backward_value(int dtype,
                              int64_t L, int64_t Nq, int64_t P, void *stream);
 
 /* mmfs_msda_backward_value == _prepare (re-pack loc/attn into the workspace, clear the level
- * cursors) followed by _run (the pixel-stationary kernel); exported separately so the kernel
- * proper can be timed / profiled on its own. */
+ * cursors), then _sort (count / prefix / scatter the tap contributions by pixel: kernel
+ * msda_bwd_value_sort), then _reduce (one lane group per pixel gathers its run of grad_out rows:
+ * kernel msda_bwd_value_reduce).  _run == _sort + _reduce.  Exported separately so each kernel can
+ * be timed / profiled on its own. */
 int mmfs_msda_backward_value_prepare(int dtype, const void *loc, const void *attn,
                                      void *workspace, int64_t workspace_bytes,
                                      int64_t B, int64_t S, int64_t H, int64_t D,
                                      int64_t L, int64_t Nq, int64_t P, void *stream);
+int mmfs_msda_backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start,
+                                  void *workspace, int64_t workspace_bytes,
+                                  int64_t B, int64_t S, int64_t H, int64_t D,
+                                  int64_t L, int64_t Nq, int64_t P, void *stream);
+int mmfs_msda_backward_value_reduce(int dtype, const void *grad_out, void *grad_value,
+                                    void *workspace, int64_t workspace_bytes,
+                                    int64_t B, int64_t S, int64_t H, int64_t D,
+                                    int64_t L, int64_t Nq, int64_t P, void *stream);
 int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
                                  const void *grad_out, void *grad_value,
                                  void *workspace, int64_t workspace_bytes,

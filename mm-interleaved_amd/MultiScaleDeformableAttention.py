@@ -61,6 +61,10 @@ _lib.mmfs_msda_backward_value_prepare.restype = _int
 _lib.mmfs_msda_backward_value_prepare.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
 _lib.mmfs_msda_backward_value_run.restype = _int
 _lib.mmfs_msda_backward_value_run.argtypes = [_int] + [_vp] * 5 + [_i64] * 8 + [_vp]
+_lib.mmfs_msda_backward_value_sort.restype = _int
+_lib.mmfs_msda_backward_value_sort.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
+_lib.mmfs_msda_backward_value_reduce.restype = _int
+_lib.mmfs_msda_backward_value_reduce.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
@@ -256,9 +260,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                                  code, sampling_loc.data_ptr(), attn_weight.data_ptr(), ws_ptr, ws_bytes,
                                  *dims, stream)
             if status == 0:
-                status = _launch("msda_bwd_value", value.device, _lib.mmfs_msda_backward_value_run, code,
-                                 spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                                 grad_output.data_ptr(), grad_value.data_ptr(), ws_ptr, ws_bytes, *dims, stream)
+                status = _launch("msda_bwd_value_sort", value.device, _lib.mmfs_msda_backward_value_sort, code,
+                                 spatial_shapes.data_ptr(), level_start_index.data_ptr(), ws_ptr, ws_bytes,
+                                 *dims, stream)
+            if status == 0:
+                status = _launch("msda_bwd_value_reduce", value.device, _lib.mmfs_msda_backward_value_reduce,
+                                 code, grad_output.data_ptr(), grad_value.data_ptr(), ws_ptr, ws_bytes,
+                                 *dims, stream)
         if status == _E_UNSUPPORTED:
             # head width without a vector path, fp64, or a non-canonical level table:
             # the library's float-atomic path (needs an fp32 scratch for 16-bit storage)

@@ -527,21 +527,24 @@ hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims
 }
 
 template <typename T>
-hipError_t dispatch(const int64_t *shapes, const int64_t *start, const Scratch &sc, const void *go, void *gv,
-                    const Dims &d, hipStream_t st)
+hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d,
+                         hipStream_t st)
 {
-    constexpr int VEC = 16 / (int)sizeof(T);
     // vectorised scan when the P locations of a (b,h,level,q) are whole, aligned 16-byte vectors
     const int loc_bytes = d.P * 2 * (int)sizeof(T);
     int nv = 0;
     if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
-    hipError_t e;
     switch (nv) {
-        case 1: e = launch_sort<T, 1>(shapes, start, sc, d, st); break;
-        case 2: e = launch_sort<T, 2>(shapes, start, sc, d, st); break;
-        default: e = launch_sort<T, 0>(shapes, start, sc, d, st); break;
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, st);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, st);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, st);
     }
-    if (e != hipSuccess) return e;
+}
+
+template <typename T>
+hipError_t dispatch_reduce(const Scratch &sc, const void *go, void *gv, const Dims &d, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
     switch (d.D / VEC) {
 #define MMFS_CASE(n) case n: return launch_reduce<T, n>(sc, go, gv, d, st);
         MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
@@ -579,19 +582,41 @@ hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, 
     return repack(attn, sc.attn_t, d, d.P * es, st);
 }
 
-// Stage 2b: the pixel-stationary kernel on a prepared workspace.
-hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
-                              const void *grad_out, void *grad_value, void *workspace, const Dims &d,
-                              hipStream_t st)
+// Stage 2b: sort the tap contributions by pixel (prepared workspace -> records + run table).
+hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
+                               const Dims &d, hipStream_t st)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
-        case 0: return dispatch<float>(shapes, start, sc, grad_out, grad_value, d, st);
-        case 1: return dispatch<half_t>(shapes, start, sc, grad_out, grad_value, d, st);
-        case 2: return dispatch<bf16_t>(shapes, start, sc, grad_out, grad_value, d, st);
+        case 0: return dispatch_sort<float>(shapes, start, sc, d, st);
+        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, st);
+        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Stage 2c: reduce every pixel's run into its grad_value row.
+hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
+                                 const Dims &d, hipStream_t st)
+{
+    if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
+    const Scratch sc = carve(workspace, dtype, d);
+    switch (dtype) {
+        case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);
+        case 1: return dispatch_reduce<half_t>(sc, grad_out, grad_value, d, st);
+        case 2: return dispatch_reduce<bf16_t>(sc, grad_out, grad_value, d, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
+                              const void *grad_out, void *grad_value, void *workspace, const Dims &d,
+                              hipStream_t st)
+{
+    const hipError_t e = backward_value_sort(dtype, shapes, start, workspace, d, st);
+    if (e != hipSuccess) return e;
+    return backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
 }
 
 hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,

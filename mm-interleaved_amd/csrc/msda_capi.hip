@@ -234,29 +234,62 @@ int mmfs_msda_backward_value_prepare(int dtype, const void *loc, const void *att
     return (int)mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, (hipStream_t)stream);
 }
 
+// common argument checks of the sort / reduce stages; returns > 0 when there is work to launch
+static int value_stage_args(int dtype, int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
+                            int64_t P, void *workspace, int64_t workspace_bytes, mmfs::Dims *d)
+{
+    if (!elem_size(dtype)) return MMFS_E_DTYPE;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, d);
+    if (rc) return rc;
+    if (B * S * H * D == 0 || B * Nq * H * L * P == 0) return 0;
+    if (!mmfs::bwd_value_tiled_supported(dtype, *d)) return MMFS_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, *d)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    return 1;
+}
+
+int mmfs_msda_backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start,
+                                  void *workspace, int64_t workspace_bytes,
+                                  int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                                  void *stream)
+{
+    mmfs::Dims d;
+    const int rc = value_stage_args(dtype, B, S, H, D, L, Nq, P, workspace, workspace_bytes, &d);
+    if (rc <= 0) return rc;
+    if (!shapes || !start) return MMFS_E_NULLPTR;
+    return (int)mmfs::backward_value_sort(dtype, shapes, start, workspace, d, (hipStream_t)stream);
+}
+
+int mmfs_msda_backward_value_reduce(int dtype, const void *grad_out, void *grad_value,
+                                    void *workspace, int64_t workspace_bytes,
+                                    int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                                    void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    const int64_t n_value = B * S * H * D;
+    if (n_value > 0 && !grad_value) return MMFS_E_NULLPTR;
+    if (n_value > 0 && B * Nq * H * L * P == 0)
+        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
+    mmfs::Dims d;
+    const int rc = value_stage_args(dtype, B, S, H, D, L, Nq, P, workspace, workspace_bytes, &d);
+    if (rc <= 0) return rc;
+    if (!grad_out) return MMFS_E_NULLPTR;
+    if (misaligned(grad_out, 16) || misaligned(grad_value, 16)) return MMFS_E_ALIGN;
+    return (int)mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, (hipStream_t)stream);
+}
+
 int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
                                  const void *grad_out, void *grad_value,
                                  void *workspace, int64_t workspace_bytes,
                                  int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
                                  void *stream)
 {
-    const int es = elem_size(dtype);
-    if (!es) return MMFS_E_DTYPE;
-    mmfs::Dims d;
-    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    const int rc = mmfs_msda_backward_value_sort(dtype, shapes, start, workspace, workspace_bytes,
+                                                 B, S, H, D, L, Nq, P, stream);
     if (rc) return rc;
-    const int64_t n_value = B * S * H * D;
-    if (n_value == 0) return MMFS_OK;
-    if (!grad_value) return MMFS_E_NULLPTR;
-    if (B * Nq * H * L * P == 0)
-        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
-    if (!mmfs::bwd_value_tiled_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
-    if (!shapes || !start || !grad_out) return MMFS_E_NULLPTR;
-    if (misaligned(grad_out, 16) || misaligned(grad_value, 16)) return MMFS_E_ALIGN;
-    if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
-    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
-    return (int)mmfs::backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d,
-                                         (hipStream_t)stream);
+    return mmfs_msda_backward_value_reduce(dtype, grad_out, grad_value, workspace, workspace_bytes,
+                                           B, S, H, D, L, Nq, P, stream);
 }
 
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream)

@@ -33,6 +33,10 @@ bool bwd_value_tiled_supported(int dtype, const Dims &d);
 int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d);   // re-packed loc/attn copies
 hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, void *workspace,
                                   const Dims &d, hipStream_t st);
+hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
+                               const Dims &d, hipStream_t st);
+hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
+                                 const Dims &d, hipStream_t st);
 hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
                               const void *grad_out, void *grad_value, void *workspace, const Dims &d,
                               hipStream_t st);

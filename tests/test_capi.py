@@ -24,6 +24,7 @@ def test_header_declares_the_path():
     names = declared_functions()
     for n in ("mmfs_msda_forward", "mmfs_msda_backward", "mmfs_msda_backward_taps",
               "mmfs_msda_backward_value", "mmfs_msda_backward_value_prepare", "mmfs_msda_backward_value_run",
+              "mmfs_msda_backward_value_sort", "mmfs_msda_backward_value_reduce",
               "mmfs_msda_backward_workspace_bytes",
               "mmfs_msda_cast_from_f32", "mmfs_msda_abi_version", "mmfs_msda_status_string"):
         assert n in names

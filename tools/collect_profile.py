@@ -26,8 +26,9 @@ if stats:
             w.writerow(r)
 shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(dst, f"{prefix}_pmc_summary.txt"))
 
-names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_tiled": "msda_bwd_value",
-         "msda_bwd_vecI": "msda_bwd_taps", "repack_kernel": "repack"}
+names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_reduce": "msda_bwd_value_reduce",
+         "msda_bwd_value_sort": "msda_bwd_value_sort", "msda_bwd_vec_taps": "msda_bwd_taps",
+         "msda_bwd_vec_atomic": "msda_bwd_atomic"}
 traffic = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
     kern, _, rest = line.partition(": ")
@@ -36,9 +37,6 @@ for line in open(os.path.join(src, "pmc_summary.txt")):
         continue
     for pat, short in names.items():
         if pat in kern:
-            m = re.search(r"msda_bwd_vecI\w+?Li\d+ELb(\d)E", kern)
-            if short == "msda_bwd_taps" and m and m.group(1) == "1":
-                short = "msda_bwd_atomic"          # first bool template argument = SCATTER
             rd = float(vals["FETCH_SIZE"]) * 1024 * 2          # gfx950 correction
             wr = float(vals.get("WRITE_SIZE", 0)) * 1024
             traffic[short] = int(rd + wr)

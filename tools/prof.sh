@@ -29,7 +29,11 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "msda" not in k and "repack" not in k: continue
-        short = k.split("(")[0].split("::")[-1][:60]
+        import re
+        m = re.search(r"(msda_[a-z_]+|repack_kernel<\d+>|repack_kernel)", k)
+        short = m.group(1) if m else k[:60]
+        flags = re.search(r"msda_bwd_vecI\w+?Li\d+ELb(\d)E", k)          # first bool = SCATTER
+        if flags: short += "_atomic" if flags.group(1) == "1" else "_taps"
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/pmc_summary.txt", "w") as fo:
     for k, cs in sorted(agg.items()):
