@@ -226,40 +226,44 @@ __device__ __forceinline__ BatchRec fetch_batch(const uint2 *__restrict__ list, 
     BatchRec r;
     r.off = kOobOffset; r.w = 0.f;
     if (e < end) {
-#ifdef MMFS_VAL_FAKE_RECORDS     // experiment: how much of the reduce is record-fetch / row latency?
-        r.off = MMFS_VAL_FAKE_RECORDS == 2 ? 0u : ((uint32_t)e * 2654435761u >> 20) * row_bytes;
-        r.w = 1.f;
-#else
         const uint2 rec = list[e];
         r.off = rec.x * row_bytes;
         r.w = __uint_as_float(rec.y);
-#endif
     }
     return r;
 }
 
-// acc += sum over one batch: the LPS records are handed round the group with wave shuffles and
-// all LPS grad_out rows are requested before the first is used.
+// acc += sum over one batch of LPS records.  Every lane fetched one record of the batch; the
+// group needs each record on ALL its lanes (they read one row together).  The records go through
+// a small per-group LDS slot: one ds_write_b64 per lane, then a broadcast ds_read_b64 per record.
+// (Measured alternatives on MI355X at the north-star shape, this form = 350 us: ds_bpermute
+// hand-off 343 us; DPP rotation, every lane reading a different row at a time, 772 us; every lane
+// loading the batch's records itself 446 us; one wave per pixel with the records on the scalar
+// side (s_load + SGPR offsets) 493 us -- too few bytes in flight per wave.)
+// All LPS row reads are requested before the first is used.
 template <typename T, int LPS, bool BUF>
-__device__ __forceinline__ void consume_batch(const BatchRec &mine, const T *__restrict__ gslice, int64_t HD,
-                                              __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
-                                              float (&acc)[Vec16<T>::N])
+__device__ __forceinline__ void consume_batch(const BatchRec &mine, int lig, uint2 *__restrict__ slot,
+                                              const T *__restrict__ gslice, int64_t HD,
+                                              __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes,
+                                              uint32_t lane_off, float (&acc)[Vec16<T>::N])
 {
     typedef Vec16<T> V;
     constexpr int U = LPS < kUnroll ? LPS : kUnroll;
+    slot[lig] = make_uint2(mine.off, __float_as_uint(mine.w));
+    __builtin_amdgcn_wave_barrier();            // same wave writes and reads: LDS keeps program order
 #pragma unroll
     for (int u0 = 0; u0 < LPS; u0 += U) {
         uint4 raw[U];
         float w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t o = (uint32_t)__shfl((int)mine.off, u0 + u, LPS);
-            w[u] = __shfl(mine.w, u0 + u, LPS);
+            const uint2 rec = slot[u0 + u];
+            w[u] = __uint_as_float(rec.y);
             if (BUF) {
-                raw[u] = buffer_load16(rsrc, o + lane_off);
+                raw[u] = buffer_load16(rsrc, rec.x + lane_off);
             } else {
-                const bool ok = o != kOobOffset;
-                raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? o / row_bytes : 0u) * HD);
+                const bool ok = rec.x != kOobOffset;
+                raw[u] = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? rec.x / row_bytes : 0u) * HD);
                 if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);   // 0 * Inf must not leak
             }
         }
@@ -271,6 +275,7 @@ __device__ __forceinline__ void consume_batch(const BatchRec &mine, const T *__r
             for (int i = 0; i < V::N; ++i) acc[i] = fmaf(w[u], g[i], acc[i]);
         }
     }
+    __builtin_amdgcn_wave_barrier();            // the slot is rewritten by the next batch
 }
 
 // ---------------------------------------------------------------- kernel A: sort
@@ -345,6 +350,7 @@ msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     constexpr int D = LPS * VEC;
     __shared__ uint2 rest[GROUPS];                   // {first record, count} left after phase 1
     __shared__ float scratch[GROUPS * D];
+    __shared__ uint2 slots[GROUPS * (LPS + 1)];      // per-group record hand-off (+1: bank skew)
 
     const int bid = blockIdx.x;
     const int h = bid % d.H;
@@ -352,6 +358,7 @@ msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     const int b = (bid / d.H) / chunks;
     const int tid = threadIdx.x;
     const int gid = tid / LPS, lig = tid % LPS;
+    uint2 *slot = slots + gid * (LPS + 1);
     const int pg = chunk * GROUPS + gid;             // pixel on the S axis
     const bool act = pg < d.S;
 
@@ -380,7 +387,7 @@ msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     for (int j = 0; j < nb; ++j) {
         const BatchRec cur_rec = pre;
         if (j + 1 < nb) pre = fetch_batch(list, (j + 1) * LPS + lig, own, row_bytes);
-        consume_batch<T, LPS, BUF>(cur_rec, gslice, HD, rsrc, row_bytes, lane_off, acc);
+        consume_batch<T, LPS, BUF>(cur_rec, lig, slot, gslice, HD, rsrc, row_bytes, lane_off, acc);
     }
     // ---- phase 2: long runs, pixel by pixel, all groups together
     if (lig == 0) rest[gid] = make_uint2(run.x + (uint32_t)own, (uint32_t)(n - own));
@@ -396,7 +403,7 @@ msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
         for (int i = 0; i < VEC; ++i) part[i] = 0.f;
         for (int j = gid; j < batches; j += GROUPS) {
             const BatchRec br = fetch_batch(rl, j * LPS + lig, rn, row_bytes);
-            consume_batch<T, LPS, BUF>(br, gslice, HD, rsrc, row_bytes, lane_off, part);
+            consume_batch<T, LPS, BUF>(br, lig, slot, gslice, HD, rsrc, row_bytes, lane_off, part);
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) scratch[gid * D + lig * VEC + i] = part[i];
