@@ -33,9 +33,9 @@
 // [B, H, L, Nq, P(,2)] in the caller-provided workspace; the scans then read 16
 // contiguous bytes per lane.
 //
-// Tiles are planned on the device from the level table (it lives in device memory, as
-// in the reference API), identically by every workgroup; the host only supplies an upper
-// bound on the tile count.
+// Tiles are planned on the device from the level table (it lives in device memory, as in the
+// reference API) by a one-thread kernel into a table; the host only supplies an upper bound on
+// the tile count.
 #include "msda_device.h"
 #include "msda_launch.h"
 #include <type_traits>
@@ -65,35 +65,41 @@ struct Tile {
     bool valid;
 };
 
-// Every workgroup derives the same plan from the level table.
-__device__ Tile plan_tile(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                          int L, int t, int nt_min)
+// The plan is computed ONCE per launch by a single thread into a table in the workspace (the
+// level table is device memory, so the host cannot do it): the sort workgroups then fetch their
+// tile with one load and surplus workgroups exit at once.  Re-deriving the plan in every
+// workgroup cost ~3 us per workgroup at L = 4 and grows with L (L = 90 for 30 images x 3 levels).
+struct TileTable {
+    int n_tiles;
+    int pad[7];
+    Tile tile[1];          // [tiles_bound]
+};
+
+__global__ void plan_tiles_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                  int L, int nt_min, int cap, TileTable *__restrict__ table)
 {
-    Tile r;
-    r.valid = false;
-    r.level = r.Hl = r.Wl = r.lstart = r.ya = r.yb = r.xa = r.xb = 0;
-    for (int l = 0; l < L; ++l) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int n = 0;
+    for (int l = 0; l < L && n < cap; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         const int px = Hl * Wl;
         if (px <= 0) continue;
         int nt = max(nt_min, (px + kMaxTilePx - 1) / kMaxTilePx);
         nt = min(nt, px);
-        const int tpx = (px + nt - 1) / nt;                     // <= kMaxTilePx
+        const int tpx = (px + nt - 1) / nt;
         int R, C;
         if (Wl <= tpx) { R = tpx / Wl; C = Wl; } else { R = 1; C = tpx; }
-        const int ny = (Hl + R - 1) / R, nx = (Wl + C - 1) / C;
-        const int n = ny * nx;
-        if (t < n) {
-            const int ty = t / nx, tx = t % nx;
-            r.level = l; r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l];
-            r.ya = ty * R; r.yb = min(Hl, r.ya + R);
-            r.xa = tx * C; r.xb = min(Wl, r.xa + C);
-            r.valid = true;
-            return r;
-        }
-        t -= n;
+        const int lstart = (int)start[l];
+        for (int ya = 0; ya < Hl && n < cap; ya += R)
+            for (int xa = 0; xa < Wl && n < cap; xa += C) {
+                Tile t;
+                t.level = l; t.Hl = Hl; t.Wl = Wl; t.lstart = lstart;
+                t.ya = ya; t.yb = min(Hl, ya + R); t.xa = xa; t.xb = min(Wl, xa + C);
+                t.valid = true;
+                table->tile[n++] = t;
+            }
     }
-    return r;
+    table->n_tiles = n;
 }
 
 // Exclusive prefix sum over a[0..n) (n <= kMaxTilePx), total left in a[n].
@@ -286,7 +292,8 @@ __global__ void __launch_bounds__(kThreads)
 msda_bwd_value_sort(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                     const T *__restrict__ loc, const T *__restrict__ attn,
                     uint2 *__restrict__ records, uint32_t *__restrict__ level_cursor,
-                    uint2 *__restrict__ pixtab, const Dims d, const TileParams tp)
+                    uint2 *__restrict__ pixtab, const TileTable *__restrict__ table,
+                    const Dims d, const TileParams tp)
 {
     __shared__ uint32_t off[kMaxTilePx + 1];
     __shared__ uint32_t cur[kMaxTilePx];
@@ -297,8 +304,8 @@ msda_bwd_value_sort(const int64_t *__restrict__ shapes, const int64_t *__restric
     const int h = bid % d.H;
     const int t = (bid / d.H) % tp.tiles_bound;
     const int b = (bid / d.H) / tp.tiles_bound;
-    const Tile tl = plan_tile(shapes, start, d.L, t, tp.nt_min);
-    if (!tl.valid) return;
+    if (t >= table->n_tiles) return;
+    const Tile tl = table->tile[t];
 
     const int tid = threadIdx.x;
     const int tw = tl.xb - tl.xa;
@@ -483,6 +490,8 @@ TileParams make_params(const Dims &d)
 struct Scratch {           // carved from the caller's workspace, 16-byte aligned pieces
     char *loc_t, *attn_t;
     uint32_t *cursor;
+    TileTable *table;      // the tile plan (one per launch)
+    int64_t table_bytes;
     uint2 *pixtab;         // [B, H, S] {first record, count}
     uint2 *records;        // [B, H, L, Nq*P*4] {query, weight}, pixel-sorted inside each tile
     int64_t cursor_bytes, total;
@@ -498,6 +507,8 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     s.loc_t = p;                 p += up(pts * 2 * es);
     s.attn_t = p;                p += up(pts * es);
     s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.table = (TileTable *)p;    s.table_bytes = up((int64_t)sizeof(TileTable) + (int64_t)make_params(d).tiles_bound * sizeof(Tile));
+    p += s.table_bytes;
     s.pixtab = (uint2 *)p;       p += up((int64_t)d.B * d.H * d.S * 8);
     s.records = (uint2 *)p;      p += up(pts * 4 * 8);
     s.total = p - (char *)workspace;
@@ -511,9 +522,11 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min,
+                       tp.tiles_bound, sc.table);
     hipLaunchKernelGGL((msda_bwd_value_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor,
-                       sc.pixtab, d, tp);
+                       sc.pixtab, sc.table, d, tp);
     return hipGetLastError();
 }
 

@@ -84,8 +84,10 @@ def test_backward_workspace_query_is_host_only():
     f.argtypes = [ctypes.c_int] + [i64] * 7 + [ctypes.c_uint]
     dims = (8, 5440, 8, 128, 4, 4096, 4)
     pts = 8 * 4096 * 8 * 4 * 4
-    # bf16, canonical levels: re-packed loc/attn + level cursors + per-pixel run table + sorted records
-    assert f(2, *dims, 1) == 3 * pts * 2 + 8 * 8 * 4 * 4 + 8 * 8 * 5440 * 8 + pts * 4 * 8
+    # bf16, canonical levels: re-packed loc/attn + level cursors + tile plan + per-pixel run table
+    # + pixel-sorted {query, weight} records
+    base = 3 * pts * 2 + 8 * 8 * 4 * 4 + 8 * 8 * 5440 * 8 + pts * 4 * 8
+    assert base < f(2, *dims, 1) <= base + (1 << 20)
     assert f(2, *dims, 0) == 8 * 5440 * 8 * 128 * 4          # unknown level table: fp32 image for atomics
     assert f(2, *dims, 3) == 8 * 5440 * 8 * 128 * 4          # forced atomic
     assert f(0, *dims, 0) == 0                               # fp32 atomics accumulate in grad_value itself
