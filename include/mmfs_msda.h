@@ -180,6 +180,38 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
  */
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MMFS sampling plan: everything the reference's MMFS.forward does
+ * between its Linear layers and the op, mm_interleaved/models/utils/ops/modules/mmfs.py:181-265
+ * (relative-position term, per-level offset scaling, visibility penalty, constant sink logit,
+ * softmax over all n*L*(P+1) logits, offsets -> normalised locations), in ONE kernel each way.
+ * The linear heads are evaluated by the caller as head(W q) (off_q, att_q) plus table rows
+ * head.weight @ query_relpos[m] (off_tab, att_tab); see mmfs_amd/modules/mmfs.py.
+ *
+ *   off_q   [N, Lq, H, P, 2]       att_q   [N, Lq, H, L, P]            (storage dtype)
+ *   off_tab [M, H, P, 2]           att_tab [M, H, L, P]                (storage dtype)
+ *           (point columns only: the head's (P+1)-th "sink" column is a constant, mmfs.py:225)
+ *   relpos  [N, Lr, n] int64   image's rank among the visible ones, 0 = not visible; Lr = 1 or Lq
+ *   ref     [Nr, Lq, 2] fp32   reference point (x, y) per query; Nr = 1 or N
+ *   shapes  [n*L, 2] int64 (H_l, W_l);   ratios [L] fp32 (spatial_shape / base_spatial_shape)
+ *   loc     [N, Lq, H, n*L, P, 2]  attn [N, Lq, H, n*L, P]  (storage dtype)   sink [N, Lq, H] fp32
+ * Limits: P in {4, 8, 16}, n*L <= 64 (else MMFS_E_UNSUPPORTED: use the framework ops).
+ * Backward: d_off_q / d_att_q are fully written (fp32, shaped like off_q / att_q); d_off_tab /
+ * d_att_tab (fp32, shaped like the tables) are ACCUMULATED into and must be zero-filled by the
+ * caller; grad_sink may be NULL (the sink weights feed nothing trainable in the reference).
+ */
+int mmfs_plan_forward(int dtype, const void *off_q, const void *att_q, const void *off_tab,
+                      const void *att_tab, const int64_t *relpos, const float *ref,
+                      const int64_t *shapes, const float *ratios, void *loc, void *attn, float *sink,
+                      int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                      int64_t Lr, int64_t Nr, void *stream);
+int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, const float *grad_sink,
+                       const void *attn, const float *sink, const int64_t *relpos,
+                       const int64_t *shapes, const float *ratios,
+                       float *d_off_q, float *d_att_q, float *d_off_tab, float *d_att_tab,
+                       int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                       int64_t Lr, int64_t Nr, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

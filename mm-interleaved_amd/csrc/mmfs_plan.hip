@@ -1,0 +1,379 @@
+// mmfs_plan.hip -- the MMFS "sampling plan" fused into one kernel each way.
+//
+// Between its Linear layers and the deformable-attention op the reference runs ~20 elementwise /
+// reduction kernels over [N, Lq, H, n*L, P(+1)] tensors
+// (mm_interleaved/models/utils/ops/modules/mmfs.py:181-265): add the per-image relative-position
+// term, scale offsets per level, add the visibility penalty, overwrite the sink logit, softmax
+// over all n*L*(P+1) logits, split points / sinks, divide offsets by the level extent, add the
+// reference point, cast.  With the two linear heads rewritten as  head(Wq) + table[relpos]
+// (mmfs_amd/modules/mmfs.py) everything after the GEMMs is a per-(sample, query, head) function
+// of two small vectors and two table rows; this file evaluates it in one pass, in fp32, from
+//     off_q  [N, Lq, H, P, 2]      = sampling_offsets(q')          (bias included)
+//     att_q  [N, Lq, H, L, P]      = attention_weights(q'), point columns only (the sink column
+//                                    is a constant, mmfs.py:225, and is never computed)
+//     off_tab[M, H, P, 2], att_tab[M, H, L, P]     = head.weight @ query_relpos rows
+//     relpos [N, Lr, n] int64      (0 = image not visible; Lr = 1 or Lq)
+// to
+//     loc  [N, Lq, H, n*L, P, 2],  attn [N, Lq, H, n*L, P],  sink [N, Lq, H] (sum of sink weights).
+//
+// One lane owns one (image, level) row of P logits / P locations (a 16-byte vector for bf16 P=8);
+// the 2^k >= n*L lanes of an item reduce with wave shuffles.  The backward walks runs of consecutive
+// queries and keeps the gradient of the lane's table row in registers (the relative position of
+// an image changes at most once per image along the sequence), flushing it with a few float atomics.
+#include "../../include/mmfs_msda.h"
+#include "msda_device.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <type_traits>
+
+namespace mmfs {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kQueryRun = 8;            // backward: consecutive queries a lane group walks (table grads in registers)
+
+struct PlanDims {
+    int N, Lq, H, L, P, n, M, Lr, Nr;
+};
+
+// lane group: G = 2^k lanes, one per (image, level) row of P points; reductions stay inside it
+template <int G> __device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_add(float v)
+{
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// P elements of T <-> floats, as one aligned vector access (P * sizeof(T) is 8, 16 or 32 bytes)
+template <typename T, int P> __device__ __forceinline__ void load_row(const T *p, float (&o)[P])
+{
+    T tmp[P];
+    __builtin_memcpy(tmp, __builtin_assume_aligned(p, P * sizeof(T) >= 16 ? 16 : P * sizeof(T)), P * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < P; ++i) o[i] = to_f32(tmp[i]);
+}
+template <typename T, int P> __device__ __forceinline__ void store_row(T *p, const float (&v)[P])
+{
+    T tmp[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) tmp[i] = (T)v[i];
+    __builtin_memcpy(__builtin_assume_aligned(p, P * sizeof(T) >= 16 ? 16 : P * sizeof(T)), tmp, P * sizeof(T));
+}
+
+// Forward: lane <-> one (item, image, level) row of P logits; G lanes (>= n*L) form an item.
+//   att_q [N, Lq, H, L, P]  att_tab [M, H, L, P]   (the dead sink column is not computed at all)
+template <typename T, int P, int G>
+__global__ void __launch_bounds__(kThreads)
+plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
+                    const T *__restrict__ off_tab, const T *__restrict__ att_tab,
+                    const int64_t *__restrict__ relpos, const float *__restrict__ ref,
+                    const int64_t *__restrict__ shapes, const float *__restrict__ ratios,
+                    T *__restrict__ loc, T *__restrict__ attn, float *__restrict__ sink, const PlanDims d)
+{
+    constexpr int IPB = kThreads / G;                       // items per workgroup
+    const int gl = threadIdx.x % G;                         // row of the item: kl = k*L + l
+    const int64_t item = (int64_t)blockIdx.x * IPB + threadIdx.x / G;     // (nb*Lq + q)*H + h
+    const int nL = d.n * d.L;
+    const bool item_ok = item < (int64_t)d.N * d.Lq * d.H;
+    const bool act = item_ok && gl < nL;
+    const int64_t it = item_ok ? item : 0;
+    const int h = (int)(it % d.H);
+    const int64_t nq = it / d.H;
+    const int q = (int)(nq % d.Lq);
+    const int nb = (int)(nq / d.Lq);
+    const int k = act ? gl / d.L : 0, l = act ? gl % d.L : 0;
+    const int64_t r = relpos[((int64_t)nb * d.Lr + (d.Lr == 1 ? 0 : q)) * d.n + k];
+    const float sink_logit = -logf((float)nL);
+
+    float lg[P];
+    float m = sink_logit;
+    if (act) {
+        float a[P], t[P];
+        load_row<T, P>(att_q + (it * d.L + l) * P, a);
+        load_row<T, P>(att_tab + ((r * d.H + h) * d.L + l) * P, t);
+        const float pen = r == 0 ? -10000.f : 0.f;          // image not visible (mmfs.py:203-218)
+#pragma unroll
+        for (int p = 0; p < P; ++p) { lg[p] = a[p] + t[p] + pen; m = fmaxf(m, lg[p]); }
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) lg[p] = -INFINITY;
+    }
+    m = group_max<G>(m);
+    float z = act ? __expf(sink_logit - m) : 0.f;           // this row's sink slot (mmfs.py:225)
+    const float my_sink = z;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { lg[p] = __expf(lg[p] - m); z += lg[p]; }
+    z = group_add<G>(z);
+    const float inv = 1.f / z;
+    const float sink_sum = group_add<G>(my_sink) * inv;
+    if (item_ok && gl == 0) sink[item] = sink_sum;
+    if (!act) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) lg[p] *= inv;
+    const int64_t row = item * nL + gl;
+    store_row<T, P>(attn + row * P, lg);
+    // locations: ref + (offset_q + offset_table) * ratio_l / (W, H)        (mmfs.py:193-198, 243-250)
+    float oq[2 * P], ot[2 * P], xy[2 * P];
+    load_row<T, 2 * P>(off_q + it * 2 * P, oq);
+    load_row<T, 2 * P>(off_tab + (r * d.H + h) * 2 * P, ot);
+    const float rx = ref[((int64_t)(d.Nr == 1 ? 0 : nb) * d.Lq + q) * 2];
+    const float ry = ref[((int64_t)(d.Nr == 1 ? 0 : nb) * d.Lq + q) * 2 + 1];
+    const float sx = ratios[l] / (float)shapes[2 * gl + 1], sy = ratios[l] / (float)shapes[2 * gl];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        xy[2 * p] = rx + (oq[2 * p] + ot[2 * p]) * sx;
+        xy[2 * p + 1] = ry + (oq[2 * p + 1] + ot[2 * p + 1]) * sy;
+    }
+    store_row<T, 2 * P>(loc + row * 2 * P, xy);
+}
+
+// Backward: same lane <-> row map; a lane group walks kQueryRun consecutive queries of one
+// (sample, head) and keeps the gradients of ITS table row (image k's relative position) in
+// registers, flushing them with P + 2P float atomics when the relative position changes or the
+// run ends.  d_att_q / d_off_q need the sum over the images of a level / over the levels of an
+// image: done through a per-group LDS slab.
+template <typename T, int P, int G>
+__global__ void __launch_bounds__(kThreads)
+plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_attn,
+                     const float *__restrict__ grad_sink, const T *__restrict__ attn,
+                     const float *__restrict__ sink, const int64_t *__restrict__ relpos,
+                     const int64_t *__restrict__ shapes, const float *__restrict__ ratios,
+                     float *__restrict__ d_off_q, float *__restrict__ d_att_q,
+                     float *__restrict__ d_off_tab, float *__restrict__ d_att_tab, const PlanDims d)
+{
+    constexpr int GPB = kThreads / G;                       // lane groups per workgroup
+    __shared__ float slab[GPB][G][3 * P];                   // per row: dlogit[P] | doff[2P]
+    __shared__ long long seg_key[GPB][G];                   // (sample*H + head, relpos) of the row's table grads
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int q_runs = (d.Lq + kQueryRun - 1) / kQueryRun;
+    const int64_t unit = (int64_t)blockIdx.x * GPB + grp;   // (nb*H + h)*q_runs + run
+    const int nL = d.n * d.L;
+    const bool unit_ok = unit < (int64_t)d.N * d.H * q_runs;
+    const int64_t u = unit_ok ? unit : 0;
+    const int run = (int)(u % q_runs);
+    const int h = (int)((u / q_runs) % d.H);
+    const int nb = (int)(u / q_runs / d.H);
+    const bool act = unit_ok && gl < nL;
+    const int k = act ? gl / d.L : 0, l = act ? gl % d.L : 0;
+    const float sx = act ? ratios[l] / (float)shapes[2 * gl + 1] : 0.f;
+    const float sy = act ? ratios[l] / (float)shapes[2 * gl] : 0.f;
+
+    float t_att[P], t_off[2 * P];
+    int64_t t_rp = -1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { t_att[p] = 0.f; t_off[2 * p] = 0.f; t_off[2 * p + 1] = 0.f; }
+    auto flush = [&]() {
+        if (t_rp < 0) return;
+        float *ta = d_att_tab + ((t_rp * d.H + h) * d.L + l) * P;
+        float *to = d_off_tab + (t_rp * d.H + h) * 2 * P;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            __hip_atomic_fetch_add(ta + p, t_att[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(to + 2 * p, t_off[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(to + 2 * p + 1, t_off[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t_att[p] = 0.f; t_off[2 * p] = 0.f; t_off[2 * p + 1] = 0.f;
+        }
+    };
+
+    const int q_lo = run * kQueryRun, q_hi = min(d.Lq, q_lo + kQueryRun);
+    for (int q = q_lo; q < q_hi; ++q) {
+        const int64_t item = ((int64_t)nb * d.Lq + q) * d.H + h;
+        float w[P], g[P], dl[P], dof[2 * P];
+        float part = 0.f;
+        int64_t r = 0;
+        if (act) {
+            r = relpos[((int64_t)nb * d.Lr + (d.Lr == 1 ? 0 : q)) * d.n + k];
+            if (r != t_rp) { flush(); t_rp = r; }
+            const int64_t row = item * nL + gl;
+            load_row<T, P>(attn + row * P, w);
+            load_row<T, P>(grad_attn + row * P, g);
+#pragma unroll
+            for (int p = 0; p < P; ++p) part += w[p] * g[p];
+        }
+        // softmax backward: dlogit_i = w_i (g_i - sum_j w_j g_j), the sinks' share included
+        float dot = group_add<G>(part);
+        if (unit_ok && grad_sink) dot += grad_sink[item] * sink[item];
+        if (act) {
+            float gxy[2 * P];
+            load_row<T, 2 * P>(grad_loc + (item * nL + gl) * 2 * P, gxy);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dl[p] = w[p] * (g[p] - dot);
+                dof[2 * p] = gxy[2 * p] * sx;
+                dof[2 * p + 1] = gxy[2 * p + 1] * sy;
+                t_att[p] += dl[p];
+                t_off[2 * p] += dof[2 * p];
+                t_off[2 * p + 1] += dof[2 * p + 1];
+                slab[grp][gl][p] = dl[p];
+                slab[grp][gl][P + 2 * p] = dof[2 * p];
+                slab[grp][gl][P + 2 * p + 1] = dof[2 * p + 1];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // a group never spans waves (G <= 64)
+        // d_att_q[item, l, :] = sum over images k of dlogit[k*L + l, :]  (rows l < L do it)
+        if (unit_ok && gl < d.L) {
+            float acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = 0.f;
+            for (int kk = 0; kk < d.n; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] += slab[grp][kk * d.L + gl][p];
+            store_row<float, P>(d_att_q + (item * d.L + gl) * P, acc);
+        }
+        // d_off_q[item, :, :] = sum over all rows (images and levels) of doff  (row 0 does it)
+        if (unit_ok && gl == 0) {
+            float acc[2 * P];
+#pragma unroll
+            for (int p = 0; p < 2 * P; ++p) acc[p] = 0.f;
+            for (int rr = 0; rr < nL; ++rr)
+#pragma unroll
+                for (int p = 0; p < 2 * P; ++p) acc[p] += slab[grp][rr][P + p];
+            store_row<float, 2 * P>(d_off_q + item * 2 * P, acc);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the table rows are shared by every query of a (sample, head): same-address atomics
+    //      serialise in L2 (measured: 6.6 ms when every lane group flushed its own), so the groups
+    //      of the workgroup -- consecutive query runs, normally the same table row -- are summed
+    //      through LDS first and only the first group of each equal-key segment issues atomics.
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        slab[grp][gl][p] = t_att[p];
+        slab[grp][gl][P + 2 * p] = t_off[2 * p];
+        slab[grp][gl][P + 2 * p + 1] = t_off[2 * p + 1];
+    }
+    seg_key[grp][gl] = (act && t_rp >= 0) ? (((long long)nb * d.H + h) << 20 | (long long)t_rp) : -1LL - grp;
+    __syncthreads();
+    if (act && t_rp >= 0 && (grp == 0 || seg_key[grp - 1][gl] != seg_key[grp][gl])) {
+        const long long key = seg_key[grp][gl];
+        for (int g2 = grp + 1; g2 < GPB && seg_key[g2][gl] == key; ++g2) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                t_att[p] += slab[g2][gl][p];
+                t_off[2 * p] += slab[g2][gl][P + 2 * p];
+                t_off[2 * p + 1] += slab[g2][gl][P + 2 * p + 1];
+            }
+        }
+        flush();
+    }
+}
+
+int esize(int dtype) { return dtype == MMFS_F32 ? 4 : (dtype == MMFS_F16 || dtype == MMFS_BF16) ? 2 : 0; }
+
+int check_dims(int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M, int64_t Lr,
+               int64_t Nr, PlanDims *d)
+{
+    const int64_t lim = 0x7fffffffLL;
+    if (N < 0 || Lq < 0 || H <= 0 || L <= 0 || P <= 0 || n <= 0 || M <= 0) return MMFS_E_DIMS;
+    if (N > lim || Lq > lim || H > lim || n > lim || M > lim) return MMFS_E_DIMS;
+    if ((Lr != 1 && Lr != Lq) || (Nr != 1 && Nr != N)) return MMFS_E_DIMS;
+    if ((P != 4 && P != 8 && P != 16) || n * L > 64) return MMFS_E_UNSUPPORTED;
+    if (N * Lq * H > lim) return MMFS_E_DIMS;
+    d->N = (int)N; d->Lq = (int)Lq; d->H = (int)H; d->L = (int)L; d->P = (int)P; d->n = (int)n;
+    d->M = (int)M; d->Lr = (int)Lr; d->Nr = (int)Nr;
+    return MMFS_OK;
+}
+
+}  // namespace
+}  // namespace mmfs
+
+// dispatch over the points per row P (4, 8, 16) and the lane-group width G (pow2 >= n*L)
+template <typename T, int P, typename F>
+static int for_group(int nL, F &&f)
+{
+    if (nL <= 4) return f(std::integral_constant<int, 4>());
+    if (nL <= 8) return f(std::integral_constant<int, 8>());
+    if (nL <= 16) return f(std::integral_constant<int, 16>());
+    if (nL <= 32) return f(std::integral_constant<int, 32>());
+    return f(std::integral_constant<int, 64>());
+}
+
+extern "C" {
+
+int mmfs_plan_forward(int dtype, const void *off_q, const void *att_q, const void *off_tab,
+                      const void *att_tab, const int64_t *relpos, const float *ref,
+                      const int64_t *shapes, const float *ratios, void *loc, void *attn, float *sink,
+                      int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                      int64_t Lr, int64_t Nr, void *stream)
+{
+    using namespace mmfs;
+    if (!esize(dtype)) return MMFS_E_DTYPE;
+    PlanDims d;
+    const int rc = check_dims(N, Lq, H, L, P, n, M, Lr, Nr, &d);
+    if (rc) return rc;
+    const int64_t items = N * Lq * H;
+    if (items == 0) return MMFS_OK;
+    if (!off_q || !att_q || !off_tab || !att_tab || !relpos || !ref || !shapes || !ratios || !loc || !attn || !sink)
+        return MMFS_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto tag_t, auto tag_p) {
+        typedef decltype(tag_t) T;
+        constexpr int PP = decltype(tag_p)::value;
+        return for_group<T, PP>(d.n * d.L, [&](auto tag_g) {
+            constexpr int G = decltype(tag_g)::value;
+            const unsigned blocks = (unsigned)((items + kThreads / G - 1) / (kThreads / G));
+            hipLaunchKernelGGL((plan_forward_kernel<T, PP, G>), dim3(blocks), dim3(kThreads), 0, st,
+                               (const T *)off_q, (const T *)att_q, (const T *)off_tab, (const T *)att_tab,
+                               relpos, ref, shapes, ratios, (T *)loc, (T *)attn, sink, d);
+            return (int)hipGetLastError();
+        });
+    };
+    auto by_p = [&](auto tag_t) {
+        if (P == 4) return go(tag_t, std::integral_constant<int, 4>());
+        if (P == 8) return go(tag_t, std::integral_constant<int, 8>());
+        return go(tag_t, std::integral_constant<int, 16>());
+    };
+    if (dtype == MMFS_F32) return by_p(float());
+    if (dtype == MMFS_F16) return by_p(half_t());
+    return by_p(bf16_t());
+}
+
+int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, const float *grad_sink,
+                       const void *attn, const float *sink, const int64_t *relpos,
+                       const int64_t *shapes, const float *ratios,
+                       float *d_off_q, float *d_att_q, float *d_off_tab, float *d_att_tab,
+                       int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                       int64_t Lr, int64_t Nr, void *stream)
+{
+    using namespace mmfs;
+    if (!esize(dtype)) return MMFS_E_DTYPE;
+    PlanDims d;
+    const int rc = check_dims(N, Lq, H, L, P, n, M, Lr, Nr, &d);
+    if (rc) return rc;
+    if (N * Lq * H == 0) return MMFS_OK;
+    if (!grad_loc || !grad_attn || !attn || !sink || !relpos || !shapes || !ratios || !d_off_q || !d_att_q ||
+        !d_off_tab || !d_att_tab)
+        return MMFS_E_NULLPTR;
+    const int64_t units = N * H * ((Lq + kQueryRun - 1) / kQueryRun);
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto tag_t, auto tag_p) {
+        typedef decltype(tag_t) T;
+        constexpr int PP = decltype(tag_p)::value;
+        return for_group<T, PP>(d.n * d.L, [&](auto tag_g) {
+            constexpr int G = decltype(tag_g)::value;
+            const unsigned blocks = (unsigned)((units + kThreads / G - 1) / (kThreads / G));
+            hipLaunchKernelGGL((plan_backward_kernel<T, PP, G>), dim3(blocks), dim3(kThreads), 0, st,
+                               (const T *)grad_loc, (const T *)grad_attn, grad_sink, (const T *)attn, sink,
+                               relpos, shapes, ratios, d_off_q, d_att_q, d_off_tab, d_att_tab, d);
+            return (int)hipGetLastError();
+        });
+    };
+    auto by_p = [&](auto tag_t) {
+        if (P == 4) return go(tag_t, std::integral_constant<int, 4>());
+        if (P == 8) return go(tag_t, std::integral_constant<int, 8>());
+        return go(tag_t, std::integral_constant<int, 16>());
+    };
+    if (dtype == MMFS_F32) return by_p(float());
+    if (dtype == MMFS_F16) return by_p(half_t());
+    return by_p(bf16_t());
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""Fused MMFS sampling plan: one gfx950 kernel each way for everything the
+reference's MMFS.forward does between its Linear layers and the op
+(mm_interleaved/models/utils/ops/modules/mmfs.py:181-265).  C ABI: ``mmfs_plan_forward`` /
+``mmfs_plan_backward`` in include/mmfs_msda.h; kernels in csrc/mmfs_plan.hip.
+
+``mmfs_plan_supported`` tells the module whether the fused path applies (device tensors, 2-D
+reference points shared by all levels, L*(P+1) <= 256); otherwise the module evaluates the same
+mathematics with framework ops -- that is NOT a CPU fallback of the sampling op, only of this
+front-end, and it is what the CPU parity tests of the module exercise.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+import MultiScaleDeformableAttention as MSDA
+
+_lib = MSDA._lib
+_i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+_lib.mmfs_plan_forward.restype = _int
+_lib.mmfs_plan_forward.argtypes = [_int] + [_vp] * 11 + [_i64] * 9 + [_vp]
+_lib.mmfs_plan_backward.restype = _int
+_lib.mmfs_plan_backward.argtypes = [_int] + [_vp] * 12 + [_i64] * 9 + [_vp]
+_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def mmfs_plan_supported(query, reference_points, n_levels, n_points, n_images):
+    return (query.is_cuda and query.dtype in _CODE and reference_points.shape[-1] == 2
+            and reference_points.shape[2] == 1 and n_points in (4, 8, 16) and n_images * n_levels <= 64)
+
+
+class MMFSPlanFunction(Function):
+    """(off_q [N,Lq,H*P*2], att_q [N,Lq,H*L*P], off_tab [M,H*P*2], att_tab [M,H*L*P]  -- point columns
+    only, the sink column of the attention head is a constant and is never evaluated --
+    relpos [N,Lr,n] long, ref [Nr,Lq,2] fp32, shapes [n*L,2] long, ratios [L] fp32, H, L, P)
+    -> loc [N,Lq,H,n*L,P,2], attn [N,Lq,H,n*L,P], sink [N,Lq,H] (fp32)."""
+
+    @staticmethod
+    def forward(ctx, off_q, att_q, off_tab, att_tab, relpos, ref, shapes, ratios, H, L, P):
+        dt = off_q.dtype
+        N, Lq = off_q.shape[0], off_q.shape[1]
+        n, Lr, Nr, M = relpos.shape[-1], relpos.shape[1], ref.shape[0], off_tab.shape[0]
+        off_q, att_q = off_q.contiguous(), att_q.to(dt).contiguous()
+        off_tab, att_tab = off_tab.to(dt).contiguous(), att_tab.to(dt).contiguous()
+        relpos, ref, ratios = relpos.contiguous(), ref.float().contiguous(), ratios.float().contiguous()
+        dev = off_q.device
+        loc = torch.empty((N, Lq, H, n * L, P, 2), dtype=dt, device=dev)
+        attn = torch.empty((N, Lq, H, n * L, P), dtype=dt, device=dev)
+        sink = torch.empty((N, Lq, H), dtype=torch.float32, device=dev)
+        dims = (N, Lq, H, L, P, n, M, Lr, Nr)
+        with torch.cuda.device(dev):
+            rc = MSDA._launch("mmfs_plan_fwd", dev, _lib.mmfs_plan_forward, _CODE[dt], off_q.data_ptr(),
+                              att_q.data_ptr(), off_tab.data_ptr(), att_tab.data_ptr(), relpos.data_ptr(),
+                              ref.data_ptr(), shapes.data_ptr(), ratios.data_ptr(), loc.data_ptr(),
+                              attn.data_ptr(), sink.data_ptr(), *dims, MSDA._stream(dev))
+        MSDA._check(rc, "mmfs_plan_forward")
+        ctx.save_for_backward(attn, sink, relpos, shapes, ratios)
+        ctx.dims = dims
+        ctx.shapes_in = (off_q.shape, att_q.shape, off_tab.shape, att_tab.shape)
+        return loc, attn, sink
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loc, g_attn, g_sink):
+        attn, sink, relpos, shapes, ratios = ctx.saved_tensors
+        dt, dev = attn.dtype, attn.device
+        N, Lq, H, L, P, n, M, Lr, Nr = ctx.dims
+        g_loc = g_loc.to(dt).contiguous()
+        g_attn = g_attn.to(dt).contiguous()
+        g_sink = g_sink.float().contiguous() if g_sink is not None else None
+        d_off_q = torch.empty((N, Lq, H * P * 2), dtype=torch.float32, device=dev)
+        d_att_q = torch.empty((N, Lq, H * L * P), dtype=torch.float32, device=dev)
+        d_off_tab = torch.zeros((M, H * P * 2), dtype=torch.float32, device=dev)
+        d_att_tab = torch.zeros((M, H * L * P), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = MSDA._launch("mmfs_plan_bwd", dev, _lib.mmfs_plan_backward, _CODE[dt], g_loc.data_ptr(),
+                              g_attn.data_ptr(), g_sink.data_ptr() if g_sink is not None else None,
+                              attn.data_ptr(), sink.data_ptr(), relpos.data_ptr(), shapes.data_ptr(),
+                              ratios.data_ptr(), d_off_q.data_ptr(), d_att_q.data_ptr(), d_off_tab.data_ptr(),
+                              d_att_tab.data_ptr(), N, Lq, H, L, P, n, M, Lr, Nr, MSDA._stream(dev))
+        MSDA._check(rc, "mmfs_plan_backward")
+        s0, s1, s2, s3 = ctx.shapes_in
+        return (d_off_q.to(dt).reshape(s0), d_att_q.to(dt).reshape(s1), d_off_tab.to(dt).reshape(s2),
+                d_att_tab.to(dt).reshape(s3), None, None, None, None, None, None, None)

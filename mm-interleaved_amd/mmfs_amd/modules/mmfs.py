@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
+from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported
 from ..levels import host_shapes
 
 
@@ -63,6 +64,7 @@ class MMFS(nn.Module):
         self.ratio = ratio
         self.offset_init_magnitude = offset_init_magnitude
         self.max_num_image_per_seq = max_num_image_per_seq
+        self.fused_plan = True                    # use csrc/mmfs_plan.hip when it applies
         d_inner = int(d_model * ratio)
         self.d_inner = d_inner
 
@@ -108,8 +110,8 @@ class MMFS(nn.Module):
 
     def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images):
         """Everything between the query and the op: sampling locations [N,Lq,H,n*L,P,2],
-        attention weights over the real points [N,Lq,H,n*L,P], and the sink weights
-        [N,Lq,H,n*L] (mmfs.py:154-163, 174-265)."""
+        attention weights over the real points [N,Lq,H,n*L,P], and the summed sink weights
+        [N,Lq,H] (mmfs.py:154-163, 174-265)."""
         N, Lq, _ = query.shape
         H, L, P, n = self.n_heads, self.n_levels, self.n_points, n_images
         nL = n * L
@@ -123,6 +125,18 @@ class MMFS(nn.Module):
         table = self.query_relpos.weight                                      # [max_img, d_query]
         off_tab = F.linear(table, self.sampling_offsets.weight)               # [max_img, H*P*2]
         att_tab = F.linear(table, self.attention_weights.weight)              # [max_img, H*L*(P+1)]
+
+        if self.fused_plan and mmfs_plan_supported(q, reference_points, L, P, n):
+            # one gfx950 kernel for the rest (csrc/mmfs_plan.hip), fp32 inside, rounded once.  Only
+            # the P point columns of the attention head are evaluated: its (P+1)-th column is
+            # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
+            dq = self.attention_weights.in_features
+            aw_w = self.attention_weights.weight.view(H, L, P + 1, dq)[:, :, :P].reshape(H * L * P, dq)
+            aw_b = self.attention_weights.bias.view(H, L, P + 1)[:, :, :P].reshape(H * L * P)
+            loc, attn, sink_sum = MMFSPlanFunction.apply(
+                self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, F.linear(table, aw_w), relpos,
+                reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
+            return loc, attn, sink_sum
 
         # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
         offsets = self.sampling_offsets(q)[:, :, None, :] + off_tab[relpos]
@@ -142,7 +156,7 @@ class MMFS(nn.Module):
         sink = points.new_full((N, Lq, H, n, L, 1), -math.log(nL))
         probs = F.softmax(torch.cat((points, sink), -1).reshape(N, Lq, H, nL * (P + 1)), -1)
         probs = probs.view(N, Lq, H, nL, P + 1)
-        attn, sink_w = probs[..., :P].contiguous(), probs[..., P]
+        attn, sink_w = probs[..., :P].contiguous(), probs[..., P].sum(-1)
 
         if reference_points.shape[-1] == 2:
             wh = torch.stack((input_spatial_shapes[:, 1], input_spatial_shapes[:, 0]), -1)
@@ -181,5 +195,5 @@ class MMFS(nn.Module):
                                          loc.to(value.dtype).contiguous(), attn, self.im2col_step)
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
-        out = out + (tok * sink_w.sum(-1, keepdim=True).to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
+        out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
         return self.output_proj(out)

@@ -112,7 +112,7 @@ def test_mmfs_known_answers(oracle_op):
     am = T(z["attention_mask"]).bool()                    # [B, n]
     per_image = attn.reshape(*attn.shape[:3], f.shape[1], L, -1).sum((-1, -2))   # [B, Lq, H, n]
     assert (per_image[~am[:, None, None, :].expand_as(per_image)] < 1e-300).all()
-    total = attn.sum((-1, -2)) + sink.sum(-1)
+    total = attn.sum((-1, -2)) + sink
     assert torch.allclose(total, torch.ones_like(total)) and (attn.sum((-1, -2)) < 1).all()
     # the normalised location is the same at every level of one image (scale_ratios cancel)
     loc5 = loc.reshape(*loc.shape[:3], f.shape[1], L, *loc.shape[4:])

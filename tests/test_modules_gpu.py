@@ -133,3 +133,42 @@ def test_bank_builders_on_gpu():
                                                     max_num_image=3)
     assert torch.equal(out["cross_attention_mask"].cpu(), torch.from_numpy(z["cross_attention_mask"]))
     assert torch.equal(out["mmfs_features_mm"].cpu(), torch.from_numpy(z["mmfs_features_mm"]))
+
+
+@pytest.mark.parametrize("n,mask_kind", [(1, "2d"), (3, "3d"), (10, "3d")])
+def test_fused_sampling_plan_matches_framework_ops(n, mask_kind):
+    """csrc/mmfs_plan.hip (one kernel each way) against the same mathematics in framework ops,
+    fp32: locations, weights, sink share, and every gradient that flows back through them.
+    n = 10 takes the kernel's atomic (non-register) table-gradient path."""
+    from mmfs_amd.modules import MMFS
+    from mmfs_amd.levels import make_level_tables
+    torch.manual_seed(0)
+    cfg = dict(d_model=64, d_query=48, d_value=32, d_out=48, n_levels=3, n_heads=4, n_points=4, ratio=1.0,
+               offset_init_magnitude=2.0, spatial_shapes=[8, 4, 2], base_spatial_shape=4, max_num_image_per_seq=12)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MMFS(**cfg).to(DEV)
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.05)
+        m.ignore_token.normal_(0, 0.3)
+    N, Lq = 2, 37
+    sh, st, S = make_level_tables([(8, 8), (4, 4), (2, 2)], n, DEV)
+    q = torch.randn(N, Lq, 48, device=DEV)
+    f = torch.randn(N, n, S // n, 32, device=DEV)
+    ref = torch.rand(1, Lq, 1, 2, device=DEV)
+    if mask_kind == "2d":
+        mask = torch.ones(N, n, device=DEV, dtype=torch.long)
+    else:   # image k becomes visible at token ~ k*3; one fully masked row
+        t = torch.arange(Lq, device=DEV)[None, :, None]
+        mask = (t >= 3 * torch.arange(n, device=DEV)[None, None, :] + 2).float().repeat(N, 1, 1)
+        mask[1, :, 0] = 0
+    res = {}
+    for fused in (True, False):
+        m.fused_plan = fused
+        m.zero_grad()
+        qq, ff = q.clone().requires_grad_(True), f.clone().requires_grad_(True)
+        out = m(qq, ref, ff, sh, st, None, mask)
+        out.backward(torch.ones_like(out) * 0.1)
+        res[fused] = [out.detach(), qq.grad, ff.grad] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+    for a, b in zip(res[True], res[False]):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-4 * scale, float((a - b).abs().max())
