@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 2
+#define MMFS_MSDA_ABI_VERSION 3
 
 enum mmfs_dtype {
     MMFS_F32  = 0,
@@ -171,6 +171,64 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
                                  void *workspace, int64_t workspace_bytes,
                                  int64_t B, int64_t S, int64_t H, int64_t D,
                                  int64_t L, int64_t Nq, int64_t P, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hybrid path (no counterpart in the reference; same results within the storage type's
+ * rounding).  On MI355X the row gathers of this op are bound by the vector-memory path, not by
+ * HBM, and every level receives the same number of taps whatever its size.  When the caller can
+ * hand over a HOST copy of the level table (``host_shapes`` [L, 2], ``host_start`` [L]: int64 in
+ * host memory, equal to the device tables), levels of at most min(256, 64*P) pixels are
+ * evaluated as dense products on the matrix cores (csrc/msda_dense.hip):
+ *     forward     out += A_l . V_l          grad_value_l = A_l^T . grad_out
+ *     taps        dot = grad_out . V_l^T    (then 4 look-ups per sample)
+ * with A_l the [queries x pixels] matrix of bilinear*attention weights, carried as hi + lo
+ * 16-bit halves (>= 16 significant bits); the other levels run through the kernels of the
+ * plain entry points, restricted to those levels.
+ * Applies to MMFS_F16 / MMFS_BF16, D in {32, 64, 128}, L <= 64, Nq >= 32, at least one such level;
+ * otherwise the *_workspace_bytes queries return 0 and the calls MMFS_E_UNSUPPORTED: use the
+ * plain entry points.  The backward additionally needs MMFS_BWD_CANONICAL_LEVELS.
+ * One behavioural difference, inherent to a dense product: a NON-FINITE value / grad_out element
+ * inside a dense level propagates (0 * Inf = NaN) to every query of its (b, h), not only to the
+ * queries that sample it.  Environment MMFS_HYBRID=0 disables the routing.
+ *
+ * ``stages`` selects which launches a call issues (OR of the bits; all of them = the whole
+ * pass, in this order), so each kernel can be timed on its own.
+ */
+#define MMFS_HYB_FWD_COARSE 1u          /* pack the dense levels' value, MFMA product -> fp32 partial output */
+#define MMFS_HYB_FWD_FINE   2u          /* row gathers of the other levels on top of it -> out */
+#define MMFS_HYB_FWD_ALL    3u
+int64_t mmfs_msda_forward_hybrid_workspace_bytes(int dtype,
+                                                 const int64_t *host_shapes, const int64_t *host_start,
+                                                 int64_t B, int64_t S, int64_t H, int64_t D,
+                                                 int64_t L, int64_t Nq, int64_t P);
+int mmfs_msda_forward_hybrid(int dtype,
+                             const void *value, const int64_t *shapes, const int64_t *start,
+                             const int64_t *host_shapes, const int64_t *host_start,
+                             const void *loc, const void *attn, void *out,
+                             void *workspace, int64_t workspace_bytes,
+                             int64_t B, int64_t S, int64_t H, int64_t D,
+                             int64_t L, int64_t Nq, int64_t P, unsigned stages, void *stream);
+
+#define MMFS_HYB_BWD_TAPS_FINE      1u
+#define MMFS_HYB_BWD_TAPS_COARSE    2u
+#define MMFS_HYB_BWD_VALUE_PREPARE  4u
+#define MMFS_HYB_BWD_VALUE_SORT     8u
+#define MMFS_HYB_BWD_VALUE_REDUCE  16u
+#define MMFS_HYB_BWD_VALUE_COARSE  32u  /* must follow _REDUCE: it overwrites the dense levels' rows */
+#define MMFS_HYB_BWD_ALL           63u
+int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype,
+                                                  const int64_t *host_shapes, const int64_t *host_start,
+                                                  int64_t B, int64_t S, int64_t H, int64_t D,
+                                                  int64_t L, int64_t Nq, int64_t P, unsigned flags);
+int mmfs_msda_backward_hybrid(int dtype,
+                              const void *value, const int64_t *shapes, const int64_t *start,
+                              const int64_t *host_shapes, const int64_t *host_start,
+                              const void *loc, const void *attn, const void *grad_out,
+                              void *grad_value, void *grad_loc, void *grad_attn,
+                              void *workspace, int64_t workspace_bytes,
+                              int64_t B, int64_t S, int64_t H, int64_t D,
+                              int64_t L, int64_t Nq, int64_t P,
+                              unsigned flags, unsigned stages, void *stream);
 
 /*
  * dst[i] = (dtype) src[i], round-to-nearest-even.  Replaces the trailing

@@ -24,9 +24,11 @@ shared library raises at import time.
 import ctypes
 import os
 
+import numpy as np
 import torch
 
-__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "library_path", "build_info"]
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "register_level_tables", "library_path",
+           "build_info"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MMFS_MSDA_LIB", os.path.join(_HERE, "libmmfs_msda.so"))
@@ -38,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 2
+_ABI_VERSION = 3
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -65,6 +67,14 @@ _lib.mmfs_msda_backward_value_sort.restype = _int
 _lib.mmfs_msda_backward_value_sort.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
 _lib.mmfs_msda_backward_value_reduce.restype = _int
 _lib.mmfs_msda_backward_value_reduce.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
+_lib.mmfs_msda_forward_hybrid_workspace_bytes.restype = _i64
+_lib.mmfs_msda_forward_hybrid_workspace_bytes.argtypes = [_int, _vp, _vp] + [_i64] * 7
+_lib.mmfs_msda_forward_hybrid.restype = _int
+_lib.mmfs_msda_forward_hybrid.argtypes = [_int] + [_vp] * 9 + [_i64] * 8 + [ctypes.c_uint, _vp]
+_lib.mmfs_msda_backward_hybrid_workspace_bytes.restype = _i64
+_lib.mmfs_msda_backward_hybrid_workspace_bytes.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint]
+_lib.mmfs_msda_backward_hybrid.restype = _int
+_lib.mmfs_msda_backward_hybrid.argtypes = [_int] + [_vp] * 12 + [_i64] * 8 + [ctypes.c_uint, ctypes.c_uint, _vp]
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
@@ -170,11 +180,38 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     sampling_loc, attn_weight = _same_dtype(value, sampling_loc, attn_weight)
     value = _aligned(value)
     out = torch.empty((B, Nq, H * D), dtype=value.dtype, device=value.device)
+    code = _DTYPE_CODE[value.dtype]
+    dims = (B, S, H, D, L, Nq, P)
     with torch.cuda.device(value.device):
-        status = _launch(
-            "msda_fwd", value.device, _lib.mmfs_msda_forward, _DTYPE_CODE[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
-            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-            out.data_ptr(), B, S, H, D, L, Nq, P, _stream(value.device))
+        stream = _stream(value.device)
+        status = _E_UNSUPPORTED
+        # hybrid routing (small levels on the matrix cores) needs the level table on the host: one
+        # small device->host copy the first time a pair of table tensors is seen, none when they
+        # come from mmfs_amd.levels.make_level_tables / register_level_tables (like the backward)
+        info = None
+        if _hybrid and code in (1, 2) and D in (32, 64, 128) and L <= 64 and Nq >= 32:
+            info = _level_info(spatial_shapes, level_start_index, S)
+        if info is not None:
+            hs, hst = info[1].ctypes.data, info[2].ctypes.data
+            ws_bytes = _lib.mmfs_msda_forward_hybrid_workspace_bytes(code, hs, hst, *dims)
+            if ws_bytes > 0:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+                args = (code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs, hst,
+                        sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes,
+                        *dims)
+                if _event_log is None:
+                    status = _lib.mmfs_msda_forward_hybrid(*args, _HYB_FWD_ALL, stream)
+                else:
+                    status = _launch("msda_fwd_coarse", value.device, _lib.mmfs_msda_forward_hybrid,
+                                     *args, _HYB_FWD_COARSE, stream)
+                    if status == 0:
+                        status = _launch("msda_fwd", value.device, _lib.mmfs_msda_forward_hybrid,
+                                         *args, _HYB_FWD_FINE, stream)
+        if status == _E_UNSUPPORTED:
+            status = _launch(
+                "msda_fwd", value.device, _lib.mmfs_msda_forward, code, value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                out.data_ptr(), *dims, stream)
     _check(status, "ms_deform_attn_forward")
     return out
 
@@ -186,6 +223,14 @@ _E_UNSUPPORTED = -5
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
+# tests / measurements: False keeps every level on the row-gather kernels
+_hybrid = os.environ.get("MMFS_HYBRID", "1") != "0"
+
+# stage bits of the *_hybrid entry points (include/mmfs_msda.h)
+_HYB_FWD_COARSE, _HYB_FWD_FINE, _HYB_FWD_ALL = 1, 2, 3
+_HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
+                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16), ("msda_bwd_value_coarse", 32))
+_HYB_BWD_ALL = 63
 
 
 def levels_are_canonical(spatial_shapes, level_start_index, S):
@@ -197,20 +242,51 @@ def levels_are_canonical(spatial_shapes, level_start_index, S):
     the tensor object (keyed by the in-place version counters).  mmfs_amd's own callers
     create their tables once with ``mmfs_amd.levels.make_level_tables`` which pre-seeds
     the cache, so the training loop never syncs here."""
-    key = (spatial_shapes._version, level_start_index._version, level_start_index.data_ptr(), int(S))
+    return _level_info(spatial_shapes, level_start_index, S)[0]
+
+
+def _level_key(spatial_shapes, level_start_index, S):
+    return (spatial_shapes._version, level_start_index._version, level_start_index.data_ptr(), int(S))
+
+
+def _level_info(spatial_shapes, level_start_index, S, sync=True):
+    """(canonical, host copy of spatial_shapes, host copy of level_start_index) -- the host
+    copies are contiguous int64 numpy arrays (what the hybrid entry points take).  Cached on
+    the spatial_shapes tensor object; with sync=False returns None instead of copying."""
+    key = _level_key(spatial_shapes, level_start_index, S)
     cached = getattr(spatial_shapes, "_mmfs_canonical", None)
     if cached is not None and cached[0] == key:
-        return cached[1]
-    sh = spatial_shapes.detach().cpu()
-    st = level_start_index.detach().cpu().reshape(-1)
+        return cached[1:]
+    if not sync:
+        return None
+    sh = spatial_shapes.detach().cpu().contiguous()
+    st = level_start_index.detach().cpu().reshape(-1).contiguous()
+    return _seed_level_info(spatial_shapes, key, sh, st, S)
+
+
+def _seed_level_info(spatial_shapes, key, sh, st, S):
     px = sh[:, 0] * sh[:, 1]
     canon = bool((sh >= 0).all()) and bool((sh < 65536).all()) and \
         bool(torch.equal(st, px.cumsum(0) - px)) and int(px.sum()) == int(S)
+    info = (canon, np.ascontiguousarray(sh.numpy(), dtype=np.int64),
+            np.ascontiguousarray(st.numpy(), dtype=np.int64))
     try:
-        spatial_shapes._mmfs_canonical = (key, canon)
+        spatial_shapes._mmfs_canonical = (key,) + info
     except Exception:
         pass
-    return canon
+    return info
+
+
+def register_level_tables(spatial_shapes, level_start_index, S, host_shapes=None, host_start=None):
+    """Tell the shim what a pair of device level tables contains (one device->host copy now, or
+    none when the host copies are passed), so that neither pass ever has to look: enables the
+    pixel-stationary backward and the hybrid routing of small levels from the first call."""
+    key = _level_key(spatial_shapes, level_start_index, S)
+    if host_shapes is None or host_start is None:
+        return _level_info(spatial_shapes, level_start_index, S)
+    sh = torch.as_tensor(host_shapes, dtype=torch.long).reshape(-1, 2).contiguous()
+    st = torch.as_tensor(host_start, dtype=torch.long).reshape(-1).contiguous()
+    return _seed_level_info(spatial_shapes, key, sh, st, S)
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
@@ -236,20 +312,41 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     code = _DTYPE_CODE[dt]
     dims = (B, S, H, D, L, Nq, P)
     flags = 0
+    info = None
     if _bwd_algo == "atomic":
         flags |= _BWD_FORCE_ATOMIC
-    elif levels_are_canonical(spatial_shapes, level_start_index, S):
-        flags |= _BWD_CANONICAL_LEVELS
+    else:
+        info = _level_info(spatial_shapes, level_start_index, S)
+        if info[0]:
+            flags |= _BWD_CANONICAL_LEVELS
     grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
     grad_loc = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
     grad_attn = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
     with torch.cuda.device(value.device):
         stream = _stream(value.device)
         status = _E_UNSUPPORTED
-        ws_bytes = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
+        hyb_bytes = 0
+        if _hybrid and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
+            hs, hst = info[1].ctypes.data, info[2].ctypes.data
+            hyb_bytes = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
+        if hyb_bytes > 0:
+            # small levels on the matrix cores, the others through the gather / sort / reduce kernels
+            ws = torch.empty(hyb_bytes, dtype=torch.uint8, device=value.device)
+            args = (code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs, hst,
+                    sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                    grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr(), hyb_bytes,
+                    *dims, flags)
+            if _event_log is None:
+                status = _lib.mmfs_msda_backward_hybrid(*args, _HYB_BWD_ALL, stream)
+            else:
+                for name, bit in _HYB_BWD_STAGES:
+                    status = _launch(name, value.device, _lib.mmfs_msda_backward_hybrid, *args, bit, stream)
+                    if status != 0:
+                        break
+        ws_bytes = 0 if hyb_bytes > 0 else _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
-        if flags & _BWD_CANONICAL_LEVELS:
+        if hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS):
             # pixel-stationary backward, stage by stage (so each kernel can be timed)
             status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
                              value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),

@@ -77,7 +77,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
              const T *__restrict__ attn, const T *__restrict__ grad_out,
              float *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
-             const Dims d)
+             const Dims d, const LevelSel sel)
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
@@ -85,12 +85,20 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int KC = (kRecsPerBlock / QPB) > kUnroll ? (kRecsPerBlock / QPB) : kUnroll;
     constexpr int STRIDE = 2 * KC + 1;
     __shared__ uint4 lds[QPB * STRIDE];
+    __shared__ uint8_t sel_idx[kMaxSelLevels];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
     const int qi = tid / LPI, lig = tid % LPI;
     const int q = bc.q0 + qi;
     const bool q_ok = q < d.Nq;
+    // hybrid routing: the levels not in sel get their grad_loc / grad_attn from msda_taps_coarse
+    const bool all_levels = sel.n < 0;
+    const int Ksel = all_levels ? d.K : sel.n * d.P;
+    if (!all_levels) {
+        if (tid < kMaxSelLevels) sel_idx[tid] = sel.idx[tid];
+        __syncthreads();
+    }
 
     const int64_t HD = (int64_t)d.H * d.D;
     const int64_t slice = ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;
@@ -114,8 +122,8 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
     }
 
-    for (int k0 = 0; k0 < d.K; k0 += KC) {
-        const int kc = min(KC, d.K - k0);
+    for (int k0 = 0; k0 < Ksel; k0 += KC) {
+        const int kc = min(KC, Ksel - k0);
         const int kc_pad = (kc + kUnroll - 1) / kUnroll * kUnroll;
         if (k0 > 0) __syncthreads();
         // ---- stage
@@ -127,8 +135,9 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             uint32_t wh = 0;
             const int sq = bc.q0 + rq;
             if (kk < kc && sq < d.Nq) {
-                const int k = k0 + kk;
-                const int l = k / d.P;
+                const int ks = k0 + kk;
+                const int l = all_levels ? ks / d.P : (int)sel_idx[ks / d.P];
+                const int k = l * d.P + ks % d.P;
                 const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
                 const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
                 const Tap<float> t = locate<float>(to_f32(loc[2 * s]), to_f32(loc[2 * s + 1]), Hl, Wl,
@@ -206,7 +215,9 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const int sq = bc.q0 + rq;
             if (kk >= kc || sq >= d.Nq) continue;
             const uint4 res = lds[rq * STRIDE + 2 * kk];
-            const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + (k0 + kk);
+            const int ks = k0 + kk;
+            const int k = all_levels ? ks : (int)sel_idx[ks / d.P] * d.P + ks % d.P;
+            const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
             grad_attn[s] = (T)__uint_as_float(res.x);
             grad_loc[2 * s] = (T)__uint_as_float(res.y);
             grad_loc[2 * s + 1] = (T)__uint_as_float(res.z);
@@ -278,7 +289,7 @@ cast_kernel(const float *__restrict__ src, T *__restrict__ dst, const int64_t n)
 template <typename T, int LPI>
 static hipError_t launch_vec(const void *value, const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *go, void *gv, void *gl,
-                             void *ga, Dims d, bool scatter, hipStream_t st)
+                             void *ga, Dims d, bool scatter, hipStream_t st, const LevelSel &sel)
 {
     constexpr int QPB = kThreads / LPI;
     d.q_tiles = (d.Nq + QPB - 1) / QPB;
@@ -288,15 +299,15 @@ static hipError_t launch_vec(const void *value, const int64_t *shapes, const int
     if (scatter)
         hipLaunchKernelGGL((msda_bwd_vec<T, LPI, true, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
-                           (float *)gv, (T *)gl, (T *)ga, d);
+                           (float *)gv, (T *)gl, (T *)ga, d, sel);
     else if (buf)
         hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
-                           (float *)nullptr, (T *)gl, (T *)ga, d);
+                           (float *)nullptr, (T *)gl, (T *)ga, d, sel);
     else
         hipLaunchKernelGGL((msda_bwd_vec<T, LPI, false, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go,
-                           (float *)nullptr, (T *)gl, (T *)ga, d);
+                           (float *)nullptr, (T *)gl, (T *)ga, d, sel);
     return hipGetLastError();
 }
 
@@ -316,17 +327,18 @@ static hipError_t launch_scalar(const void *value, const int64_t *shapes, const 
 template <typename T>
 static hipError_t dispatch_bwd(const void *value, const int64_t *shapes, const int64_t *start,
                                const void *loc, const void *attn, const void *go, void *gv, void *gl,
-                               void *ga, const Dims &d, bool scatter, hipStream_t st)
+                               void *ga, const Dims &d, bool scatter, hipStream_t st, const LevelSel &sel)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (d.D % VEC == 0) {
         switch (d.D / VEC) {
-#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, go, gv, gl, ga, d, scatter, st);
+#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, go, gv, gl, ga, d, scatter, st, sel);
             MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
             default: break;
         }
     }
+    if (sel.n >= 0) return hipErrorInvalidValue;
     return launch_scalar<T>(value, shapes, start, loc, attn, go, gv, gl, ga, d, st);
 }
 
@@ -343,14 +355,21 @@ bool bwd_has_vector_path(int dtype, const Dims &d)
 // scatter = false: gv ignored (requires bwd_has_vector_path)
 hipError_t backward_taps(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                          const void *loc, const void *attn, const void *grad_out,
-                         void *gv, void *gl, void *ga, const Dims &d, bool scatter, hipStream_t st)
+                         void *gv, void *gl, void *ga, const Dims &d, bool scatter, hipStream_t st,
+                         const LevelSel *sel)
 {
     if (!scatter && !bwd_has_vector_path(dtype, d)) return hipErrorInvalidValue;
+    LevelSel all;
+    all.n = -1;
+    const bool routed = sel != nullptr && sel->n >= 0;
+    if (routed && scatter) return hipErrorInvalidValue;
+    const LevelSel &s = routed ? *sel : all;
     switch (dtype) {
-        case 0: return dispatch_bwd<float>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
-        case 1: return dispatch_bwd<half_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
-        case 2: return dispatch_bwd<bf16_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st);
-        case 3: return launch_scalar<double>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
+        case 0: return dispatch_bwd<float>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st, s);
+        case 1: return dispatch_bwd<half_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st, s);
+        case 2: return dispatch_bwd<bf16_t>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, scatter, st, s);
+        case 3: if (routed) return hipErrorInvalidValue;
+                return launch_scalar<double>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -292,6 +292,110 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
                                            B, S, H, D, L, Nq, P, stream);
 }
 
+// ---------------------------------------------------------------- hybrid entry points
+static mmfs::HybridPlan hybrid_plan(int dtype, const mmfs::Dims &d, const int64_t *host_shapes,
+                                    const int64_t *host_start)
+{
+    return mmfs::make_hybrid_plan(dtype, d, host_shapes, host_start);
+}
+
+int64_t mmfs_msda_forward_hybrid_workspace_bytes(int dtype, const int64_t *host_shapes, const int64_t *host_start,
+                                                 int64_t B, int64_t S, int64_t H, int64_t D,
+                                                 int64_t L, int64_t Nq, int64_t P)
+{
+    mmfs::Dims d;
+    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
+    if (B * Nq * H * D == 0 || d.K == 0 || S == 0) return 0;
+    return mmfs::hybrid_fwd_workspace_bytes(dtype, d, hybrid_plan(dtype, d, host_shapes, host_start));
+}
+
+int mmfs_msda_forward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                             const int64_t *host_shapes, const int64_t *host_start,
+                             const void *loc, const void *attn, void *out,
+                             void *workspace, int64_t workspace_bytes,
+                             int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                             unsigned stages, void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    if (B * Nq * H * D == 0 || d.K == 0 || S == 0) return MMFS_E_UNSUPPORTED;     // use mmfs_msda_forward
+    const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
+    if (!plan.active) return MMFS_E_UNSUPPORTED;
+    if (!value || !shapes || !start || !loc || !attn || !out) return MMFS_E_NULLPTR;
+    if (misaligned(value, 16) || misaligned(out, 16) || misaligned(loc, es) || misaligned(attn, es))
+        return MMFS_E_ALIGN;
+    if (!workspace || workspace_bytes < mmfs::hybrid_fwd_workspace_bytes(dtype, d, plan)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (stages & MMFS_HYB_FWD_COARSE) {
+        const hipError_t e = mmfs::forward_coarse(dtype, value, loc, attn, workspace, d, plan, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (stages & MMFS_HYB_FWD_FINE)
+        return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st, &plan.fine,
+                                  mmfs::hybrid_fwd_init(workspace, d, plan));
+    return MMFS_OK;
+}
+
+int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host_shapes, const int64_t *host_start,
+                                                  int64_t B, int64_t S, int64_t H, int64_t D,
+                                                  int64_t L, int64_t Nq, int64_t P, unsigned flags)
+{
+    mmfs::Dims d;
+    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
+    if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
+    const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
+    if (!plan.active) return 0;
+    const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
+    return base + mmfs::hybrid_bwd_partial_bytes(d, plan);
+}
+
+int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const int64_t *host_shapes, const int64_t *host_start,
+                              const void *loc, const void *attn, const void *grad_out,
+                              void *grad_value, void *grad_loc, void *grad_attn,
+                              void *workspace, int64_t workspace_bytes,
+                              int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                              unsigned flags, unsigned stages, void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
+    const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
+    if (!plan.active) return MMFS_E_UNSUPPORTED;
+    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
+        return MMFS_E_NULLPTR;
+    if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||
+        misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es))
+        return MMFS_E_ALIGN;
+    const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
+    if (!workspace || workspace_bytes < base + mmfs::hybrid_bwd_partial_bytes(d, plan)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    void *partial = (char *)workspace + base;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE))
+        e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
+                                d, false, st, &plan.fine);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_COARSE))
+        e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))
+        e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
+        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, plan.coarse_mask);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
+        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_COARSE))
+        e = mmfs::backward_value_coarse(dtype, loc, attn, grad_out, grad_value, partial, d, plan, st);
+    return (int)e;
+}
+
 int mmfs_msda_cast_from_f32(int dtype, const float *src, void *dst, int64_t n, void *stream)
 {
     if (dtype != MMFS_F32 && dtype != MMFS_F16 && dtype != MMFS_BF16) return MMFS_E_DTYPE;

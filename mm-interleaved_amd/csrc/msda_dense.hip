@@ -1,0 +1,741 @@
+// msda_dense.hip -- the small levels of multi-scale deformable attention as dense matrix
+// products on the matrix cores ("hybrid" path).
+//
+// Why.  Measured on MI355X the row-gather kernels are bound by the
+// vector-memory path: every tap corner is one D*sizeof(T)-byte row through L1 (64 B/clk/CU),
+// 24x the op's compulsory bytes, and every level receives the same number of taps whatever its
+// size.  A level of <= 256 pixels is a tiny dense matrix, though: for a tile of queries
+//
+//      out[q, :]      +=  A_l[q, :] . V_l               A_l[q, pix] = sum of the bilinear*attention
+//      grad_value_l   +=  A_l^T . grad_out                            weights of q's taps on pix
+//      dot[q, pix]     =  grad_out[q, :] . V_l[pix, :]  (then grad_attn / grad_loc are 4 look-ups)
+//
+// are GEMMs with K_l = H_l*W_l <= 256, and v_mfma_f32_32x32x16_{bf16,f16} does 1017 FLOP/clk/SIMD.
+// For the 16x16 + 8x8 levels of the north-star shape that is 2560 MFMA clocks per 64 queries
+// against 8192 clocks of row reads -- with the matrix pipe otherwise idle.  The big levels stay
+// with the gather kernels (LevelSel routing, msda_fwd.hip / msda_bwd.hip / msda_bwd_value.hip).
+//
+// Precision.  The MFMA takes 16-bit operands.  V and grad_out ARE 16-bit (this path exists for
+// f16 / bf16 storage only), products are exact and accumulate in fp32 like the fmaf chains of
+// the gather kernels.  The fp32 weights A are split into hi + lo 16-bit halves (hi = leading
+// bits, lo = rounded remainder): both halves sit side by side in ONE 32-bit word of the weight
+// tile and multiply the same (duplicated) V element, so one MFMA K-slot pair evaluates
+// (hi + lo) * v -- 16-17 significant bits of weight, well inside the storage type's rounding.
+// The weight tile is built in LDS with plain read-add-write: the 4 lanes of a query own the
+// pixels with (pixel & 3) == lane, so no two lanes ever touch one word (LDS float atomics run
+// at 0.33 lane-adds/clk/CU).
+//
+// Semantics that differ from the gather kernels, by construction of a dense product: a
+// non-finite value / grad_out element in a dense level reaches every query of its (b, h) as
+// 0 * Inf = NaN instead of only the queries that sample it.  (Non-finite *locations* are
+// handled identically: they produce zero weights.)
+//
+// The reference has no counterpart (its kernels are one thread per output scalar,
+// ms_deform_im2col_cuda.cuh:240-923); results are checked against the same oracle.
+#include "msda_device.h"
+#include "msda_launch.h"
+#include <cstdlib>
+
+namespace mmfs {
+
+namespace {
+
+constexpr int kDT = 256;                         // 4 waves
+constexpr int kTileQ = 64;                       // queries per tile
+constexpr int kAStride = kCoarseMaxPx + 4;       // words per query row ([q][pixel] tiles)
+constexpr int kQStride = kTileQ + 4;             // words per pixel row ([pixel][q] tile)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(const uint4 &a, const uint4 &b, const f32x16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    // fp32 weight -> {hi (low half), lo (high half)}, hi + lo == a to ~2^-17 relative
+    static __device__ __forceinline__ uint32_t split(float a) {
+        uint32_t hi = __float_as_uint(a) & 0xffff0000u;
+        if (a != a) hi = 0x7fc00000u;                                  // keep NaN a NaN
+        const bool inf = (__float_as_uint(a) & 0x7fffffffu) == 0x7f800000u;
+        const float r = inf ? 0.f : a - __uint_as_float(hi);          // exact
+        const __bf16 lo = (__bf16)r;                                   // RNE
+        return (hi >> 16) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+    }
+};
+
+template <> struct Mma<half_t> {
+    static __device__ __forceinline__ f32x16 run(const uint4 &a, const uint4 &b, const f32x16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t split(float a) {
+        // weights beyond the f16 range saturate (they would need |attention| > 65504)
+        const float c = a != a ? a : fminf(fmaxf(a, -65504.f), 65504.f);
+        const _Float16 hi = (_Float16)c;
+        const _Float16 lo = (_Float16)(c - (float)hi);
+        return (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+    }
+};
+
+// C/D layout of the 32x32 MFMAs: column = lane & 31, row = this (cdna_hip_programming.md section 3)
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// The P samples (locations + attention weights) of one (query, level), requested early so the
+// memory latency hides behind the previous phase.  NV = P / 4 (16-byte location vectors, 8-byte
+// weight vectors; P = 4, 8); NV = 0: any P, read when needed.
+template <typename T, int NV>
+struct Samples {
+    uint4 l[NV > 0 ? NV : 1];
+    uint2 a[NV > 0 ? NV : 1];
+    __device__ __forceinline__ void request(const T *__restrict__ loc, const T *__restrict__ attn, int64_t s0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            l[v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
+            a[v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
+        }
+    }
+};
+
+// The weight tile of one level for the 64 queries q0..q0+63 of (b, h), accumulated in fp32 with
+// plain read-add-write.  Thread t serves query t/4 and only the pixels with (pixel & 3) == t%4.
+//   BY_PIXEL = false: A[q][pixel]  (row stride kAStride)      -- forward
+//   BY_PIXEL = true : A[pixel][q]  (row stride kQStride)      -- grad_value
+template <bool BY_PIXEL>
+__device__ __forceinline__ void add_sample(float *__restrict__ A, float lx, float ly, float a, int Hl, int Wl,
+                                           int qi, int j)
+{
+    const Tap<float> t = locate<float>(lx, ly, Hl, Wl, 0);
+    const float gy = 1.f - t.fy, gx = 1.f - t.fx;
+    const float w[4] = {gy * gx * a, gy * t.fx * a, t.fy * gx * a, t.fy * t.fx * a};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (t.row[c] >= 0 && (t.row[c] & 3) == j) {
+            float *e = BY_PIXEL ? A + t.row[c] * kQStride + qi : A + qi * kAStride + t.row[c];
+            *e += w[c];
+        }
+    }
+}
+
+template <typename T, int NV, bool BY_PIXEL>
+__device__ __forceinline__ void build_weight_tile(float *__restrict__ A, const Samples<T, NV> &sm,
+                                                  const T *__restrict__ loc, const T *__restrict__ attn,
+                                                  const Dims &d, int b, int h, int q0, int level, int Hl, int Wl)
+{
+    const int tid = threadIdx.x, qi = tid >> 2, j = tid & 3;
+    const int q = q0 + qi;
+    if (q >= d.Nq) return;
+    if (NV > 0) {
+        typedef Vec16<T> V;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float l[8], a[8];
+            V::unpack(sm.l[v], l);
+            V::unpack(make_uint4(sm.a[v].x, sm.a[v].y, 0u, 0u), a);      // first 4 valid
+#pragma unroll
+            for (int i = 0; i < 4; ++i) add_sample<BY_PIXEL>(A, l[2 * i], l[2 * i + 1], a[i], Hl, Wl, qi, j);
+        }
+    } else {
+        const int64_t s0 = ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P;
+        for (int p = 0; p < d.P; ++p)
+            add_sample<BY_PIXEL>(A, to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]), to_f32(attn[s0 + p]),
+                                 Hl, Wl, qi, j);
+    }
+}
+
+// rows x cols4 16-byte vectors of a tile: fill with zeros / split every fp32 weight in place
+template <int STRIDE4>
+__device__ __forceinline__ void tile_zero(float *A, int rows, int cols4)
+{
+    uint4 *v = reinterpret_cast<uint4 *>(A);
+    for (int i = threadIdx.x; i < rows * cols4; i += kDT) {
+        const int r = i / cols4, c = i - r * cols4;
+        v[r * STRIDE4 + c] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+template <typename T, int STRIDE4>
+__device__ __forceinline__ void tile_split(float *A, int rows, int cols4)
+{
+    uint4 *v = reinterpret_cast<uint4 *>(A);
+    for (int i = threadIdx.x; i < rows * cols4; i += kDT) {
+        const int r = i / cols4, c = i - r * cols4;
+        uint4 x = v[r * STRIDE4 + c];
+        x.x = Mma<T>::split(__uint_as_float(x.x)); x.y = Mma<T>::split(__uint_as_float(x.y));
+        x.z = Mma<T>::split(__uint_as_float(x.z)); x.w = Mma<T>::split(__uint_as_float(x.w));
+        v[r * STRIDE4 + c] = x;
+    }
+}
+
+// 4 consecutive 16-bit elements -> the MFMA operand that meets the {hi, lo} weight words: every
+// element twice
+__device__ __forceinline__ uint4 dup4(uint32_t lo, uint32_t hi)
+{
+    return make_uint4(__builtin_amdgcn_perm(lo, lo, 0x01000100u), __builtin_amdgcn_perm(lo, lo, 0x03020302u),
+                      __builtin_amdgcn_perm(hi, hi, 0x01000100u), __builtin_amdgcn_perm(hi, hi, 0x03020302u));
+}
+
+// ---------------------------------------------------------------- value of the dense levels, packed
+// vt[(b*H + h)][g][ch][4]: the dense levels' pixels of one (b, h), levels back to back (each padded
+// with zero pixels to a multiple of 8), in groups of 4 pixels per channel -- the 8 bytes one lane
+// of the forward's B operand needs.
+template <typename T>
+__global__ void __launch_bounds__(256)
+coarse_pack_kernel(const T *__restrict__ value, T *__restrict__ vt, const Dims d, const CoarsePlan cp)
+{
+    __shared__ CoarseLevel lv[kMaxCoarse];
+    if ((int)threadIdx.x < cp.n) lv[threadIdx.x] = cp.lv[threadIdx.x];
+    __syncthreads();
+    const int groups = cp.ktot / 4;
+    const int64_t total = (int64_t)d.B * d.H * groups * d.D;
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(value);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % d.D);
+        const int64_t r = i / d.D;
+        const int g = (int)(r % groups);
+        const int64_t bh = r / groups;
+        const int b = (int)(bh / d.H), h = (int)(bh % d.H);
+        const int kk = g * 4;
+        int ci = 0;
+        while (ci + 1 < cp.n && kk >= lv[ci + 1].coff) ++ci;
+        const int pix0 = kk - lv[ci].coff, px = lv[ci].Hl * lv[ci].Wl;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = pix0 + j;
+            v[j] = pix < px ? (uint32_t)src[(((int64_t)b * d.S + lv[ci].start + pix) * d.H + h) * d.D + ch] : 0u;
+        }
+        reinterpret_cast<uint2 *>(vt)[i] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    }
+}
+
+// ---------------------------------------------------------------- forward, dense levels
+// One workgroup = 64 queries of one (b, h).  Per dense level: zero the weight tile, build it,
+// split it, then every wave multiplies it with its 32-channel slice of the packed value.
+// NS = D / 32 channel slices; the 2 * NS (32-query block, slice) jobs are dealt to the 4 waves.
+// Everything that comes from global memory is requested a phase ahead: the next level's samples
+// before this level is built, this level's value fragments before its tile is zeroed.
+// Result: cinit[b, q, h, :] (fp32), the starting value of the gather kernel's accumulators.
+template <typename T, int NS, int NV>
+__global__ void __launch_bounds__(kDT, 2)
+msda_fwd_coarse(const T *__restrict__ vt, const T *__restrict__ loc, const T *__restrict__ attn,
+                float *__restrict__ cinit, const Dims d, const CoarsePlan cp)
+{
+    constexpr int JOBS = (2 * NS + 3) / 4;
+    constexpr int PF = 8;                           // pixel octets requested ahead (one group of 64 pixels)
+    __shared__ __attribute__((aligned(16))) float A[kTileQ * kAStride];
+
+    const BlockCoord bc = block_coord(d, kTileQ);
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform
+    const int ns = wave % NS;
+    const int64_t bh = (int64_t)bc.b * d.H + bc.h;
+    const int64_t sq = (((int64_t)bc.b * d.Nq + min(bc.q0 + (tid >> 2), d.Nq - 1)) * d.H + bc.h) * d.L;
+
+    f32x16 acc[JOBS];
+#pragma unroll
+    for (int j = 0; j < JOBS; ++j) acc[j] = zero16();
+
+    Samples<T, NV> nxt;
+    nxt.request(loc, attn, (sq + uni(cp.lv[0].level)) * d.P);
+    for (int ci = 0; ci < cp.n; ++ci) {
+        const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
+        const int coff = uni(cp.lv[ci].coff), K = uni(cp.lv[ci].kpad);
+        // the product runs over whole groups of 64 pixels: the tile's extra columns are zero and
+        // meet (finite) elements of the level's last pixels
+        const int ngrp = (K + 63) / 64, kz = ngrp * 64, last_g4 = K / 4 - 1;
+        const Samples<T, NV> cur = nxt;
+        if (ci + 1 < cp.n) nxt.request(loc, attn, (sq + uni(cp.lv[ci + 1].level)) * d.P);
+        const uint2 *bsrc = reinterpret_cast<const uint2 *>(vt) + (bh * cp.ktot + coff) / 4 * d.D + ns * 32 + l32;
+        uint2 x[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) x[u] = bsrc[(int64_t)min(u * 2 + kg, last_g4) * d.D];
+
+        if (ci > 0) __syncthreads();                // the previous level's fragments are all read
+        tile_zero<kAStride / 4>(A, kTileQ, kz / 4);
+        __syncthreads();
+        build_weight_tile<T, NV, false>(A, cur, loc, attn, d, bc.b, bc.h, bc.q0, level, Hl, Wl);
+        __syncthreads();
+        tile_split<T, kAStride / 4>(A, kTileQ, kz / 4);
+        __syncthreads();
+
+        for (int g = 0; g < ngrp; ++g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int kb = g * PF + u;
+                const uint4 bfrag = dup4(x[u].x, x[u].y);
+                x[u] = bsrc[(int64_t)min((kb + PF) * 2 + kg, last_g4) * d.D];
+#pragma unroll
+                for (int j = 0; j < JOBS; ++j) {
+                    const int jj = wave + 4 * j;
+                    if (4 * JOBS <= 2 * NS || jj < 2 * NS) {           // constant-true unless NS == 1
+                        const int mb = jj / NS;
+                        const uint4 afrag = *reinterpret_cast<const uint4 *>(
+                            &A[(mb * 32 + l32) * kAStride + kb * 8 + kg * 4]);
+                        acc[j] = Mma<T>::run(afrag, bfrag, acc[j]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JOBS; ++j) {
+        const int jj = wave + 4 * j;
+        if (jj < 2 * NS) {
+            const int mb = jj / NS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = bc.q0 + mb * 32 + mfma_row(r, lane);
+                if (q < d.Nq)
+                    cinit[(((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + ns * 32 + l32] = acc[j][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- grad_loc / grad_attn, dense levels
+// dot[q, pix] = grad_out[q, :] . value[pix, :] for 64 queries x all pixels of a dense level by
+// MFMA (both operands are 16-byte channel vectors straight from global memory: no packing, no
+// split), parked in LDS; then one thread per (query, point) looks its four corners up and
+// finishes the per-sample algebra of msda_bwd_vec (cuh:119-161).  The look-up threads' samples
+// are requested before the products start (IT = samples per thread when P is 4, 8 or 16).
+template <typename T, int NS, int IT>
+__global__ void __launch_bounds__(kDT)
+msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ attn,
+                 const T *__restrict__ grad_out, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
+                 const Dims d, const CoarsePlan cp)
+{
+    constexpr int KB = 2 * NS;                      // 16-channel steps
+    constexpr int ITN = IT > 0 ? IT : 1;
+    __shared__ __attribute__((aligned(16))) float G[kTileQ * kAStride];
+
+    const BlockCoord bc = block_coord(d, kTileQ);
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform
+    const int mb = wave & 1;                        // this wave's 32 queries
+    const int64_t HD = (int64_t)d.H * d.D;
+    const uint32_t *loc2 = reinterpret_cast<const uint32_t *>(loc);       // (x, y) pairs of 16-bit scalars
+    const uint16_t *attn1 = reinterpret_cast<const uint16_t *>(attn);
+
+    uint4 af[KB];
+    {
+        const int q = min(bc.q0 + mb * 32 + l32, d.Nq - 1);
+        const T *gp = grad_out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + kg * 8;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) af[kb] = *reinterpret_cast<const uint4 *>(gp + kb * 16);
+    }
+
+    for (int ci = 0; ci < cp.n; ++ci) {
+        const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
+        const int lstart = uni(cp.lv[ci].start);
+        const int px = Hl * Wl, NB = (px + 31) / 32;
+        // the look-up phase's samples: thread -> (query, point) pairs tid, tid + 256, ...
+        uint32_t sxy[ITN], sa[ITN];
+        if (IT > 0) {
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int idx = tid + i * kDT, qi = idx / d.P, p = idx - qi * d.P;
+                const int64_t s = ((((int64_t)bc.b * d.Nq + min(bc.q0 + qi, d.Nq - 1)) * d.H + bc.h) * d.L + level) * d.P + p;
+                sxy[i] = loc2[s];
+                sa[i] = attn1[s];
+            }
+        }
+        if (ci > 0) __syncthreads();                // the previous level's look-ups are done
+        for (int nb0 = wave >> 1; nb0 < NB; nb0 += 4) {
+            // two pixel blocks per round: all value fragments requested before the first product
+            uint4 bf[2][KB];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nb = nb0 + 2 * t;
+                const int pix = min(nb * 32 + l32, px - 1);
+                const T *vp = value + ((int64_t)bc.b * d.S + lstart + pix) * HD + (int64_t)bc.h * d.D + kg * 8;
+                if (nb < NB) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) bf[t][kb] = *reinterpret_cast<const uint4 *>(vp + kb * 16);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nb = nb0 + 2 * t;
+                if (nb < NB) {
+                    f32x16 acc = zero16();
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) acc = Mma<T>::run(af[kb], bf[t][kb], acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) G[(mb * 32 + mfma_row(r, lane)) * kAStride + nb * 32 + l32] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        auto finish = [&](int idx, bool preloaded, uint32_t rxy, uint32_t ra) {
+            const int qi = idx / d.P, p = idx - qi * d.P;
+            const int q = bc.q0 + qi;
+            if (q >= d.Nq) return;
+            const int64_t s = ((((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.L + level) * d.P + p;
+            float lx, ly, a;
+            if (preloaded) {
+                float l[Vec16<T>::N];
+                Vec16<T>::unpack(make_uint4(rxy, ra, 0u, 0u), l);     // {x, y, a, -}
+                lx = l[0]; ly = l[1]; a = l[2];
+            } else {
+                lx = to_f32(loc[2 * s]); ly = to_f32(loc[2 * s + 1]); a = to_f32(attn[s]);
+            }
+            const Tap<float> t = locate<float>(lx, ly, Hl, Wl, 0);
+            const float *g = G + qi * kAStride;
+            float dot[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot[c] = t.row[c] >= 0 ? g[t.row[c]] : 0.f;
+            const float fx = t.fx, fy = t.fy, gy = 1.f - fy, gx = 1.f - fx;
+            const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+            const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
+            const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
+            const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
+            grad_attn[s] = (T)ga;
+            grad_loc[2 * s] = (T)((float)Wl * dw * a);
+            grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
+        };
+        if (IT > 0) {
+#pragma unroll
+            for (int i = 0; i < IT; ++i) finish(tid + i * kDT, true, sxy[i], sa[i]);
+        } else {
+            for (int idx = tid; idx < kTileQ * d.P; idx += kDT) finish(idx, false, 0u, 0u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- grad_value, dense levels
+// One workgroup = one (b, h, dense level, chunk of query tiles).  The level's whole grad_value
+// [pixels x D] lives in MFMA accumulators across the chunk; per tile the weight tile is built
+// pixel-major and multiplied with the tile's grad_out rows.  The tile's grad_out elements and the
+// next tile's samples are requested before the tile is built.  Partial sums per chunk go to the
+// workspace; coarse_value_epilogue adds the chunks and stores the rows in the storage type.
+// NJ = (32-pixel block, channel slice) jobs per wave, a power of two covering the level: the body
+// is straight-line code (a branch per job makes the compiler shuffle the accumulators around).
+struct ValueCoarseArgs {
+    int b, h, chunk, level, Hl, Wl, coff, kpad, PB, t_begin, t_end;
+};
+
+template <typename T, int NS, int NV, int NJ>
+__device__ __forceinline__ void value_coarse_body(float *__restrict__ At, const T *__restrict__ loc,
+                                                  const T *__restrict__ attn, const T *__restrict__ grad_out,
+                                                  float *__restrict__ partial, const Dims &d, int ktot,
+                                                  const ValueCoarseArgs &v)
+{
+    constexpr int PBSTEP = 4 / NS;
+    constexpr int QB = kTileQ / 8;                  // query octets per tile
+    constexpr int ROWS = NJ * PBSTEP * 32;          // tile rows the jobs read (<= 256)
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ns = wave % NS, pb0 = wave / NS;
+    const int64_t HD = (int64_t)d.H * d.D;
+    const uint16_t *go = reinterpret_cast<const uint16_t *>(grad_out) + ((int64_t)v.b * d.Nq * d.H + v.h) * d.D + ns * 32 + l32;
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = zero16();
+
+    auto sample_base = [&](int t) {
+        return ((((int64_t)v.b * d.Nq + min(t * kTileQ + (tid >> 2), d.Nq - 1)) * d.H + v.h) * d.L + v.level) * d.P;
+    };
+    Samples<T, NV> nxt;
+    if (v.t_begin < v.t_end) nxt.request(loc, attn, sample_base(v.t_begin));
+    for (int t = v.t_begin; t < v.t_end; ++t) {
+        const int q0 = t * kTileQ;
+        const Samples<T, NV> cur = nxt;
+        nxt.request(loc, attn, sample_base(min(t + 1, v.t_end - 1)));
+        // this lane's grad_out elements of the tile: 4 queries per MFMA step, one channel
+        // (first half of the tile now, second half while the first is used)
+        uint32_t g[QB / 2][4];
+#pragma unroll
+        for (int qb = 0; qb < QB / 2; ++qb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = q0 + qb * 8 + kg * 4 + i;
+                g[qb][i] = go[(int64_t)min(q, d.Nq - 1) * HD];
+            }
+        }
+        if (t > v.t_begin) __syncthreads();
+        tile_zero<kQStride / 4>(At, ROWS, kTileQ / 4);
+        __syncthreads();
+        build_weight_tile<T, NV, true>(At, cur, loc, attn, d, v.b, v.h, q0, v.level, v.Hl, v.Wl);
+        __syncthreads();
+        tile_split<T, kQStride / 4>(At, ROWS, kTileQ / 4);
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = q0 + qb * 8 + kg * 4 + i;
+                const uint32_t e = g[qb % (QB / 2)][i];
+                w[i] = q < d.Nq ? (e | (e << 16)) : 0u;                  // every element twice: meets {hi, lo}
+                if (qb < QB / 2) g[qb][i] = go[(int64_t)min(q + 8 * (QB / 2), d.Nq - 1) * HD];
+            }
+            const uint4 bfrag = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int pb = pb0 + j * PBSTEP;
+                const uint4 afrag = *reinterpret_cast<const uint4 *>(&At[(pb * 32 + l32) * kQStride + qb * 8 + kg * 4]);
+                acc[j] = Mma<T>::run(afrag, bfrag, acc[j]);
+            }
+        }
+    }
+    float *pp = partial + ((((int64_t)v.chunk * d.B + v.b) * d.H + v.h) * ktot + v.coff) * d.D + ns * 32 + l32;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int pb = pb0 + j * PBSTEP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = pb * 32 + mfma_row(r, lane);
+            if (pix < v.kpad) pp[(int64_t)pix * d.D] = acc[j][r];
+        }
+    }
+}
+
+template <typename T, int NS, int NV>
+__global__ void __launch_bounds__(kDT, 2)
+msda_value_coarse(const T *__restrict__ loc, const T *__restrict__ attn, const T *__restrict__ grad_out,
+                  float *__restrict__ partial, const Dims d, const CoarsePlan cp, const int chunks,
+                  const int tiles_per_chunk)
+{
+    constexpr int PBSTEP = 4 / NS;
+    __shared__ __attribute__((aligned(16))) float At[kCoarseMaxPx * kQStride];
+
+    int bid = blockIdx.x;
+    ValueCoarseArgs v;
+    v.h = bid % d.H; bid /= d.H;
+    const int ci = bid % cp.n; bid /= cp.n;
+    v.chunk = bid % chunks;
+    v.b = bid / chunks;
+    v.level = uni(cp.lv[ci].level); v.Hl = uni(cp.lv[ci].Hl); v.Wl = uni(cp.lv[ci].Wl);
+    v.coff = uni(cp.lv[ci].coff); v.kpad = uni(cp.lv[ci].kpad);
+    v.PB = (v.Hl * v.Wl + 31) / 32;
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    v.t_begin = v.chunk * tiles_per_chunk;
+    v.t_end = min(q_tiles, v.t_begin + tiles_per_chunk);
+    const int need = (v.PB + PBSTEP - 1) / PBSTEP;          // jobs per wave that cover the level
+    if (need <= 1) value_coarse_body<T, NS, NV, 1>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
+    else if (need <= 2) value_coarse_body<T, NS, NV, 2>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
+    else if (NS >= 2 && need <= 4) value_coarse_body<T, NS, NV, (NS >= 2 ? 4 : 2)>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
+    else if (NS >= 4) value_coarse_body<T, NS, NV, (NS >= 4 ? 8 : 2)>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+coarse_value_epilogue(const float *__restrict__ partial, T *__restrict__ grad_value, const Dims d,
+                      const CoarsePlan cp, const int chunks)
+{
+    __shared__ CoarseLevel lv[kMaxCoarse];
+    if ((int)threadIdx.x < cp.n) lv[threadIdx.x] = cp.lv[threadIdx.x];
+    __syncthreads();
+    const int d4 = d.D / 4;
+    const int64_t total = (int64_t)d.B * d.H * cp.ktot * d4;
+    const int64_t chunk_stride = (int64_t)d.B * d.H * cp.ktot * d.D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % d4);
+        const int64_t r = i / d4;
+        const int kk = (int)(r % cp.ktot);
+        const int64_t bh = r / cp.ktot;
+        int ci = 0;
+        while (ci + 1 < cp.n && kk >= lv[ci + 1].coff) ++ci;
+        const int pix = kk - lv[ci].coff;
+        if (pix >= lv[ci].Hl * lv[ci].Wl) continue;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src = partial + r * d.D + c4 * 4;
+        for (int c = 0; c < chunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + c * chunk_stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int b = (int)(bh / d.H), h = (int)(bh % d.H);
+        T o[4] = {(T)s.x, (T)s.y, (T)s.z, (T)s.w};
+        T *dst = grad_value + (((int64_t)b * d.S + lv[ci].start + pix) * d.H + h) * d.D + c4 * 4;
+        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+    }
+}
+
+int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+
+int value_chunks(const Dims &d, const CoarsePlan &cp)
+{
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int64_t slices = (int64_t)d.B * d.H * std::max(1, cp.n);
+    const int64_t want = (512 + slices - 1) / slices;            // ~2 workgroups per CU
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, q_tiles));
+}
+
+// samples per (query, level) as whole vectors?  (P = 4 or 8, 16-byte aligned tensors)
+inline int sample_vectors(const void *loc, const void *attn, const Dims &d)
+{
+    if ((d.P != 4 && d.P != 8) || ((uintptr_t)loc % 16) || ((uintptr_t)attn % 8)) return 0;
+    return d.P / 4;
+}
+
+template <typename T, int NS>
+hipError_t launch_fwd_coarse(const void *value, const void *loc, const void *attn, void *workspace,
+                             const Dims &din, const CoarsePlan &cp, hipStream_t st)
+{
+    Dims d = din;
+    d.q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    T *vt = (T *)workspace;
+    float *cinit = (float *)((char *)workspace + up256((int64_t)d.B * d.H * cp.ktot * d.D * (int64_t)sizeof(T)));
+    const int64_t pk = (int64_t)d.B * d.H * (cp.ktot / 4) * d.D;
+    hipLaunchKernelGGL((coarse_pack_kernel<T>), dim3((unsigned)std::min<int64_t>((pk + 255) / 256, 256 * 32)),
+                       dim3(256), 0, st, (const T *)value, vt, d, cp);
+#define MMFS_L(NV) hipLaunchKernelGGL((msda_fwd_coarse<T, NS, NV>), dim3((unsigned)blocks), dim3(kDT), 0, st, \
+                                      (const T *)vt, (const T *)loc, (const T *)attn, cinit, d, cp)
+    switch (sample_vectors(loc, attn, d)) { case 1: MMFS_L(1); break; case 2: MMFS_L(2); break; default: MMFS_L(0); }
+#undef MMFS_L
+    return hipGetLastError();
+}
+
+template <typename T, int NS>
+hipError_t launch_taps_coarse(const void *value, const void *loc, const void *attn, const void *go,
+                              void *gl, void *ga, const Dims &din, const CoarsePlan &cp, hipStream_t st)
+{
+    Dims d = din;
+    d.q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define MMFS_L(IT) hipLaunchKernelGGL((msda_taps_coarse<T, NS, IT>), dim3((unsigned)blocks), dim3(kDT), 0, st, \
+                                      (const T *)value, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga, d, cp)
+    const bool al = ((uintptr_t)loc % 4) == 0;                  // (x, y) pairs are read as one 32-bit word
+    switch (al ? d.P : 0) { case 4: MMFS_L(1); break; case 8: MMFS_L(2); break; case 16: MMFS_L(4); break; default: MMFS_L(0); }
+#undef MMFS_L
+    return hipGetLastError();
+}
+
+template <typename T, int NS>
+hipError_t launch_value_coarse(const void *loc, const void *attn, const void *go, void *gv, void *partial,
+                               const Dims &d, const CoarsePlan &cp, hipStream_t st)
+{
+    const int chunks = value_chunks(d, cp);
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int tpc = (q_tiles + chunks - 1) / chunks;
+    const int64_t blocks = (int64_t)d.B * d.H * cp.n * chunks;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define MMFS_L(NV) hipLaunchKernelGGL((msda_value_coarse<T, NS, NV>), dim3((unsigned)blocks), dim3(kDT), 0, st, \
+                                      (const T *)loc, (const T *)attn, (const T *)go, (float *)partial, d, cp, chunks, tpc)
+    switch (sample_vectors(loc, attn, d)) { case 1: MMFS_L(1); break; case 2: MMFS_L(2); break; default: MMFS_L(0); }
+#undef MMFS_L
+    const int64_t items = (int64_t)d.B * d.H * cp.ktot * (d.D / 4);
+    hipLaunchKernelGGL((coarse_value_epilogue<T>), dim3((unsigned)std::min<int64_t>((items + 255) / 256, 256 * 32)),
+                       dim3(256), 0, st, (const float *)partial, (T *)gv, d, cp, chunks);
+    return hipGetLastError();
+}
+
+#define MMFS_DENSE_DISPATCH(FN, ...)                                                            \
+    do {                                                                                        \
+        const int ns = d.D / 32;                                                                \
+        if (dtype == 1) {                                                                       \
+            if (ns == 1) return FN<half_t, 1>(__VA_ARGS__);                                     \
+            if (ns == 2) return FN<half_t, 2>(__VA_ARGS__);                                     \
+            if (ns == 4) return FN<half_t, 4>(__VA_ARGS__);                                     \
+        } else if (dtype == 2) {                                                                \
+            if (ns == 1) return FN<bf16_t, 1>(__VA_ARGS__);                                     \
+            if (ns == 2) return FN<bf16_t, 2>(__VA_ARGS__);                                     \
+            if (ns == 4) return FN<bf16_t, 4>(__VA_ARGS__);                                     \
+        }                                                                                       \
+        return hipErrorInvalidValue;                                                            \
+    } while (0)
+
+}  // namespace
+
+// Which levels go dense.  Needs a HOST copy of the level table (the reference API keeps it in
+// device memory); without one, or for fp32 / fp64 storage or other head widths, the plan is
+// inactive and the plain kernels run.
+HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes, const int64_t *host_start)
+{
+    HybridPlan p;
+    p.active = false;
+    p.fine.n = -1;
+    p.coarse.n = 0;
+    p.coarse.ktot = 0;
+    p.coarse_mask = 0;
+    if (!host_shapes || !host_start) return p;
+    if (dtype != 1 && dtype != 2) return p;
+    if (d.D != 32 && d.D != 64 && d.D != 128) return p;
+    if (d.L <= 0 || d.L > kMaxSelLevels || d.P <= 0 || d.Nq < 32) return p;
+    if (const char *e = getenv("MMFS_HYBRID")) if (atoi(e) == 0) return p;
+    // a level pays off densely while its pixel count (MFMA work per query) stays below the row
+    // reads it replaces: K/4 MFMA clocks against 16*P row clocks per query at D = 128
+    const int64_t max_px = std::min<int64_t>(kCoarseMaxPx, 64LL * d.P);
+    int nf = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const int64_t Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1], st = host_start[l];
+        const int64_t px = Hl * Wl;
+        const bool dense = Hl > 0 && Wl > 0 && px <= max_px && p.coarse.n < kMaxCoarse && st >= 0 && st + px <= d.S;
+        if (dense) {
+            CoarseLevel &c = p.coarse.lv[p.coarse.n++];
+            c.level = l; c.Hl = (int)Hl; c.Wl = (int)Wl; c.start = (int)st;
+            c.coff = p.coarse.ktot;
+            c.kpad = (int)((px + 7) / 8 * 8);
+            p.coarse.ktot += c.kpad;
+            p.coarse_mask |= 1ull << l;
+        } else {
+            p.fine.idx[nf++] = (uint8_t)l;
+        }
+    }
+    if (p.coarse.n == 0) { p.fine.n = -1; return p; }
+    for (int i = nf; i < kMaxSelLevels; ++i) p.fine.idx[i] = 0;
+    p.fine.n = nf;
+    p.active = true;
+    return p;
+}
+
+int64_t hybrid_fwd_workspace_bytes(int dtype, const Dims &d, const HybridPlan &p)
+{
+    if (!p.active) return 0;
+    const int64_t es = 2;
+    return up256((int64_t)d.B * d.H * p.coarse.ktot * d.D * es) + up256((int64_t)d.B * d.Nq * d.H * d.D * 4);
+}
+
+const float *hybrid_fwd_init(void *workspace, const Dims &d, const HybridPlan &p)
+{
+    return (const float *)((char *)workspace + up256((int64_t)d.B * d.H * p.coarse.ktot * d.D * 2));
+}
+
+hipError_t forward_coarse(int dtype, const void *value, const void *loc, const void *attn, void *workspace,
+                          const Dims &d, const HybridPlan &p, hipStream_t st)
+{
+    if (!p.active) return hipErrorInvalidValue;
+    MMFS_DENSE_DISPATCH(launch_fwd_coarse, value, loc, attn, workspace, d, p.coarse, st);
+}
+
+hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, const void *attn,
+                                const void *grad_out, void *grad_loc, void *grad_attn, const Dims &d,
+                                const HybridPlan &p, hipStream_t st)
+{
+    if (!p.active) return hipErrorInvalidValue;
+    MMFS_DENSE_DISPATCH(launch_taps_coarse, value, loc, attn, grad_out, grad_loc, grad_attn, d, p.coarse, st);
+}
+
+int64_t hybrid_bwd_partial_bytes(const Dims &d, const HybridPlan &p)
+{
+    if (!p.active) return 0;
+    return up256((int64_t)value_chunks(d, p.coarse) * d.B * d.H * p.coarse.ktot * d.D * 4);
+}
+
+hipError_t backward_value_coarse(int dtype, const void *loc, const void *attn, const void *grad_out,
+                                 void *grad_value, void *partial, const Dims &d, const HybridPlan &p,
+                                 hipStream_t st)
+{
+    if (!p.active) return hipErrorInvalidValue;
+    MMFS_DENSE_DISPATCH(launch_value_coarse, loc, attn, grad_out, grad_value, partial, d, p.coarse, st);
+}
+
+}  // namespace mmfs

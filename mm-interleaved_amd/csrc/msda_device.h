@@ -141,6 +141,31 @@ __device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, uint
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// ---------------------------------------------------------------- level routing (hybrid path)
+// When the host knows the level table (a host copy handed to the *_hybrid entry points), levels
+// of at most kCoarseMaxPx pixels are taken out of the row-gather kernels and evaluated as dense
+// matrix products on the matrix cores (msda_dense.hip); the gather kernels then visit only the
+// levels listed in a LevelSel.
+constexpr int kMaxSelLevels = 64;      // hybrid routing only for L <= 64
+constexpr int kMaxCoarse = 32;
+constexpr int kCoarseMaxPx = 256;
+
+struct LevelSel {
+    int n;                             // levels to visit; < 0: all L levels in order
+    uint8_t idx[kMaxSelLevels];
+};
+
+struct CoarseLevel {
+    int level, Hl, Wl, start;          // index in the level table, extent, first pixel on the S axis
+    int coff, kpad;                    // offset / padded pixel count (multiple of 8) in the packed coarse axis
+};
+
+struct CoarsePlan {
+    int n;                             // dense levels
+    int ktot;                          // sum of kpad
+    CoarseLevel lv[kMaxCoarse];
+};
+
 // Workgroup -> (b, h, first query).  Blocks are dealt to XCDs round-robin
 // (block i -> XCD i % 8, observed, MI355X_MICROARCH.md "Workgroup dispatch"), so
 // taking h = block % H pins every head's value slice [S, D] of a sample to one

@@ -7,6 +7,7 @@ they are built once per (shapes, n_images, device) and cached; the tensors carry
 (``MultiScaleDeformableAttention.levels_are_canonical``), so the backward never has to
 copy them back to the host to choose its algorithm.
 """
+import numpy as np
 import torch
 
 _cache = {}
@@ -26,8 +27,10 @@ def make_level_tables(shapes_per_image, n_images, device):
     S = int(px.sum())
     shapes = host.to(device)
     start = start_host.to(device)
-    # pre-seed the shim's cache: (versions, start ptr, S) -> canonical
-    shapes._mmfs_canonical = ((shapes._version, start._version, start.data_ptr(), S), True)
+    # pre-seed the shim's cache: (versions, start ptr, S) -> (canonical, host shapes, host start)
+    shapes._mmfs_canonical = ((shapes._version, start._version, start.data_ptr(), S), True,
+                              np.ascontiguousarray(host.numpy(), dtype=np.int64),
+                              np.ascontiguousarray(start_host.numpy(), dtype=np.int64))
     shapes._mmfs_host = host
     out = (shapes, start, S)
     _cache[key] = out
