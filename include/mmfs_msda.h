@@ -88,6 +88,8 @@ int mmfs_msda_forward(int dtype,
  *   and the pixel-stationary kernel applies; without it the library falls back to
  *   float-atomic accumulation, which is also correct for gapped or overlapping levels. */
 #define MMFS_BWD_FORCE_ATOMIC 2u      /* testing/measurement: always take the atomic path */
+#define MMFS_BWD_DENSE_TAPS   4u      /* mmfs_msda_backward_hybrid: small levels' grad_loc / grad_attn by MFMA */
+#define MMFS_BWD_DENSE_VALUE  8u      /* mmfs_msda_backward_hybrid: small levels' grad_value by MFMA */
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.
@@ -186,7 +188,8 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
  * plain entry points, restricted to those levels.
  * Applies to MMFS_F16 / MMFS_BF16, D in {32, 64, 128}, L <= 64, Nq >= 32, at least one such level;
  * otherwise the *_workspace_bytes queries return 0 and the calls MMFS_E_UNSUPPORTED: use the
- * plain entry points.  The backward additionally needs MMFS_BWD_CANONICAL_LEVELS.
+ * plain entry points.  The backward additionally needs MMFS_BWD_CANONICAL_LEVELS and at least one
+ * of MMFS_BWD_DENSE_TAPS / MMFS_BWD_DENSE_VALUE in ``flags`` (which of its two halves go dense).
  * One behavioural difference, inherent to a dense product: a NON-FINITE value / grad_out element
  * inside a dense level propagates (0 * Inf = NaN) to every query of its (b, h), not only to the
  * queries that sample it.  Environment MMFS_HYBRID=0 disables the routing.

@@ -189,7 +189,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         # small device->host copy the first time a pair of table tensors is seen, none when they
         # come from mmfs_amd.levels.make_level_tables / register_level_tables (like the backward)
         info = None
-        if _hybrid and code in (1, 2) and D in (32, 64, 128) and L <= 64 and Nq >= 32:
+        if _hybrid and "fwd" in _hybrid_parts and code in (1, 2) and D in (32, 64, 128) and L <= 64 and Nq >= 32:
             info = _level_info(spatial_shapes, level_start_index, S)
         if info is not None:
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
@@ -219,12 +219,18 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 # flags of mmfs_msda_backward (include/mmfs_msda.h)
 _BWD_CANONICAL_LEVELS = 1
 _BWD_FORCE_ATOMIC = 2
+_BWD_DENSE_TAPS = 4
+_BWD_DENSE_VALUE = 8
 _E_UNSUPPORTED = -5
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
 # tests / measurements: False keeps every level on the row-gather kernels
 _hybrid = os.environ.get("MMFS_HYBRID", "1") != "0"
+# which parts route their small levels to the matrix cores: comma list of fwd, taps, value.
+# Measured on MI355X: "taps" pays; the forward's dense part costs an fp32 round
+# trip of the output through HBM and the dense grad_value kernel is not yet faster than sort+reduce.
+_hybrid_parts = set(x for x in os.environ.get("MMFS_HYBRID_PARTS", "taps").split(",") if x)
 
 # stage bits of the *_hybrid entry points (include/mmfs_msda.h)
 _HYB_FWD_COARSE, _HYB_FWD_FINE, _HYB_FWD_ALL = 1, 2, 3
@@ -327,6 +333,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         status = _E_UNSUPPORTED
         hyb_bytes = 0
         if _hybrid and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
+            flags |= (_BWD_DENSE_TAPS if "taps" in _hybrid_parts else 0) | (_BWD_DENSE_VALUE if "value" in _hybrid_parts else 0)
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             hyb_bytes = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
         if hyb_bytes > 0:

@@ -347,10 +347,11 @@ int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host
     mmfs::Dims d;
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
+    if (!(flags & (MMFS_BWD_DENSE_TAPS | MMFS_BWD_DENSE_VALUE))) return 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     if (!plan.active) return 0;
     const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    return base + mmfs::hybrid_bwd_partial_bytes(d, plan);
+    return base + ((flags & MMFS_BWD_DENSE_VALUE) ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0);
 }
 
 int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
@@ -367,6 +368,8 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
     if (rc) return rc;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
+    const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) != 0, dense_value = (flags & MMFS_BWD_DENSE_VALUE) != 0;
+    if (!dense_taps && !dense_value) return MMFS_E_UNSUPPORTED;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     if (!plan.active) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
@@ -375,23 +378,24 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
         misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es))
         return MMFS_E_ALIGN;
     const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    if (!workspace || workspace_bytes < base + mmfs::hybrid_bwd_partial_bytes(d, plan)) return MMFS_E_NULLPTR;
+    if (!workspace || workspace_bytes < base + (dense_value ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0))
+        return MMFS_E_NULLPTR;
     if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
     void *partial = (char *)workspace + base;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE))
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
-                                d, false, st, &plan.fine);
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_COARSE))
+                                d, false, st, dense_taps ? &plan.fine : nullptr);
+    if (e == hipSuccess && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
         e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))
         e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
-        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, plan.coarse_mask);
+        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, dense_value ? plan.coarse_mask : 0);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
         e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_COARSE))
+    if (e == hipSuccess && dense_value && (stages & MMFS_HYB_BWD_VALUE_COARSE))
         e = mmfs::backward_value_coarse(dtype, loc, attn, grad_out, grad_value, partial, d, plan, st);
     return (int)e;
 }

@@ -41,6 +41,7 @@ namespace mmfs {
 namespace {
 
 constexpr int kDT = 256;                         // 4 waves
+constexpr int kBT = 1024;                        // 16 waves: the workgroups that own a CU
 constexpr int kTileQ = 64;                       // queries per tile
 constexpr int kAStride = kCoarseMaxPx + 4;       // words per query row ([q][pixel] tiles)
 constexpr int kQStride = kTileQ + 4;             // words per pixel row ([pixel][q] tile)
@@ -83,6 +84,21 @@ template <> struct Mma<half_t> {
 
 // C/D layout of the 32x32 MFMAs: column = lane & 31, row = this (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Development aid (tools/exp_build.sh dense_prof "-DMMFS_PROFILE_DENSE"): shader clocks per phase,
+// summed over workgroups (thread 0 of each), read back with mmfs_debug_dense_profile().
+#ifdef MMFS_PROFILE_DENSE
+}  // namespace
+__device__ unsigned long long g_dense_prof[32];
+namespace {
+#define PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_c = __builtin_readcyclecounter()
+#define PROF(i) do { const unsigned long long prof_n = __builtin_readcyclecounter(); prof_t[i] += prof_n - prof_c; prof_c = prof_n; } while (0)
+#define PROF_END(base) do { if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_dense_prof[(base) + i], prof_t[i]); } while (0)
+#else
+#define PROF_DECL do {} while (0)
+#define PROF(i) do {} while (0)
+#define PROF_END(base) do {} while (0)
+#endif
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -308,229 +324,298 @@ msda_fwd_coarse(const T *__restrict__ vt, const T *__restrict__ loc, const T *__
 
 // ---------------------------------------------------------------- grad_loc / grad_attn, dense levels
 // dot[q, pix] = grad_out[q, :] . value[pix, :] for 64 queries x all pixels of a dense level by
-// MFMA (both operands are 16-byte channel vectors straight from global memory: no packing, no
-// split), parked in LDS; then one thread per (query, point) looks its four corners up and
-// finishes the per-sample algebra of msda_bwd_vec (cuh:119-161).  The look-up threads' samples
-// are requested before the products start (IT = samples per thread when P is 4, 8 or 16).
-template <typename T, int NS, int IT>
-__global__ void __launch_bounds__(kDT)
+// MFMA, parked in LDS; then one thread per (query, point) looks its four corners up and finishes
+// the per-sample algebra of msda_bwd_vec (cuh:119-161).
+// One 1024-lane workgroup per CU owns a run of query tiles of one (b, h) and walks level by level,
+// tile by tile.  16 waves = 2 query blocks x 8 pixel blocks, one 32x32 product per step each:
+//   * a wave's value fragments (its 32 pixels x D channels) do not change along the tiles of a
+//     level: loaded once per level, straight from global memory;
+//   * the tile's grad_out rows are read coalesced (one 16-byte vector per thread, requested a step
+//     ahead) and go through a double-buffered LDS tile into the MFMA operand layout.  Fetching
+//     MFMA operands lane-by-lane from global memory (every lane its own row) ran at ~1 lane/clk
+//     through the vector-memory path: 154 us for this kernel instead of ~40;
+//   * the look-up threads' samples are requested a step ahead as well.
+template <typename T, int NS>
+__global__ void __launch_bounds__(kBT)
 msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ attn,
                  const T *__restrict__ grad_out, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
-                 const Dims d, const CoarsePlan cp)
+                 const Dims d, const CoarsePlan cp, const int chunks, const int tiles_per_chunk)
 {
     constexpr int KB = 2 * NS;                      // 16-channel steps
-    constexpr int ITN = IT > 0 ? IT : 1;
+    constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row (D / 8)
+    constexpr int GS = VPR + 1;                     // row stride of the staged tile, in vectors
     __shared__ __attribute__((aligned(16))) float G[kTileQ * kAStride];
+    __shared__ uint4 gtile[2][kTileQ * GS];
 
-    const BlockCoord bc = block_coord(d, kTileQ);
+    int bid = blockIdx.x;
+    const int h = bid % d.H; bid /= d.H;
+    const int chunk = bid % chunks;
+    const int b = bid / chunks;
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int t_begin = chunk * tiles_per_chunk, t_end = min(q_tiles, t_begin + tiles_per_chunk);
+    if (t_begin >= t_end) return;
+
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform
-    const int mb = wave & 1;                        // this wave's 32 queries
+    const int wave = uni(tid >> 6);
+    const int mb = wave & 1, nbw = wave >> 1;       // this wave's 32 queries / 32 pixels
     const int64_t HD = (int64_t)d.H * d.D;
     const uint32_t *loc2 = reinterpret_cast<const uint32_t *>(loc);       // (x, y) pairs of 16-bit scalars
+    const uint16_t *loc1 = reinterpret_cast<const uint16_t *>(loc);
     const uint16_t *attn1 = reinterpret_cast<const uint16_t *>(attn);
+    const bool pair_ok = (reinterpret_cast<uintptr_t>(loc) & 3) == 0;
+    const int items = kTileQ * d.P;                 // look-ups per step; thread i < items does one (P <= 16)
+    const int iq = tid / d.P, ip = tid - iq * d.P;
+    const int vq = tid / VPR, vc = tid - vq * VPR;  // staging: (row, vector) of the grad_out tile
+    const bool stager = tid < kTileQ * VPR;
 
-    uint4 af[KB];
-    {
-        const int q = min(bc.q0 + mb * 32 + l32, d.Nq - 1);
-        const T *gp = grad_out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + kg * 8;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) af[kb] = *reinterpret_cast<const uint4 *>(gp + kb * 16);
-    }
+    auto go_vector = [&](int t) {
+        const int q = min(t * kTileQ + vq, d.Nq - 1);
+        return *reinterpret_cast<const uint4 *>(grad_out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + vc * 8);
+    };
+    auto sample_index = [&](int t, int level) {
+        const int q = min(t * kTileQ + iq, d.Nq - 1);
+        return ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P + ip;
+    };
+    auto sample_load = [&](int t, int level, uint32_t &xy, uint32_t &a) {
+        if (tid < items) {
+            const int64_t s = sample_index(t, level);
+            if (pair_ok) xy = loc2[s];
+            else xy = (uint32_t)loc1[2 * s] | ((uint32_t)loc1[2 * s + 1] << 16);
+            a = attn1[s];
+        }
+    };
 
+    PROF_DECL;
+    uint32_t nxy = 0, na = 0;
+    if (stager) gtile[0][vq * GS + vc] = go_vector(t_begin);
+    sample_load(t_begin, uni(cp.lv[0].level), nxy, na);
+    __syncthreads();
+    int cur = 0;
     for (int ci = 0; ci < cp.n; ++ci) {
         const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
         const int lstart = uni(cp.lv[ci].start);
         const int px = Hl * Wl, NB = (px + 31) / 32;
-        // the look-up phase's samples: thread -> (query, point) pairs tid, tid + 256, ...
-        uint32_t sxy[ITN], sa[ITN];
-        if (IT > 0) {
+        const int next_level = uni(cp.lv[min(ci + 1, cp.n - 1)].level);
+        const bool prod = nbw < NB;                 // this wave has a pixel block in this level
+        uint4 bf[KB];
+        if (prod) {
+            const int pix = min(nbw * 32 + l32, px - 1);
+            const T *vp = value + ((int64_t)b * d.S + lstart + pix) * HD + (int64_t)h * d.D + kg * 8;
 #pragma unroll
-            for (int i = 0; i < IT; ++i) {
-                const int idx = tid + i * kDT, qi = idx / d.P, p = idx - qi * d.P;
-                const int64_t s = ((((int64_t)bc.b * d.Nq + min(bc.q0 + qi, d.Nq - 1)) * d.H + bc.h) * d.L + level) * d.P + p;
-                sxy[i] = loc2[s];
-                sa[i] = attn1[s];
-            }
+            for (int kb = 0; kb < KB; ++kb) bf[kb] = *reinterpret_cast<const uint4 *>(vp + kb * 16);
         }
-        if (ci > 0) __syncthreads();                // the previous level's look-ups are done
-        for (int nb0 = wave >> 1; nb0 < NB; nb0 += 4) {
-            // two pixel blocks per round: all value fragments requested before the first product
-            uint4 bf[2][KB];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int nb = nb0 + 2 * t;
-                const int pix = min(nb * 32 + l32, px - 1);
-                const T *vp = value + ((int64_t)bc.b * d.S + lstart + pix) * HD + (int64_t)bc.h * d.D + kg * 8;
-                if (nb < NB) {
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) bf[t][kb] = *reinterpret_cast<const uint4 *>(vp + kb * 16);
-                }
+        for (int t = t_begin; t < t_end; ++t) {
+            const bool last_tile = t + 1 == t_end;
+            const bool more = !(last_tile && ci + 1 == cp.n);
+            const int nt = last_tile ? t_begin : t + 1;
+            const uint32_t sxy = nxy, sa = na;
+            uint4 nv = make_uint4(0u, 0u, 0u, 0u);
+            if (more) {
+                if (stager) nv = go_vector(nt);
+                sample_load(nt, last_tile ? next_level : level, nxy, na);
             }
+            if (prod) {
+                const uint4 *arow = &gtile[cur][(mb * 32 + l32) * GS + kg];
+                f32x16 acc = zero16();
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int nb = nb0 + 2 * t;
-                if (nb < NB) {
-                    f32x16 acc = zero16();
+                for (int kb = 0; kb < KB; ++kb) acc = Mma<T>::run(arow[kb * 2], bf[kb], acc);
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) acc = Mma<T>::run(af[kb], bf[t][kb], acc);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) G[(mb * 32 + mfma_row(r, lane)) * kAStride + nb * 32 + l32] = acc[r];
-                }
+                for (int r = 0; r < 16; ++r) G[(mb * 32 + mfma_row(r, lane)) * kAStride + nbw * 32 + l32] = acc[r];
             }
-        }
-        __syncthreads();
-        auto finish = [&](int idx, bool preloaded, uint32_t rxy, uint32_t ra) {
-            const int qi = idx / d.P, p = idx - qi * d.P;
-            const int q = bc.q0 + qi;
-            if (q >= d.Nq) return;
-            const int64_t s = ((((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.L + level) * d.P + p;
-            float lx, ly, a;
-            if (preloaded) {
+            PROF(0);
+            if (more && stager) gtile[cur ^ 1][vq * GS + vc] = nv;
+            PROF(1);
+            __syncthreads();
+            PROF(2);
+            if (tid < items && t * kTileQ + iq < d.Nq) {
+                const int64_t s = sample_index(t, level);
                 float l[Vec16<T>::N];
-                Vec16<T>::unpack(make_uint4(rxy, ra, 0u, 0u), l);     // {x, y, a, -}
-                lx = l[0]; ly = l[1]; a = l[2];
-            } else {
-                lx = to_f32(loc[2 * s]); ly = to_f32(loc[2 * s + 1]); a = to_f32(attn[s]);
+                Vec16<T>::unpack(make_uint4(sxy, sa, 0u, 0u), l);         // {x, y, a, -}
+                const float a = l[2];
+                const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
+                const float *g = G + iq * kAStride;
+                float dot[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dot[c] = tp.row[c] >= 0 ? g[tp.row[c]] : 0.f;
+                const float fx = tp.fx, fy = tp.fy, gy = 1.f - fy, gx = 1.f - fx;
+                const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+                const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
+                const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
+                const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
+                grad_attn[s] = (T)ga;
+                grad_loc[2 * s] = (T)((float)Wl * dw * a);
+                grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
             }
-            const Tap<float> t = locate<float>(lx, ly, Hl, Wl, 0);
-            const float *g = G + qi * kAStride;
-            float dot[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dot[c] = t.row[c] >= 0 ? g[t.row[c]] : 0.f;
-            const float fx = t.fx, fy = t.fy, gy = 1.f - fy, gx = 1.f - fx;
-            const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
-            const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
-            const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
-            const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
-            grad_attn[s] = (T)ga;
-            grad_loc[2 * s] = (T)((float)Wl * dw * a);
-            grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
-        };
-        if (IT > 0) {
-#pragma unroll
-            for (int i = 0; i < IT; ++i) finish(tid + i * kDT, true, sxy[i], sa[i]);
-        } else {
-            for (int idx = tid; idx < kTileQ * d.P; idx += kDT) finish(idx, false, 0u, 0u);
+            PROF(3);
+            __syncthreads();
+            PROF(4);
+            cur ^= 1;
         }
     }
+    PROF_END(0);
 }
 
 // ---------------------------------------------------------------- grad_value, dense levels
-// One workgroup = one (b, h, dense level, chunk of query tiles).  The level's whole grad_value
-// [pixels x D] lives in MFMA accumulators across the chunk; per tile the weight tile is built
-// pixel-major and multiplied with the tile's grad_out rows.  The tile's grad_out elements and the
-// next tile's samples are requested before the tile is built.  Partial sums per chunk go to the
-// workspace; coarse_value_epilogue adds the chunks and stores the rows in the storage type.
-// NJ = (32-pixel block, channel slice) jobs per wave, a power of two covering the level: the body
-// is straight-line code (a branch per job makes the compiler shuffle the accumulators around).
-struct ValueCoarseArgs {
-    int b, h, chunk, level, Hl, Wl, coff, kpad, PB, t_begin, t_end;
-};
+// One 1024-lane workgroup per CU = one (b, h, chunk of query tiles), all dense levels in turn.
+// A level's whole grad_value [pixels x D] lives in MFMA accumulators across the chunk; per tile
+// the weight tile is built pixel-major -- 256 threads turn one sample each into a {4 pixels,
+// 4 weights} record, then all 1024 apply the records (the 16 lanes of a query own the pixels with
+// (pixel & 15) == lane: plain read-add-write, no two lanes on one word) -- split into {hi, lo} and
+// multiplied with the tile's grad_out rows: 16 waves = channel slices x pixel blocks.  The tile's
+// grad_out elements and the next tile's samples are requested before the tile is built.  Partial
+// sums per chunk go to the workspace; coarse_value_epilogue adds the chunks and stores the rows
+// in the storage type.
+struct alignas(16) SampleRec { int pix[4]; float w[4]; };
 
-template <typename T, int NS, int NV, int NJ>
-__device__ __forceinline__ void value_coarse_body(float *__restrict__ At, const T *__restrict__ loc,
-                                                  const T *__restrict__ attn, const T *__restrict__ grad_out,
-                                                  float *__restrict__ partial, const Dims &d, int ktot,
-                                                  const ValueCoarseArgs &v)
-{
-    constexpr int PBSTEP = 4 / NS;
-    constexpr int QB = kTileQ / 8;                  // query octets per tile
-    constexpr int ROWS = NJ * PBSTEP * 32;          // tile rows the jobs read (<= 256)
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ns = wave % NS, pb0 = wave / NS;
-    const int64_t HD = (int64_t)d.H * d.D;
-    const uint16_t *go = reinterpret_cast<const uint16_t *>(grad_out) + ((int64_t)v.b * d.Nq * d.H + v.h) * d.D + ns * 32 + l32;
-
-    f32x16 acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = zero16();
-
-    auto sample_base = [&](int t) {
-        return ((((int64_t)v.b * d.Nq + min(t * kTileQ + (tid >> 2), d.Nq - 1)) * d.H + v.h) * d.L + v.level) * d.P;
-    };
-    Samples<T, NV> nxt;
-    if (v.t_begin < v.t_end) nxt.request(loc, attn, sample_base(v.t_begin));
-    for (int t = v.t_begin; t < v.t_end; ++t) {
-        const int q0 = t * kTileQ;
-        const Samples<T, NV> cur = nxt;
-        nxt.request(loc, attn, sample_base(min(t + 1, v.t_end - 1)));
-        // this lane's grad_out elements of the tile: 4 queries per MFMA step, one channel
-        // (first half of the tile now, second half while the first is used)
-        uint32_t g[QB / 2][4];
-#pragma unroll
-        for (int qb = 0; qb < QB / 2; ++qb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = q0 + qb * 8 + kg * 4 + i;
-                g[qb][i] = go[(int64_t)min(q, d.Nq - 1) * HD];
-            }
-        }
-        if (t > v.t_begin) __syncthreads();
-        tile_zero<kQStride / 4>(At, ROWS, kTileQ / 4);
-        __syncthreads();
-        build_weight_tile<T, NV, true>(At, cur, loc, attn, d, v.b, v.h, q0, v.level, v.Hl, v.Wl);
-        __syncthreads();
-        tile_split<T, kQStride / 4>(At, ROWS, kTileQ / 4);
-        __syncthreads();
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = q0 + qb * 8 + kg * 4 + i;
-                const uint32_t e = g[qb % (QB / 2)][i];
-                w[i] = q < d.Nq ? (e | (e << 16)) : 0u;                  // every element twice: meets {hi, lo}
-                if (qb < QB / 2) g[qb][i] = go[(int64_t)min(q + 8 * (QB / 2), d.Nq - 1) * HD];
-            }
-            const uint4 bfrag = make_uint4(w[0], w[1], w[2], w[3]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int pb = pb0 + j * PBSTEP;
-                const uint4 afrag = *reinterpret_cast<const uint4 *>(&At[(pb * 32 + l32) * kQStride + qb * 8 + kg * 4]);
-                acc[j] = Mma<T>::run(afrag, bfrag, acc[j]);
-            }
-        }
-    }
-    float *pp = partial + ((((int64_t)v.chunk * d.B + v.b) * d.H + v.h) * ktot + v.coff) * d.D + ns * 32 + l32;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int pb = pb0 + j * PBSTEP;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pix = pb * 32 + mfma_row(r, lane);
-            if (pix < v.kpad) pp[(int64_t)pix * d.D] = acc[j][r];
-        }
-    }
-}
-
-template <typename T, int NS, int NV>
-__global__ void __launch_bounds__(kDT, 2)
+template <typename T, int NS>
+__global__ void __launch_bounds__(kBT)
 msda_value_coarse(const T *__restrict__ loc, const T *__restrict__ attn, const T *__restrict__ grad_out,
                   float *__restrict__ partial, const Dims d, const CoarsePlan cp, const int chunks,
                   const int tiles_per_chunk)
 {
-    constexpr int PBSTEP = 4 / NS;
+    constexpr int PBSTEP = 16 / NS;                 // pixel blocks between a wave's jobs
+    constexpr int NJ = NS >= 4 ? NS / 2 : 1;        // jobs per wave (8 pixel blocks * NS slices / 16 waves)
+    constexpr int QB = kTileQ / 8;                  // query octets per tile
     __shared__ __attribute__((aligned(16))) float At[kCoarseMaxPx * kQStride];
+    __shared__ SampleRec rec[kTileQ * 4];
 
     int bid = blockIdx.x;
-    ValueCoarseArgs v;
-    v.h = bid % d.H; bid /= d.H;
-    const int ci = bid % cp.n; bid /= cp.n;
-    v.chunk = bid % chunks;
-    v.b = bid / chunks;
-    v.level = uni(cp.lv[ci].level); v.Hl = uni(cp.lv[ci].Hl); v.Wl = uni(cp.lv[ci].Wl);
-    v.coff = uni(cp.lv[ci].coff); v.kpad = uni(cp.lv[ci].kpad);
-    v.PB = (v.Hl * v.Wl + 31) / 32;
+    const int h = bid % d.H; bid /= d.H;
+    const int chunk = bid % chunks;
+    const int b = bid / chunks;
     const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
-    v.t_begin = v.chunk * tiles_per_chunk;
-    v.t_end = min(q_tiles, v.t_begin + tiles_per_chunk);
-    const int need = (v.PB + PBSTEP - 1) / PBSTEP;          // jobs per wave that cover the level
-    if (need <= 1) value_coarse_body<T, NS, NV, 1>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
-    else if (need <= 2) value_coarse_body<T, NS, NV, 2>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
-    else if (NS >= 2 && need <= 4) value_coarse_body<T, NS, NV, (NS >= 2 ? 4 : 2)>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
-    else if (NS >= 4) value_coarse_body<T, NS, NV, (NS >= 4 ? 8 : 2)>(At, loc, attn, grad_out, partial, d, cp.ktot, v);
+    const int t_begin = chunk * tiles_per_chunk, t_end = min(q_tiles, t_begin + tiles_per_chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
+    const int wave = uni(tid >> 6);
+    const int ns = wave % NS, pb0 = wave / NS;
+    const int64_t HD = (int64_t)d.H * d.D;
+    // grad_out elements through a buffer descriptor over this (b, h)'s rows: one 32-bit lane
+    // offset + a uniform offset per element, and rows past the last query read as zero
+    const __amdgpu_buffer_rsrc_t go_rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
+                                                          ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
+    const uint32_t go_row = (uint32_t)(HD * sizeof(T));
+    const uint32_t go_lane = (uint32_t)((ns * 32 + l32) * sizeof(T)) + (uint32_t)(kg * 4) * go_row;
+    const uint16_t *loc1 = reinterpret_cast<const uint16_t *>(loc);
+    const uint16_t *attn1 = reinterpret_cast<const uint16_t *>(attn);
+    const int sq = tid >> 2, sp = tid & 3;          // record makers: threads 0..255 -> (query, point of the pass)
+    const int aq = tid >> 4, aj = tid & 15;         // record appliers: (query, owned pixel class)
+    const int passes = (d.P + 3) / 4;
+
+    for (int ci = 0; ci < cp.n; ++ci) {
+        const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
+        const int coff = uni(cp.lv[ci].coff), kpad = uni(cp.lv[ci].kpad);
+        const int PB = (Hl * Wl + 31) / 32;
+        const int rows = min(kCoarseMaxPx, (PB + PBSTEP - 1) / PBSTEP * PBSTEP * 32);   // rows some job reads
+        const bool mm = pb0 < PB;                   // this wave has a pixel block in this level
+
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = zero16();
+
+        for (int t = t_begin; t < t_end; ++t) {
+            const int q0 = t * kTileQ;
+            PROF_DECL;
+            // this lane's grad_out elements of the tile: 4 queries per MFMA step, one channel
+            // (first half of the tile now, second half while the first is used)
+            uint32_t g[QB / 2][4];
+#pragma unroll
+            for (int qb = 0; qb < QB / 2; ++qb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    g[qb][i] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
+                        go_rsrc, (int)(go_lane + (uint32_t)q0 * go_row), (int)((uint32_t)(qb * 8 + i) * go_row), 0);
+            }
+            __syncthreads();                        // the previous tile's fragments are all read
+            PROF(0);
+            {   // zero: rows x 16 vectors
+                uint4 *v4 = reinterpret_cast<uint4 *>(At);
+                for (int r = tid >> 4; r < rows; r += kBT / 16) v4[r * (kQStride / 4) + (tid & 15)] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            PROF(1);
+            for (int pass = 0; pass < passes; ++pass) {
+                if (tid < kTileQ * 4) {
+                    SampleRec rc;
+                    rc.pix[0] = rc.pix[1] = rc.pix[2] = rc.pix[3] = -1;
+                    rc.w[0] = rc.w[1] = rc.w[2] = rc.w[3] = 0.f;
+                    const int q = q0 + sq, p = pass * 4 + sp;
+                    if (q < d.Nq && p < d.P) {
+                        const int64_t s = ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P + p;
+                        float l[Vec16<T>::N];
+                        Vec16<T>::unpack(make_uint4((uint32_t)loc1[2 * s] | ((uint32_t)loc1[2 * s + 1] << 16),
+                                                    (uint32_t)attn1[s], 0u, 0u), l);      // {x, y, a, -}
+                        const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
+                        const float gy = 1.f - tp.fy, gx = 1.f - tp.fx, a = l[2];
+                        rc.pix[0] = tp.row[0]; rc.pix[1] = tp.row[1]; rc.pix[2] = tp.row[2]; rc.pix[3] = tp.row[3];
+                        rc.w[0] = gy * gx * a; rc.w[1] = gy * tp.fx * a; rc.w[2] = tp.fy * gx * a; rc.w[3] = tp.fy * tp.fx * a;
+                    }
+                    rec[tid] = rc;
+                }
+                __syncthreads();
+                PROF(2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const SampleRec rc = rec[aq * 4 + k];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (rc.pix[c] >= 0 && (rc.pix[c] & 15) == aj) At[rc.pix[c] * kQStride + aq] += rc.w[c];
+                }
+                __syncthreads();
+                PROF(3);
+            }
+            {   // split {hi, lo} in place
+                uint4 *v4 = reinterpret_cast<uint4 *>(At);
+                for (int r = tid >> 4; r < rows; r += kBT / 16) {
+                    uint4 x = v4[r * (kQStride / 4) + (tid & 15)];
+                    x.x = Mma<T>::split(__uint_as_float(x.x)); x.y = Mma<T>::split(__uint_as_float(x.y));
+                    x.z = Mma<T>::split(__uint_as_float(x.z)); x.w = Mma<T>::split(__uint_as_float(x.w));
+                    v4[r * (kQStride / 4) + (tid & 15)] = x;
+                }
+            }
+            __syncthreads();
+            PROF(4);
+            // (waves without a pixel block in this level multiply zero / foreign rows: never stored)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t e = g[qb % (QB / 2)][i];
+                    w[i] = e | (e << 16);                                    // every element twice: meets {hi, lo}
+                    if (qb < QB / 2)
+                        g[qb][i] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
+                            go_rsrc, (int)(go_lane + (uint32_t)q0 * go_row),
+                            (int)((uint32_t)((qb + QB / 2) * 8 + i) * go_row), 0);
+                }
+                const uint4 bfrag = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int pb = min(pb0 + j * PBSTEP, kCoarseMaxPx / 32 - 1);
+                    const uint4 afrag = *reinterpret_cast<const uint4 *>(&At[(pb * 32 + l32) * kQStride + qb * 8 + kg * 4]);
+                    acc[j] = Mma<T>::run(afrag, bfrag, acc[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // keep the fragment reads next to their products
+            }
+            PROF(5);
+            PROF_END(8 + (ci == 0 ? 0 : 8));
+        }
+        if (mm) {
+            // through a buffer descriptor over the level's kpad rows of this chunk: a lane offset +
+            // a uniform offset per element, and rows past kpad are dropped by the hardware
+            const __amdgpu_buffer_rsrc_t prs = make_slab_rsrc(
+                partial + ((((int64_t)chunk * d.B + b) * d.H + h) * cp.ktot + coff) * d.D, (int64_t)kpad * d.D * 4);
+            const uint32_t prow = (uint32_t)d.D * 4u;
+            const uint32_t plane = (uint32_t)(pb0 * 32 + 4 * kg) * prow + (uint32_t)(ns * 32 + l32) * 4u;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), prs, (int)plane,
+                                                          (int)((uint32_t)(j * PBSTEP * 32 + (r & 3) + 8 * (r >> 2)) * prow), 0);
+            }
+        }
+    }
 }
 
 template <typename T>
@@ -568,13 +653,8 @@ coarse_value_epilogue(const float *__restrict__ partial, T *__restrict__ grad_va
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
-int value_chunks(const Dims &d, const CoarsePlan &cp)
-{
-    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
-    const int64_t slices = (int64_t)d.B * d.H * std::max(1, cp.n);
-    const int64_t want = (512 + slices - 1) / slices;            // ~2 workgroups per CU
-    return (int)std::max<int64_t>(1, std::min<int64_t>(want, q_tiles));
-}
+int tile_chunks(const Dims &d);
+int value_chunks(const Dims &d, const CoarsePlan &) { return tile_chunks(d); }
 
 // samples per (query, level) as whole vectors?  (P = 4 or 8, 16-byte aligned tensors)
 inline int sample_vectors(const void *loc, const void *attn, const Dims &d)
@@ -603,19 +683,28 @@ hipError_t launch_fwd_coarse(const void *value, const void *loc, const void *att
     return hipGetLastError();
 }
 
+// chunks of query tiles per (b, h): one 1024-lane workgroup per CU and then some
+int tile_chunks(const Dims &d)
+{
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int64_t slices = (int64_t)d.B * d.H;
+    const int64_t want = (256 + slices - 1) / slices;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, q_tiles));
+}
+
 template <typename T, int NS>
 hipError_t launch_taps_coarse(const void *value, const void *loc, const void *attn, const void *go,
-                              void *gl, void *ga, const Dims &din, const CoarsePlan &cp, hipStream_t st)
+                              void *gl, void *ga, const Dims &d, const CoarsePlan &cp, hipStream_t st)
 {
-    Dims d = din;
-    d.q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
-    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
+    if (d.P > 16) return hipErrorInvalidValue;
+    const int chunks = tile_chunks(d);
+    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int tpc = (q_tiles + chunks - 1) / chunks;
+    const int64_t blocks = (int64_t)d.B * d.H * chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-#define MMFS_L(IT) hipLaunchKernelGGL((msda_taps_coarse<T, NS, IT>), dim3((unsigned)blocks), dim3(kDT), 0, st, \
-                                      (const T *)value, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga, d, cp)
-    const bool al = ((uintptr_t)loc % 4) == 0;                  // (x, y) pairs are read as one 32-bit word
-    switch (al ? d.P : 0) { case 4: MMFS_L(1); break; case 8: MMFS_L(2); break; case 16: MMFS_L(4); break; default: MMFS_L(0); }
-#undef MMFS_L
+    hipLaunchKernelGGL((msda_taps_coarse<T, NS>), dim3((unsigned)blocks), dim3(kBT), 0, st,
+                       (const T *)value, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga, d, cp,
+                       chunks, tpc);
     return hipGetLastError();
 }
 
@@ -626,12 +715,10 @@ hipError_t launch_value_coarse(const void *loc, const void *attn, const void *go
     const int chunks = value_chunks(d, cp);
     const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
     const int tpc = (q_tiles + chunks - 1) / chunks;
-    const int64_t blocks = (int64_t)d.B * d.H * cp.n * chunks;
+    const int64_t blocks = (int64_t)d.B * d.H * chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-#define MMFS_L(NV) hipLaunchKernelGGL((msda_value_coarse<T, NS, NV>), dim3((unsigned)blocks), dim3(kDT), 0, st, \
-                                      (const T *)loc, (const T *)attn, (const T *)go, (float *)partial, d, cp, chunks, tpc)
-    switch (sample_vectors(loc, attn, d)) { case 1: MMFS_L(1); break; case 2: MMFS_L(2); break; default: MMFS_L(0); }
-#undef MMFS_L
+    hipLaunchKernelGGL((msda_value_coarse<T, NS>), dim3((unsigned)blocks), dim3(kBT), 0, st,
+                       (const T *)loc, (const T *)attn, (const T *)go, (float *)partial, d, cp, chunks, tpc);
     const int64_t items = (int64_t)d.B * d.H * cp.ktot * (d.D / 4);
     hipLaunchKernelGGL((coarse_value_epilogue<T>), dim3((unsigned)std::min<int64_t>((items + 255) / 256, 256 * 32)),
                        dim3(256), 0, st, (const float *)partial, (T *)gv, d, cp, chunks);
@@ -669,7 +756,8 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
     if (!host_shapes || !host_start) return p;
     if (dtype != 1 && dtype != 2) return p;
     if (d.D != 32 && d.D != 64 && d.D != 128) return p;
-    if (d.L <= 0 || d.L > kMaxSelLevels || d.P <= 0 || d.Nq < 32) return p;
+    if (d.L <= 0 || d.L > kMaxSelLevels || d.P <= 0 || d.P > 16 || d.Nq < 32) return p;
+    if ((int64_t)d.Nq * d.H * d.D * 2 > kMaxSlabBytes) return p;           // grad_out rows by 32-bit offsets
     if (const char *e = getenv("MMFS_HYBRID")) if (atoi(e) == 0) return p;
     // a level pays off densely while its pixel count (MFMA work per query) stays below the row
     // reads it replaces: K/4 MFMA clocks against 16*P row clocks per query at D = 128
@@ -739,3 +827,15 @@ hipError_t backward_value_coarse(int dtype, const void *loc, const void *attn, c
 }
 
 }  // namespace mmfs
+
+#ifdef MMFS_PROFILE_DENSE
+extern "C" int mmfs_debug_dense_profile(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mmfs::g_dense_prof), sizeof(unsigned long long) * 32);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_dense_prof), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif

@@ -80,6 +80,19 @@ def timing(args, hybrid, iters=20):
         run(args, hybrid)
     torch.cuda.synchronize()
     print(f"    wall per fwd+bwd            {(time.perf_counter() - t) / iters * 1e6:9.1f} us", flush=True)
+    if hybrid and hasattr(MSDA._lib, "mmfs_debug_dense_profile"):
+        import ctypes
+        buf = (ctypes.c_ulonglong * 32)()
+        MSDA._lib.mmfs_debug_dense_profile(buf, 1)
+        run(args, True)
+        MSDA._lib.mmfs_debug_dense_profile(buf, 1)
+        v = list(buf)
+        print("    taps phases (kclk summed over WGs): mfma %d | reload+G %d | bar1 %d | lookup %d | bar2 %d" %
+              tuple(x // 1000 for x in v[0:5]), flush=True)
+        for lv in (0, 1):
+            o = 8 + 8 * lv
+            print("    value L%d phases (kclk): g+bar %d | zero %d | record %d | apply %d | split %d | mfma %d" %
+                  ((lv,) + tuple(x // 1000 for x in v[o:o + 6])), flush=True)
 
 
 CASES = [
