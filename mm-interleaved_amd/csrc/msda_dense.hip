@@ -335,8 +335,9 @@ msda_fwd_coarse(const T *__restrict__ vt, const T *__restrict__ loc, const T *__
 //     MFMA operands lane-by-lane from global memory (every lane its own row) ran at ~1 lane/clk
 //     through the vector-memory path: 154 us for this kernel instead of ~40;
 //   * the look-up threads' samples are requested a step ahead as well.
-template <typename T, int NS>
-__global__ void __launch_bounds__(kBT)
+// MB = 32-query blocks per tile (workgroup = MB * 512 lanes)
+template <typename T, int NS, int MB>
+__global__ void __launch_bounds__(MB * 512)
 msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ attn,
                  const T *__restrict__ grad_out, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
                  const Dims d, const CoarsePlan cp, const int chunks, const int tiles_per_chunk)
@@ -344,36 +345,37 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
     constexpr int KB = 2 * NS;                      // 16-channel steps
     constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row (D / 8)
     constexpr int GS = VPR + 1;                     // row stride of the staged tile, in vectors
-    __shared__ __attribute__((aligned(16))) float G[kTileQ * kAStride];
-    __shared__ uint4 gtile[2][kTileQ * GS];
+    constexpr int TQ = 32 * MB;                     // queries per tile
+    __shared__ __attribute__((aligned(16))) float G[TQ * kAStride];
+    __shared__ uint4 gtile[2][TQ * GS];
 
     int bid = blockIdx.x;
     const int h = bid % d.H; bid /= d.H;
     const int chunk = bid % chunks;
     const int b = bid / chunks;
-    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int q_tiles = (d.Nq + TQ - 1) / TQ;
     const int t_begin = chunk * tiles_per_chunk, t_end = min(q_tiles, t_begin + tiles_per_chunk);
     if (t_begin >= t_end) return;
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
     const int wave = uni(tid >> 6);
-    const int mb = wave & 1, nbw = wave >> 1;       // this wave's 32 queries / 32 pixels
+    const int mb = wave % MB, nbw = wave / MB;       // this wave's 32 queries / 32 pixels
     const int64_t HD = (int64_t)d.H * d.D;
     const uint32_t *loc2 = reinterpret_cast<const uint32_t *>(loc);       // (x, y) pairs of 16-bit scalars
     const uint16_t *loc1 = reinterpret_cast<const uint16_t *>(loc);
     const uint16_t *attn1 = reinterpret_cast<const uint16_t *>(attn);
     const bool pair_ok = (reinterpret_cast<uintptr_t>(loc) & 3) == 0;
-    const int items = kTileQ * d.P;                 // look-ups per step; thread i < items does one (P <= 16)
+    const int items = TQ * d.P;                 // look-ups per step; thread i < items does one (P <= 16)
     const int iq = tid / d.P, ip = tid - iq * d.P;
     const int vq = tid / VPR, vc = tid - vq * VPR;  // staging: (row, vector) of the grad_out tile
-    const bool stager = tid < kTileQ * VPR;
+    const bool stager = tid < TQ * VPR;
 
     auto go_vector = [&](int t) {
-        const int q = min(t * kTileQ + vq, d.Nq - 1);
+        const int q = min(t * TQ + vq, d.Nq - 1);
         return *reinterpret_cast<const uint4 *>(grad_out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + vc * 8);
     };
     auto sample_index = [&](int t, int level) {
-        const int q = min(t * kTileQ + iq, d.Nq - 1);
+        const int q = min(t * TQ + iq, d.Nq - 1);
         return ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P + ip;
     };
     auto sample_load = [&](int t, int level, uint32_t &xy, uint32_t &a) {
@@ -427,7 +429,7 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
             PROF(1);
             __syncthreads();
             PROF(2);
-            if (tid < items && t * kTileQ + iq < d.Nq) {
+            if (tid < items && t * TQ + iq < d.Nq) {
                 const int64_t s = sample_index(t, level);
                 float l[Vec16<T>::N];
                 Vec16<T>::unpack(make_uint4(sxy, sa, 0u, 0u), l);         // {x, y, a, -}
@@ -457,15 +459,25 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
 
 // ---------------------------------------------------------------- grad_value, dense levels
 // One 1024-lane workgroup per CU = one (b, h, chunk of query tiles), all dense levels in turn.
-// A level's whole grad_value [pixels x D] lives in MFMA accumulators across the chunk; per tile
-// the weight tile is built pixel-major -- 256 threads turn one sample each into a {4 pixels,
-// 4 weights} record, then all 1024 apply the records (the 16 lanes of a query own the pixels with
-// (pixel & 15) == lane: plain read-add-write, no two lanes on one word) -- split into {hi, lo} and
-// multiplied with the tile's grad_out rows: 16 waves = channel slices x pixel blocks.  The tile's
-// grad_out elements and the next tile's samples are requested before the tile is built.  Partial
-// sums per chunk go to the workspace; coarse_value_epilogue adds the chunks and stores the rows
-// in the storage type.
+// A level's whole grad_value [pixels x D] lives in MFMA accumulators across the chunk.  Per tile:
+//   stage   the tile's grad_out rows, read coalesced a step ahead, are stored TRANSPOSED in LDS
+//           ([channel][query]) so that a lane's B operand (4 queries of its channel) is one 8-byte read;
+//   build   256 threads turn one sample each (requested a step ahead) into a {4 pixels, 4 weights}
+//           record, then all 1024 apply the records to the pixel-major fp32 weight tile: the 16
+//           lanes of a query own the pixels with (pixel & 15) == lane -- plain read-add-write, no
+//           two lanes on one word (LDS float atomics: 0.33 lane-adds/clk/CU);
+//   split   every row becomes [hi of 64 queries | lo of 64 queries], in place (read all, barrier,
+//           write): the MFMA K-slots are {hi q0..q3, lo q0..q3} against {g q0..q3, g q0..q3};
+//   product 16 waves = channel slices x pixel blocks.
+// Partial sums per chunk go to the workspace; coarse_value_epilogue adds the chunks and stores the
+// rows in the storage type.
 struct alignas(16) SampleRec { int pix[4]; float w[4]; };
+
+template <typename T> __device__ __forceinline__ void split_hi_lo(float a, uint32_t &hi, uint32_t &lo)
+{
+    const uint32_t w = Mma<T>::split(a);
+    hi = w & 0xffffu; lo = w >> 16;
+}
 
 template <typename T, int NS>
 __global__ void __launch_bounds__(kBT)
@@ -476,8 +488,13 @@ msda_value_coarse(const T *__restrict__ loc, const T *__restrict__ attn, const T
     constexpr int PBSTEP = 16 / NS;                 // pixel blocks between a wave's jobs
     constexpr int NJ = NS >= 4 ? NS / 2 : 1;        // jobs per wave (8 pixel blocks * NS slices / 16 waves)
     constexpr int QB = kTileQ / 8;                  // query octets per tile
-    __shared__ __attribute__((aligned(16))) float At[kCoarseMaxPx * kQStride];
+    constexpr int RS = 66;                          // words per pixel row of the weight tile (8-byte accesses: no bank conflicts)
+    constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row
+    constexpr int GTS = kTileQ + 4;                 // halfwords per channel row of the transposed grad_out tile
+    constexpr int MAXPASS = 4;                      // P <= 16
+    __shared__ __attribute__((aligned(16))) float At[kCoarseMaxPx * RS];
     __shared__ SampleRec rec[kTileQ * 4];
+    __shared__ __attribute__((aligned(16))) uint16_t gT[32 * NS * GTS];
 
     int bid = blockIdx.x;
     const int h = bid % d.H; bid /= d.H;
@@ -485,26 +502,48 @@ msda_value_coarse(const T *__restrict__ loc, const T *__restrict__ attn, const T
     const int b = bid / chunks;
     const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
     const int t_begin = chunk * tiles_per_chunk, t_end = min(q_tiles, t_begin + tiles_per_chunk);
+    if (t_begin >= t_end) return;
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kg = lane >> 5;
     const int wave = uni(tid >> 6);
     const int ns = wave % NS, pb0 = wave / NS;
-    const int64_t HD = (int64_t)d.H * d.D;
-    // grad_out elements through a buffer descriptor over this (b, h)'s rows: one 32-bit lane
-    // offset + a uniform offset per element, and rows past the last query read as zero
-    const __amdgpu_buffer_rsrc_t go_rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
-                                                          ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
-    const uint32_t go_row = (uint32_t)(HD * sizeof(T));
-    const uint32_t go_lane = (uint32_t)((ns * 32 + l32) * sizeof(T)) + (uint32_t)(kg * 4) * go_row;
     const uint16_t *loc1 = reinterpret_cast<const uint16_t *>(loc);
     const uint16_t *attn1 = reinterpret_cast<const uint16_t *>(attn);
     const int sq = tid >> 2, sp = tid & 3;          // record makers: threads 0..255 -> (query, point of the pass)
     const int aq = tid >> 4, aj = tid & 15;         // record appliers: (query, owned pixel class)
+    const int vq = tid / VPR, vc = tid - vq * VPR;  // stagers: (row, vector) of the grad_out tile
+    const bool stager = tid < kTileQ * VPR, maker = tid < kTileQ * 4;
     const int passes = (d.P + 3) / 4;
+
+    auto go_vector = [&](int t) {
+        const int q = t * kTileQ + vq;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);       // rows past the last query contribute nothing
+        if (stager && q < d.Nq)
+            v = *reinterpret_cast<const uint4 *>(grad_out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + vc * 8);
+        return v;
+    };
+    auto sample_load = [&](int t, int level, uint32_t (&xy)[MAXPASS], uint32_t (&a)[MAXPASS]) {
+        if (maker) {
+            const int q = min(t * kTileQ + sq, d.Nq - 1);
+#pragma unroll
+            for (int pass = 0; pass < MAXPASS; ++pass) {
+                if (pass < passes) {
+                    const int64_t s = ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P + min(pass * 4 + sp, d.P - 1);
+                    xy[pass] = (uint32_t)loc1[2 * s] | ((uint32_t)loc1[2 * s + 1] << 16);
+                    a[pass] = attn1[s];
+                }
+            }
+        }
+    };
+
+    uint4 nv = go_vector(t_begin);
+    uint32_t nxy[MAXPASS] = {0, 0, 0, 0}, na[MAXPASS] = {0, 0, 0, 0};
+    sample_load(t_begin, uni(cp.lv[0].level), nxy, na);
 
     for (int ci = 0; ci < cp.n; ++ci) {
         const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
         const int coff = uni(cp.lv[ci].coff), kpad = uni(cp.lv[ci].kpad);
+        const int next_level = uni(cp.lv[min(ci + 1, cp.n - 1)].level);
         const int PB = (Hl * Wl + 31) / 32;
         const int rows = min(kCoarseMaxPx, (PB + PBSTEP - 1) / PBSTEP * PBSTEP * 32);   // rows some job reads
         const bool mm = pb0 < PB;                   // this wave has a pixel block in this level
@@ -515,87 +554,110 @@ msda_value_coarse(const T *__restrict__ loc, const T *__restrict__ attn, const T
 
         for (int t = t_begin; t < t_end; ++t) {
             const int q0 = t * kTileQ;
+            const bool last_tile = t + 1 == t_end;
+            const bool more = !(last_tile && ci + 1 == cp.n);
+            const int nt = last_tile ? t_begin : t + 1;
             PROF_DECL;
-            // this lane's grad_out elements of the tile: 4 queries per MFMA step, one channel
-            // (first half of the tile now, second half while the first is used)
-            uint32_t g[QB / 2][4];
+            const uint4 cv = nv;
+            uint32_t sxy[MAXPASS], sa[MAXPASS];
 #pragma unroll
-            for (int qb = 0; qb < QB / 2; ++qb) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    g[qb][i] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
-                        go_rsrc, (int)(go_lane + (uint32_t)q0 * go_row), (int)((uint32_t)(qb * 8 + i) * go_row), 0);
-            }
+            for (int i = 0; i < MAXPASS; ++i) { sxy[i] = nxy[i]; sa[i] = na[i]; }
             __syncthreads();                        // the previous tile's fragments are all read
+            if (more) {                             // next step's global reads: a whole step to arrive
+                nv = go_vector(nt);
+                sample_load(nt, last_tile ? next_level : level, nxy, na);
+            }
             PROF(0);
-            {   // zero: rows x 16 vectors
-                uint4 *v4 = reinterpret_cast<uint4 *>(At);
-                for (int r = tid >> 4; r < rows; r += kBT / 16) v4[r * (kQStride / 4) + (tid & 15)] = make_uint4(0u, 0u, 0u, 0u);
+            {   // zero the weight tile; stage the grad_out tile transposed
+                uint2 *v2 = reinterpret_cast<uint2 *>(At);
+                for (int r = tid >> 5; r < rows; r += kBT / 32) v2[r * (RS / 2) + (tid & 31)] = make_uint2(0u, 0u);
+                if (stager) {
+                    const uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        gT[(vc * 8 + 2 * i) * GTS + vq] = (uint16_t)(w[i] & 0xffffu);
+                        gT[(vc * 8 + 2 * i + 1) * GTS + vq] = (uint16_t)(w[i] >> 16);
+                    }
+                }
             }
             __syncthreads();
             PROF(1);
-            for (int pass = 0; pass < passes; ++pass) {
-                if (tid < kTileQ * 4) {
-                    SampleRec rc;
-                    rc.pix[0] = rc.pix[1] = rc.pix[2] = rc.pix[3] = -1;
-                    rc.w[0] = rc.w[1] = rc.w[2] = rc.w[3] = 0.f;
-                    const int q = q0 + sq, p = pass * 4 + sp;
-                    if (q < d.Nq && p < d.P) {
-                        const int64_t s = ((((int64_t)b * d.Nq + q) * d.H + h) * d.L + level) * d.P + p;
-                        float l[Vec16<T>::N];
-                        Vec16<T>::unpack(make_uint4((uint32_t)loc1[2 * s] | ((uint32_t)loc1[2 * s + 1] << 16),
-                                                    (uint32_t)attn1[s], 0u, 0u), l);      // {x, y, a, -}
-                        const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
-                        const float gy = 1.f - tp.fy, gx = 1.f - tp.fx, a = l[2];
-                        rc.pix[0] = tp.row[0]; rc.pix[1] = tp.row[1]; rc.pix[2] = tp.row[2]; rc.pix[3] = tp.row[3];
-                        rc.w[0] = gy * gx * a; rc.w[1] = gy * tp.fx * a; rc.w[2] = tp.fy * gx * a; rc.w[3] = tp.fy * tp.fx * a;
+#pragma unroll
+            for (int pass = 0; pass < MAXPASS; ++pass) {
+                if (pass < passes) {
+                    if (maker) {
+                        SampleRec rc;
+                        rc.pix[0] = rc.pix[1] = rc.pix[2] = rc.pix[3] = -1;
+                        rc.w[0] = rc.w[1] = rc.w[2] = rc.w[3] = 0.f;
+                        if (q0 + sq < d.Nq && pass * 4 + sp < d.P) {
+                            float l[Vec16<T>::N];
+                            Vec16<T>::unpack(make_uint4(sxy[pass], sa[pass], 0u, 0u), l);     // {x, y, a, -}
+                            const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
+                            const float gy = 1.f - tp.fy, gx = 1.f - tp.fx, a = l[2];
+                            rc.pix[0] = tp.row[0]; rc.pix[1] = tp.row[1]; rc.pix[2] = tp.row[2]; rc.pix[3] = tp.row[3];
+                            rc.w[0] = gy * gx * a; rc.w[1] = gy * tp.fx * a; rc.w[2] = tp.fy * gx * a; rc.w[3] = tp.fy * tp.fx * a;
+                        }
+                        rec[tid] = rc;
                     }
-                    rec[tid] = rc;
-                }
-                __syncthreads();
-                PROF(2);
+                    __syncthreads();
+                    PROF(2);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const SampleRec rc = rec[aq * 4 + k];
+                    for (int k = 0; k < 4; ++k) {
+                        const SampleRec rc = rec[aq * 4 + k];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (rc.pix[c] >= 0 && (rc.pix[c] & 15) == aj) At[rc.pix[c] * kQStride + aq] += rc.w[c];
+                        for (int c = 0; c < 4; ++c)
+                            if (rc.pix[c] >= 0 && (rc.pix[c] & 15) == aj) At[rc.pix[c] * RS + aq] += rc.w[c];
+                    }
+                    __syncthreads();
+                    PROF(3);
                 }
-                __syncthreads();
-                PROF(3);
             }
-            {   // split {hi, lo} in place
-                uint4 *v4 = reinterpret_cast<uint4 *>(At);
-                for (int r = tid >> 4; r < rows; r += kBT / 16) {
-                    uint4 x = v4[r * (kQStride / 4) + (tid & 15)];
-                    x.x = Mma<T>::split(__uint_as_float(x.x)); x.y = Mma<T>::split(__uint_as_float(x.y));
-                    x.z = Mma<T>::split(__uint_as_float(x.z)); x.w = Mma<T>::split(__uint_as_float(x.w));
-                    v4[r * (kQStride / 4) + (tid & 15)] = x;
+            {   // split: fp32 row -> [hi x 64 | lo x 64], in place (every thread reads its words first)
+                uint2 *v2 = reinterpret_cast<uint2 *>(At);
+                const int c = tid & 15;             // 4 queries
+                uint2 hi[4], lo[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = (tid >> 4) + it * (kBT / 16);
+                    hi[it] = lo[it] = make_uint2(0u, 0u);
+                    if (r < rows) {
+                        const uint2 x0 = v2[r * (RS / 2) + 2 * c], x1 = v2[r * (RS / 2) + 2 * c + 1];
+                        uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                        split_hi_lo<T>(__uint_as_float(x0.x), h0, l0); split_hi_lo<T>(__uint_as_float(x0.y), h1, l1);
+                        split_hi_lo<T>(__uint_as_float(x1.x), h2, l2); split_hi_lo<T>(__uint_as_float(x1.y), h3, l3);
+                        hi[it] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        lo[it] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = (tid >> 4) + it * (kBT / 16);
+                    if (r < rows) {
+                        v2[r * (RS / 2) + c] = hi[it];
+                        v2[r * (RS / 2) + 16 + c] = lo[it];
+                    }
                 }
             }
             __syncthreads();
             PROF(4);
             // (waves without a pixel block in this level multiply zero / foreign rows: never stored)
+            {
+                const uint2 *v2 = reinterpret_cast<const uint2 *>(At);
+                const uint2 *g2 = reinterpret_cast<const uint2 *>(gT + (ns * 32 + l32) * GTS);
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                uint32_t w[4];
+                for (int qb = 0; qb < QB; ++qb) {
+                    const uint2 g = g2[qb * 2 + kg];
+                    const uint4 bfrag = make_uint4(g.x, g.y, g.x, g.y);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t e = g[qb % (QB / 2)][i];
-                    w[i] = e | (e << 16);                                    // every element twice: meets {hi, lo}
-                    if (qb < QB / 2)
-                        g[qb][i] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
-                            go_rsrc, (int)(go_lane + (uint32_t)q0 * go_row),
-                            (int)((uint32_t)((qb + QB / 2) * 8 + i) * go_row), 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        const int pb = min(pb0 + j * PBSTEP, kCoarseMaxPx / 32 - 1);
+                        const uint2 ah = v2[(pb * 32 + l32) * (RS / 2) + qb * 2 + kg];
+                        const uint2 al = v2[(pb * 32 + l32) * (RS / 2) + 16 + qb * 2 + kg];
+                        acc[j] = Mma<T>::run(make_uint4(ah.x, ah.y, al.x, al.y), bfrag, acc[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads next to their products
                 }
-                const uint4 bfrag = make_uint4(w[0], w[1], w[2], w[3]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int pb = min(pb0 + j * PBSTEP, kCoarseMaxPx / 32 - 1);
-                    const uint4 afrag = *reinterpret_cast<const uint4 *>(&At[(pb * 32 + l32) * kQStride + qb * 8 + kg * 4]);
-                    acc[j] = Mma<T>::run(afrag, bfrag, acc[j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);          // keep the fragment reads next to their products
             }
             PROF(5);
             PROF_END(8 + (ci == 0 ? 0 : 8));
@@ -653,8 +715,8 @@ coarse_value_epilogue(const float *__restrict__ partial, T *__restrict__ grad_va
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
-int tile_chunks(const Dims &d);
-int value_chunks(const Dims &d, const CoarsePlan &) { return tile_chunks(d); }
+int tile_chunks(const Dims &d, int tile_q, int target);
+int value_chunks(const Dims &d, const CoarsePlan &) { return tile_chunks(d, kTileQ, 256); }
 
 // samples per (query, level) as whole vectors?  (P = 4 or 8, 16-byte aligned tensors)
 inline int sample_vectors(const void *loc, const void *attn, const Dims &d)
@@ -683,26 +745,30 @@ hipError_t launch_fwd_coarse(const void *value, const void *loc, const void *att
     return hipGetLastError();
 }
 
-// chunks of query tiles per (b, h): one 1024-lane workgroup per CU and then some
-int tile_chunks(const Dims &d)
+// chunks of query tiles per (b, h) so that about ``target`` workgroups exist
+int tile_chunks(const Dims &d, int tile_q = kTileQ, int target = 256)
 {
-    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int q_tiles = (d.Nq + tile_q - 1) / tile_q;
     const int64_t slices = (int64_t)d.B * d.H;
-    const int64_t want = (256 + slices - 1) / slices;
+    const int64_t want = (target + slices - 1) / slices;
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, q_tiles));
 }
 
+#ifndef MMFS_TAPS_MB
+#define MMFS_TAPS_MB 2
+#endif
 template <typename T, int NS>
 hipError_t launch_taps_coarse(const void *value, const void *loc, const void *attn, const void *go,
                               void *gl, void *ga, const Dims &d, const CoarsePlan &cp, hipStream_t st)
 {
+    constexpr int MB = MMFS_TAPS_MB;                // 2: 64-query tiles, 1024 lanes, one workgroup per CU (59 us at cfg2); 1: 68 us
     if (d.P > 16) return hipErrorInvalidValue;
-    const int chunks = tile_chunks(d);
-    const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
+    const int chunks = tile_chunks(d, 32 * MB, MB == 1 ? 768 : 256);
+    const int q_tiles = (d.Nq + 32 * MB - 1) / (32 * MB);
     const int tpc = (q_tiles + chunks - 1) / chunks;
     const int64_t blocks = (int64_t)d.B * d.H * chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_taps_coarse<T, NS>), dim3((unsigned)blocks), dim3(kBT), 0, st,
+    hipLaunchKernelGGL((msda_taps_coarse<T, NS, MB>), dim3((unsigned)blocks), dim3(512 * MB), 0, st,
                        (const T *)value, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga, d, cp,
                        chunks, tpc);
     return hipGetLastError();
