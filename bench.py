@@ -65,10 +65,18 @@ def algorithmic_bytes(w, e):
     bwd = e * (2 * B * S * C + 6 * pts + B * Nq * C)
     # the staged backward: each kernel priced on the tensors IT must touch once (scratch excluded)
     taps = e * (B * S * C + 6 * pts + B * Nq * C)       # value, loc, attn, grad_out -> grad_loc, grad_attn
+    # hybrid routing (csrc/msda_dense.hip): levels of <= min(256, 64 P) pixels get their grad_loc /
+    # grad_attn from dense dot products on the matrix cores, the others from the row-gather kernel
+    dense = [h * ww <= min(256, 64 * P) for h, ww in w["shapes"]] * w["n"]
+    Sd = sum(h * ww for (h, ww), dn in zip(w["shapes"] * w["n"], dense) if dn)
+    pts_d = B * Nq * H * sum(dense) * P
+    taps_dense = e * (B * Sd * C + 6 * pts_d + B * Nq * C)
+    taps_fine = e * (B * (S - Sd) * C + 6 * (pts - pts_d) + B * Nq * C)
     sort = e * 3 * pts                                  # loc, attn -> (scratch)
     red = e * (B * S * C + B * Nq * C)                  # grad_out -> grad_value
     return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value_sort=sort,
-                msda_bwd_value_reduce=red, fwdbwd=fwd + bwd)
+                msda_bwd_value_reduce=red, fwdbwd=fwd + bwd,
+                msda_bwd_taps_coarse=taps_dense, msda_bwd_taps_fine=taps_fine)
 
 
 def make_inputs(w, device, seed):
@@ -184,6 +192,8 @@ def main():
         for name, a, b in log:
             per_kernel.setdefault(name, []).append(a.elapsed_time(b))     # ms
         mean_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+        if "msda_bwd_taps_coarse" in mean_ms:          # the gather kernel then covers the other levels only
+            ab["msda_bwd_taps"] = ab["msda_bwd_taps_fine"]
         dom = max((k for k in mean_ms if k in ab), key=lambda k: mean_ms[k])
         achieved = ab[dom] / (mean_ms[dom] * 1e-3) / 1e9
         traffic = None

@@ -347,6 +347,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 status = _lib.mmfs_msda_backward_hybrid(*args, _HYB_BWD_ALL, stream)
             else:
                 for name, bit in _HYB_BWD_STAGES:
+                    if (bit == 2 and not flags & _BWD_DENSE_TAPS) or (bit == 32 and not flags & _BWD_DENSE_VALUE):
+                        continue
                     status = _launch(name, value.device, _lib.mmfs_msda_backward_hybrid, *args, bit, stream)
                     if status != 0:
                         break

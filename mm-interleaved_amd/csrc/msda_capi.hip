@@ -323,7 +323,7 @@ int mmfs_msda_forward_hybrid(int dtype, const void *value, const int64_t *shapes
     if (rc) return rc;
     if (B * Nq * H * D == 0 || d.K == 0 || S == 0) return MMFS_E_UNSUPPORTED;     // use mmfs_msda_forward
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    if (!plan.active) return MMFS_E_UNSUPPORTED;
+    if (!plan.coarse_active) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !out) return MMFS_E_NULLPTR;
     if (misaligned(value, 16) || misaligned(out, 16) || misaligned(loc, es) || misaligned(attn, es))
         return MMFS_E_ALIGN;
@@ -347,11 +347,12 @@ int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host
     mmfs::Dims d;
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
-    if (!(flags & (MMFS_BWD_DENSE_TAPS | MMFS_BWD_DENSE_VALUE))) return 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    if (!plan.active) return 0;
+    const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
+    const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;
+    if (!dense_taps && !dense_value) return 0;
     const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    return base + ((flags & MMFS_BWD_DENSE_VALUE) ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0);
+    return base + (dense_value ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0);
 }
 
 int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
@@ -368,10 +369,10 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
     if (rc) return rc;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
-    const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) != 0, dense_value = (flags & MMFS_BWD_DENSE_VALUE) != 0;
-    if (!dense_taps && !dense_value) return MMFS_E_UNSUPPORTED;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    if (!plan.active) return MMFS_E_UNSUPPORTED;
+    const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
+    const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;
+    if (!dense_taps && !dense_value) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
         return MMFS_E_NULLPTR;
     if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||
@@ -386,7 +387,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     hipError_t e = hipSuccess;
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE))
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
-                                d, false, st, dense_taps ? &plan.fine : nullptr);
+                                d, false, st, dense_taps ? &plan.fine_taps : nullptr);
     if (e == hipSuccess && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
         e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))

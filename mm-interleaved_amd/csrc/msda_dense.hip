@@ -340,7 +340,7 @@ template <typename T, int NS, int MB>
 __global__ void __launch_bounds__(MB * 512)
 msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ attn,
                  const T *__restrict__ grad_out, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
-                 const Dims d, const CoarsePlan cp, const int chunks, const int tiles_per_chunk)
+                 const Dims d, const DotPlan cp, const int chunks, const int tiles_per_chunk)
 {
     constexpr int KB = 2 * NS;                      // 16-channel steps
     constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row (D / 8)
@@ -390,19 +390,20 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
     PROF_DECL;
     uint32_t nxy = 0, na = 0;
     if (stager) gtile[0][vq * GS + vc] = go_vector(t_begin);
-    sample_load(t_begin, uni(cp.lv[0].level), nxy, na);
+    sample_load(t_begin, uni(cp.c[0].level), nxy, na);
     __syncthreads();
     int cur = 0;
     for (int ci = 0; ci < cp.n; ++ci) {
-        const int level = uni(cp.lv[ci].level), Hl = uni(cp.lv[ci].Hl), Wl = uni(cp.lv[ci].Wl);
-        const int lstart = uni(cp.lv[ci].start);
-        const int px = Hl * Wl, NB = (px + 31) / 32;
-        const int next_level = uni(cp.lv[min(ci + 1, cp.n - 1)].level);
-        const bool prod = nbw < NB;                 // this wave has a pixel block in this level
+        const int level = uni(cp.c[ci].level), Hl = uni(cp.c[ci].Hl), Wl = uni(cp.c[ci].Wl);
+        const int row0 = uni(cp.c[ci].row0), own0 = uni(cp.c[ci].own0), own1 = uni(cp.c[ci].own1);
+        const int px = uni(cp.c[ci].nrows) * Wl, NB = (px + 31) / 32;      // this chunk's pixels
+        const int first = uni(cp.c[ci].start) + row0 * Wl, pix0 = row0 * Wl;
+        const int next_level = uni(cp.c[min(ci + 1, cp.n - 1)].level);
+        const bool prod = nbw < NB;                 // this wave has a pixel block in this chunk
         uint4 bf[KB];
         if (prod) {
             const int pix = min(nbw * 32 + l32, px - 1);
-            const T *vp = value + ((int64_t)b * d.S + lstart + pix) * HD + (int64_t)h * d.D + kg * 8;
+            const T *vp = value + ((int64_t)b * d.S + first + pix) * HD + (int64_t)h * d.D + kg * 8;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) bf[kb] = *reinterpret_cast<const uint4 *>(vp + kb * 16);
         }
@@ -435,18 +436,24 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
                 Vec16<T>::unpack(make_uint4(sxy, sa, 0u, 0u), l);         // {x, y, a, -}
                 const float a = l[2];
                 const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
-                const float *g = G + iq * kAStride;
-                float dot[4];
+                // the chunk that owns the sample's top row finishes it (same arithmetic as locate)
+                const float yy = l[1] * (float)Hl - 0.5f, xx = l[0] * (float)Wl - 0.5f;
+                const bool inside = (yy > -1.f) && (xx > -1.f) && (yy < (float)Hl) && (xx < (float)Wl);
+                const int y0 = inside ? (int)floorf(yy) : -1;
+                if (y0 >= own0 && y0 < own1) {
+                    const float *g = G + iq * kAStride - pix0;
+                    float dot[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) dot[c] = tp.row[c] >= 0 ? g[tp.row[c]] : 0.f;
-                const float fx = tp.fx, fy = tp.fy, gy = 1.f - fy, gx = 1.f - fx;
-                const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
-                const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
-                const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
-                const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
-                grad_attn[s] = (T)ga;
-                grad_loc[2 * s] = (T)((float)Wl * dw * a);
-                grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
+                    for (int c = 0; c < 4; ++c) dot[c] = tp.row[c] >= 0 ? g[tp.row[c]] : 0.f;
+                    const float fx = tp.fx, fy = tp.fy, gy = 1.f - fy, gx = 1.f - fx;
+                    const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+                    const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
+                    const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
+                    const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
+                    grad_attn[s] = (T)ga;
+                    grad_loc[2 * s] = (T)((float)Wl * dw * a);
+                    grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
+                }
             }
             PROF(3);
             __syncthreads();
@@ -759,7 +766,7 @@ int tile_chunks(const Dims &d, int tile_q = kTileQ, int target = 256)
 #endif
 template <typename T, int NS>
 hipError_t launch_taps_coarse(const void *value, const void *loc, const void *attn, const void *go,
-                              void *gl, void *ga, const Dims &d, const CoarsePlan &cp, hipStream_t st)
+                              void *gl, void *ga, const Dims &d, const DotPlan &cp, hipStream_t st)
 {
     constexpr int MB = MMFS_TAPS_MB;                // 2: 64-query tiles, 1024 lanes, one workgroup per CU (59 us at cfg2); 1: 68 us
     if (d.P > 16) return hipErrorInvalidValue;
@@ -814,8 +821,9 @@ hipError_t launch_value_coarse(const void *loc, const void *attn, const void *go
 HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes, const int64_t *host_start)
 {
     HybridPlan p;
-    p.active = false;
-    p.fine.n = -1;
+    p.active = p.dots_active = p.coarse_active = false;
+    p.fine.n = p.fine_taps.n = -1;
+    p.dots.n = 0;
     p.coarse.n = 0;
     p.coarse.ktot = 0;
     p.coarse_mask = 0;
@@ -825,8 +833,46 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
     if (d.L <= 0 || d.L > kMaxSelLevels || d.P <= 0 || d.P > 16 || d.Nq < 32) return p;
     if ((int64_t)d.Nq * d.H * d.D * 2 > kMaxSlabBytes) return p;           // grad_out rows by 32-bit offsets
     if (const char *e = getenv("MMFS_HYBRID")) if (atoi(e) == 0) return p;
-    // a level pays off densely while its pixel count (MFMA work per query) stays below the row
-    // reads it replaces: K/4 MFMA clocks against 16*P row clocks per query at D = 128
+
+    // ---- grad_loc / grad_attn by dense dot products.  Per 64 queries a level costs px * D / 31.8
+    // MFMA clocks (1017 FLOP/clk/SIMD) against 8 * P * D clocks of row reads (64 B/clk/CU): on
+    // paper dense pays below ~254 * P pixels (190 * P with room for the look-ups).  Levels above 256
+    // pixels can be walked in chunks of whole rows that share one row (see DotChunk).
+    int nft = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const int64_t Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1], st = host_start[l];
+        const int64_t px = Hl * Wl;
+        bool dense = Hl > 0 && Wl > 0 && Wl <= kCoarseMaxPx / 2 && Hl < 32768 && st >= 0 && st + px <= d.S;
+        int R = 0, step = 0, chunks = 0;
+        if (dense) {
+            R = (int)std::min<int64_t>(Hl, kCoarseMaxPx / Wl);            // pixel rows per chunk
+            step = R >= Hl ? (int)Hl : R - 1;                               // rows a chunk owns
+            chunks = R >= Hl ? 1 : (int)((Hl - 1 + step - 1) / step);
+            const int64_t px_eff = (int64_t)chunks * R * Wl;                // pixels multiplied, overlap included
+            dense = px_eff <= 190LL * d.P && p.dots.n + chunks <= kMaxDotChunks;
+            // Measured (MI355X): a chunk step costs ~4k clocks per 64 queries, 4x its
+            // MFMA time, so only single-chunk levels (<= 256 pixels) beat their row reads; 32x32 levels
+            // in 5 chunks ran 1.6x slower than gathering them.  MMFS_DOT_CHUNKS=1 re-enables them.
+            static const bool multi = getenv("MMFS_DOT_CHUNKS") && atoi(getenv("MMFS_DOT_CHUNKS")) > 0;
+            if (chunks > 1 && !multi) dense = false;
+        }
+        if (!dense) { p.fine_taps.idx[nft++] = (uint8_t)l; continue; }
+        for (int c = 0; c < chunks; ++c) {
+            DotChunk &k = p.dots.c[p.dots.n++];
+            k.level = l; k.Hl = (int)Hl; k.Wl = (int)Wl; k.start = (int)st;
+            k.row0 = c * step;
+            k.nrows = (int)std::min<int64_t>(R, Hl - k.row0);
+            k.own0 = c == 0 ? -1 : k.row0;
+            k.own1 = c + 1 == chunks ? (int)Hl : k.row0 + step;
+        }
+    }
+    if (p.dots.n > 0) {
+        for (int i = nft; i < kMaxSelLevels; ++i) p.fine_taps.idx[i] = 0;
+        p.fine_taps.n = nft;
+        p.dots_active = true;
+    }
+
+    // ---- forward / grad_value (experimental): whole levels of <= min(256, 64 * P) pixels
     const int64_t max_px = std::min<int64_t>(kCoarseMaxPx, 64LL * d.P);
     int nf = 0;
     for (int l = 0; l < d.L; ++l) {
@@ -844,16 +890,18 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
             p.fine.idx[nf++] = (uint8_t)l;
         }
     }
-    if (p.coarse.n == 0) { p.fine.n = -1; return p; }
-    for (int i = nf; i < kMaxSelLevels; ++i) p.fine.idx[i] = 0;
-    p.fine.n = nf;
-    p.active = true;
+    if (p.coarse.n > 0) {
+        for (int i = nf; i < kMaxSelLevels; ++i) p.fine.idx[i] = 0;
+        p.fine.n = nf;
+        p.coarse_active = true;
+    }
+    p.active = p.dots_active || p.coarse_active;
     return p;
 }
 
 int64_t hybrid_fwd_workspace_bytes(int dtype, const Dims &d, const HybridPlan &p)
 {
-    if (!p.active) return 0;
+    if (!p.coarse_active) return 0;
     const int64_t es = 2;
     return up256((int64_t)d.B * d.H * p.coarse.ktot * d.D * es) + up256((int64_t)d.B * d.Nq * d.H * d.D * 4);
 }
@@ -866,7 +914,7 @@ const float *hybrid_fwd_init(void *workspace, const Dims &d, const HybridPlan &p
 hipError_t forward_coarse(int dtype, const void *value, const void *loc, const void *attn, void *workspace,
                           const Dims &d, const HybridPlan &p, hipStream_t st)
 {
-    if (!p.active) return hipErrorInvalidValue;
+    if (!p.coarse_active) return hipErrorInvalidValue;
     MMFS_DENSE_DISPATCH(launch_fwd_coarse, value, loc, attn, workspace, d, p.coarse, st);
 }
 
@@ -874,13 +922,13 @@ hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, c
                                 const void *grad_out, void *grad_loc, void *grad_attn, const Dims &d,
                                 const HybridPlan &p, hipStream_t st)
 {
-    if (!p.active) return hipErrorInvalidValue;
-    MMFS_DENSE_DISPATCH(launch_taps_coarse, value, loc, attn, grad_out, grad_loc, grad_attn, d, p.coarse, st);
+    if (!p.dots_active) return hipErrorInvalidValue;
+    MMFS_DENSE_DISPATCH(launch_taps_coarse, value, loc, attn, grad_out, grad_loc, grad_attn, d, p.dots, st);
 }
 
 int64_t hybrid_bwd_partial_bytes(const Dims &d, const HybridPlan &p)
 {
-    if (!p.active) return 0;
+    if (!p.coarse_active) return 0;
     return up256((int64_t)value_chunks(d, p.coarse) * d.B * d.H * p.coarse.ktot * d.D * 4);
 }
 
@@ -888,7 +936,7 @@ hipError_t backward_value_coarse(int dtype, const void *loc, const void *attn, c
                                  void *grad_value, void *partial, const Dims &d, const HybridPlan &p,
                                  hipStream_t st)
 {
-    if (!p.active) return hipErrorInvalidValue;
+    if (!p.coarse_active) return hipErrorInvalidValue;
     MMFS_DENSE_DISPATCH(launch_value_coarse, loc, attn, grad_out, grad_value, partial, d, p.coarse, st);
 }
 

@@ -166,6 +166,23 @@ struct CoarsePlan {
     CoarseLevel lv[kMaxCoarse];
 };
 
+// Dense dot products for grad_loc / grad_attn (msda_taps_coarse): a level is walked in chunks of
+// whole pixel rows, at most 256 pixels each, consecutive chunks sharing one row, so that every
+// sample's 2x2 footprint lies inside the chunk that owns its top row.
+constexpr int kMaxDotChunks = 48;
+
+struct DotChunk {
+    int level, Hl, Wl, start;          // the level (index in the table, extent, first pixel on the S axis)
+    int row0, nrows;                   // pixel rows [row0, row0 + nrows) of the level; nrows * Wl <= 256
+    int own0, own1;                    // finishes the samples whose top row y0 is in [own0, own1); own0 = -1
+                                       // also takes the samples outside the map (all-zero gradients)
+};
+
+struct DotPlan {
+    int n;
+    DotChunk c[kMaxDotChunks];
+};
+
 // Workgroup -> (b, h, first query).  Blocks are dealt to XCDs round-robin
 // (block i -> XCD i % 8, observed, MI355X_MICROARCH.md "Workgroup dispatch"), so
 // taking h = block % H pins every head's value slice [S, D] of a sample to one

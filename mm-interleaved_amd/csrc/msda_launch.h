@@ -48,8 +48,14 @@ hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t 
 // Hybrid path: levels of <= 256 pixels as dense MFMA products, the rest through the gather
 // kernels above restricted to plan.fine.                   [msda_dense.hip]
 struct HybridPlan {
-    bool active;
-    LevelSel fine;            // levels left to the gather kernels
+    bool active;              // some part has a dense level
+    // grad_loc / grad_attn: dense dot products, levels chunked by pixel rows
+    bool dots_active;
+    DotPlan dots;
+    LevelSel fine_taps;       // levels left to msda_bwd_vec
+    // forward / grad_value (experimental, whole levels of <= 256 pixels)
+    bool coarse_active;
+    LevelSel fine;            // levels left to the gather / sort+reduce kernels
     CoarsePlan coarse;        // dense levels
     uint64_t coarse_mask;     // bit l set: level l is dense
 };

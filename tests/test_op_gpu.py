@@ -103,6 +103,51 @@ def test_hip_matches_oracle_seeded(case, dtype):
     check(run_hip(x, dtype), run_oracle(x), dtype, str(case[:5]))
 
 
+HYBRID_CASES = [
+    # B, H, D, Nq, P, shapes: levels of <= 256 pixels go to the matrix cores (csrc/msda_dense.hip)
+    (2, 4, 128, 200, 4, [(16, 16), (8, 8), (20, 20), (5, 7)]),     # dense + gathered levels mixed, ragged tile
+    (2, 3, 64, 333, 8, [(32, 32), (16, 16), (8, 8)] * 2),          # LLM geometry, two images, P = 8 (two record passes)
+    (1, 2, 32, 130, 4, [(16, 16), (3, 3)]),                        # every level dense, D = 32 (idle waves)
+    (1, 8, 128, 64, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),    # the north-star pyramid, one full tile
+    (1, 2, 64, 97, 16, [(1, 1), (2, 9), (16, 16)]),                # P = 16, degenerate levels
+]
+
+
+@pytest.mark.parametrize("parts", ["taps", "value", "fwd", "fwd,taps,value"])
+@pytest.mark.parametrize("case", HYBRID_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in HYBRID_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hybrid_dense_levels_match_oracle(case, dtype, parts, monkeypatch):
+    """Every part of the hybrid path (dense dot products for grad_loc / grad_attn -- the default --
+    and the opt-in dense forward / grad_value) against the oracle, same bars as the plain kernels."""
+    import MultiScaleDeformableAttention as MSDA
+    monkeypatch.setattr(MSDA, "_hybrid", True)
+    monkeypatch.setattr(MSDA, "_hybrid_parts", set(parts.split(",")))
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=11, loc_range=(-0.15, 1.15), dtype=dtype)
+    x["loc"][0, 3, 0, 0, 0, 0] = float("nan")          # non-finite locations contribute nothing
+    x["loc"][0, 5, 1 % H, -1, 0, 1] = float("inf")
+    log = []
+    monkeypatch.setattr(MSDA, "_event_log", log)
+    got = run_hip(x, dtype, use_autograd=False)
+    monkeypatch.setattr(MSDA, "_event_log", None)
+    names = {n for n, _, _ in log}
+    for part, kernel in (("taps", "msda_bwd_taps_coarse"), ("value", "msda_bwd_value_coarse"), ("fwd", "msda_fwd_coarse")):
+        assert (kernel in names) == (part in parts.split(",")), (parts, names)
+    check(got, run_oracle(x), dtype, f"hybrid[{parts}] {case[:5]}")
+
+
+def test_hybrid_off_uses_plain_kernels(monkeypatch):
+    import MultiScaleDeformableAttention as MSDA
+    monkeypatch.setattr(MSDA, "_hybrid", False)
+    x = make_inputs(2, 4, 128, 200, 4, [(16, 16), (8, 8)], seed=2, dtype=torch.bfloat16)
+    log = []
+    monkeypatch.setattr(MSDA, "_event_log", log)
+    got = run_hip(x, torch.bfloat16, use_autograd=False)
+    monkeypatch.setattr(MSDA, "_event_log", None)
+    assert not any("coarse" in n for n, _, _ in log)
+    check(got, run_oracle(x), torch.bfloat16, "hybrid off")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CASES[:5], ids=[str(i) for i in range(5)])
 def test_atomic_backward_path_matches_oracle(case, dtype, monkeypatch):
