@@ -232,6 +232,48 @@ _hybrid = os.environ.get("MMFS_HYBRID", "1") != "0"
 # trip of the output through HBM and the dense grad_value kernel is not yet faster than sort+reduce.
 _hybrid_parts = set(x for x in os.environ.get("MMFS_HYBRID_PARTS", "taps").split(",") if x)
 
+# The backward's two halves are independent (grad_loc / grad_attn read value; grad_value does not)
+# and can be launched on two streams (a side stream that forks from and joins the caller's stream
+# inside the call).  Measured on MI355X: both halves already fill the chip, so they mostly
+# time-share: -1.2 % step time at the north-star shape, -3 % at the SD geometry, but +15 % at
+# config 1, where the step is host-bound and the extra stream calls cost more than they hide.
+# Off by default; MMFS_BWD_OVERLAP=1 turns it on.
+_bwd_overlap = os.environ.get("MMFS_BWD_OVERLAP", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _fork:
+    """with _fork(device) as side: launches inside go to the side stream (None: overlap off)."""
+
+    def __init__(self, device):
+        self.device, self.side, self.ctx = device, None, None
+
+    def __enter__(self):
+        if _bwd_overlap:
+            self.main = torch.cuda.current_stream(self.device)
+            self.side = _side_stream(self.device)
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
 # stage bits of the *_hybrid entry points (include/mmfs_msda.h)
 _HYB_FWD_COARSE, _HYB_FWD_FINE, _HYB_FWD_ALL = 1, 2, 3
 _HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
@@ -343,24 +385,35 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                     grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr(), hyb_bytes,
                     *dims, flags)
-            if _event_log is None:
-                status = _lib.mmfs_msda_backward_hybrid(*args, _HYB_BWD_ALL, stream)
-            else:
-                for name, bit in _HYB_BWD_STAGES:
+            def run_stages(stages):
+                st = 0
+                if _event_log is None:
+                    bits = sum(bit for _, bit in stages)
+                    return _lib.mmfs_msda_backward_hybrid(*args, bits, _stream(value.device))
+                for name, bit in stages:
                     if (bit == 2 and not flags & _BWD_DENSE_TAPS) or (bit == 32 and not flags & _BWD_DENSE_VALUE):
                         continue
-                    status = _launch(name, value.device, _lib.mmfs_msda_backward_hybrid, *args, bit, stream)
-                    if status != 0:
+                    st = _launch(name, value.device, _lib.mmfs_msda_backward_hybrid, *args, bit, _stream(value.device))
+                    if st != 0:
                         break
+                return st
+            fork = _fork(value.device)
+            with fork:
+                status = run_stages(_HYB_BWD_STAGES[:2])         # grad_loc / grad_attn (side stream)
+            if status == 0:
+                status = run_stages(_HYB_BWD_STAGES[2:])         # grad_value
+            fork.join()
         ws_bytes = 0 if hyb_bytes > 0 else _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
         if hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS):
             # pixel-stationary backward, stage by stage (so each kernel can be timed)
-            status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
-                             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-                             grad_loc.data_ptr(), grad_attn.data_ptr(), *dims, stream)
+            fork = _fork(value.device)
+            with fork:
+                status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
+                                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                 sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                 grad_loc.data_ptr(), grad_attn.data_ptr(), *dims, _stream(value.device))
             if status == 0:
                 status = _launch("msda_bwd_value_prepare", value.device, _lib.mmfs_msda_backward_value_prepare,
                                  code, sampling_loc.data_ptr(), attn_weight.data_ptr(), ws_ptr, ws_bytes,
@@ -373,6 +426,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 status = _launch("msda_bwd_value_reduce", value.device, _lib.mmfs_msda_backward_value_reduce,
                                  code, grad_output.data_ptr(), grad_value.data_ptr(), ws_ptr, ws_bytes,
                                  *dims, stream)
+            fork.join()
         if status == _E_UNSUPPORTED:
             # head width without a vector path, fp64, or a non-canonical level table:
             # the library's float-atomic path (needs an fp32 scratch for 16-bit storage)
