@@ -1,0 +1,626 @@
+// msda_bwd_block.hip -- grad_value of multi-scale deformable attention, block-stationary and
+// cell-sorted: the second generation of the pixel-stationary kernels in msda_bwd_value.hip.
+//
+// What bounds the pixel-stationary reduce is not HBM and not the 64 B/clk/CU L1 path but rows that
+// miss L1: random 256-byte rows out of an L2-resident region arrive at ~9.6 TB/s chip-wide
+// (tools/ubench/gather.hip), and every sample makes FOUR pixel owners read the same grad_out row.
+// Here the unit of the sort is the SAMPLE, keyed by the cell of its top-left corner, and the unit of
+// the reduce is a 2x2 pixel block:
+//
+//   * one 16-byte record {query, fy, fx, attention} per sample instead of four 8-byte {query,
+//     weight} records: a quarter of the LDS atomics and of the scattered stores of the sort
+//     (those stores, ~1.3 lanes/clk/CU, bound it), half the record bytes;
+//   * a lane group owns a 2x2 block of one level's pixels and walks the runs of the 9 cells whose
+//     footprints touch it: one grad_out row read per (sample, block) serves up to 4 pixels --
+//     on average 2.25 row reads per sample instead of 4;
+//   * the weights are the same products (wy * wx * attention) in the same order as before; only the
+//     order of the fp32 sums changes.  Every grad_value row still has exactly one owner and is
+//     written once in the storage type.
+//
+// Cells are indexed (y0 + 1, x0 + 1) with y0 in [-1, H-1], x0 in [-1, W-1]: (H+1)(W+1) per level.
+// Reference semantics as in msda_bwd_value.hip (ms_deform_im2col_cuda.cuh:128-155, cast at the end:
+// ms_deform_attn_cuda.cu:122-165).
+#include "msda_device.h"
+#include "msda_launch.h"
+#include <cstdlib>
+
+namespace mmfs {
+
+namespace {
+
+constexpr int kThreads = 1024;          // sort: 16 waves per workgroup
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxTileCells = 4096;     // cells per sort tile (two counter arrays of 16 KiB)
+constexpr int kScanUnroll = 4;
+constexpr int kMaxLevels = 128;         // level rows cached in LDS by the reduce
+
+struct CTile {
+    int level, Hl, Wl, cbase;           // cbase: the level's first entry in the cell table
+    int ya, yb, xa, xb;                 // cell coordinates [ya, yb) x [xa, xb)
+};
+
+struct LevelRow {
+    int Hl, Wl, lstart, cbase;
+    int bbase, nbx, nby, split;         // first (virtual) block index, blocks per row / column, lane groups per block
+};
+constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
+
+struct CellHeader {
+    int n_tiles, n_blocks, n_cells, L;
+    int pad[4];
+};
+
+// workspace table: CellHeader | LevelRow[L] | CTile[cap]
+__device__ __host__ inline LevelRow *level_rows(CellHeader *h) { return reinterpret_cast<LevelRow *>(h + 1); }
+__device__ __host__ inline const LevelRow *level_rows(const CellHeader *h) { return reinterpret_cast<const LevelRow *>(h + 1); }
+__device__ __host__ inline CTile *tiles_of(CellHeader *h, int L) { return reinterpret_cast<CTile *>(level_rows(h) + L); }
+__device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { return reinterpret_cast<const CTile *>(level_rows(h) + L); }
+
+// Lane groups per 2x2 block of a level: the block's list holds ~2.25 * Nq * P / blocks records
+// (every sample is visited by 2.25 blocks on average); aim at <= 128 records per lane group.
+__device__ __host__ inline int split_of(int64_t samples, int64_t blocks)
+{
+    const int64_t per_block = blocks > 0 ? (samples * 9 / 4 + blocks - 1) / blocks : 0;
+    int s = 1;
+    while (s < kMaxSplit && per_block > 128LL * s) s <<= 1;
+    return s;
+}
+
+__global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                  int L, int nt_min, int cap, int64_t samples_per_level,
+                                  CellHeader *__restrict__ hdr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LevelRow *lv = level_rows(hdr);
+    CTile *tile = tiles_of(hdr, L);
+    int n = 0, cbase = 0, bbase = 0;
+    for (int l = 0; l < L; ++l) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        LevelRow r;
+        r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l]; r.cbase = cbase; r.bbase = bbase;
+        r.nbx = (Wl + 1) / 2; r.nby = (Hl + 1) / 2; r.split = 1;
+        if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = 0; lv[l] = r; continue; }
+        r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
+        lv[l] = r;
+        const int Hc = Hl + 1, Wc = Wl + 1, cells = Hc * Wc;
+        int nt = max(nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
+        nt = min(nt, cells);
+        const int tc = (cells + nt - 1) / nt;
+        int R, C;
+        if (Wc <= tc) { R = tc / Wc; C = Wc; } else { R = 1; C = tc; }
+        for (int ya = 0; ya < Hc && n < cap; ya += R)
+            for (int xa = 0; xa < Wc && n < cap; xa += C) {
+                CTile t;
+                t.level = l; t.Hl = Hl; t.Wl = Wl; t.cbase = cbase;
+                t.ya = ya; t.yb = min(Hc, ya + R); t.xa = xa; t.xb = min(Wc, xa + C);
+                tile[n++] = t;
+            }
+        cbase += cells;
+        bbase += r.nbx * r.nby * r.split;
+        bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
+    }
+    hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
+}
+
+// Exclusive prefix sum over a[0..n) (n <= kMaxTileCells), total left in a[n].
+__device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
+{
+    constexpr int PER = kMaxTileCells / kThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t c[PER], v = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        c[i] = tid * PER + i < n ? a[tid * PER + i] : 0u;
+        v += c[i];
+    }
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    uint32_t run = base + inc - v;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (tid * PER + i < n) a[tid * PER + i] = run;
+        run += c[i];
+    }
+    if (tid == kThreads - 1) a[n] = run;
+    __syncthreads();
+}
+
+enum ScanMode { kCount = 0, kScatter = 1 };
+
+// One sample against the tile: if its top-left cell is in the tile
+//   kCount  : off[cell] += 1
+//   kScatter: list[off[cell] + cur[cell]++] = {q, fy, fx, attention}
+template <int MODE>
+__device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q, const CTile &tl, int tw,
+                                             uint32_t *off, uint32_t *cur, uint4 *__restrict__ list)
+{
+    const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
+    const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
+    if (!inside) return;
+    const float yf = floorf(y), xf = floorf(x);
+    const int cy = (int)yf + 1, cx = (int)xf + 1;
+    if (cy < tl.ya || cy >= tl.yb || cx < tl.xa || cx >= tl.xb) return;
+    const int pl = (cy - tl.ya) * tw + (cx - tl.xa);
+    if (MODE == kCount) {
+        atomicAdd(&off[pl], 1u);
+    } else {
+        const uint32_t slot = off[pl] + atomicAdd(&cur[pl], 1u);
+        list[slot] = make_uint4((uint32_t)q, __float_as_uint(y - yf), __float_as_uint(x - xf), __float_as_uint(a));
+    }
+}
+
+template <typename T, int MODE, int NV>
+__device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T *__restrict__ attn,
+                                             const Dims &d, const CTile &tl, int b, int h,
+                                             uint32_t *off, uint32_t *cur, uint4 *__restrict__ list)
+{
+    const int tw = tl.xb - tl.xa;
+    const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
+    if (NV == 0) {
+        for (int q = (int)threadIdx.x; q < d.Nq; q += kThreads) {
+            const int64_t s0 = s_first + (int64_t)q * d.P;
+            for (int p = 0; p < d.P; ++p)
+                visit_sample<MODE>(to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]),
+                                   MODE == kScatter ? to_f32(attn[s0 + p]) : 0.f, q, tl, tw, off, cur, list);
+        }
+        return;
+    }
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int NVV = NV > 0 ? NV : 1;
+    for (int q0 = (int)threadIdx.x; q0 < d.Nq; q0 += kThreads * kScanUnroll) {
+        uint4 lraw[kScanUnroll][NVV];
+        uint2 araw[kScanUnroll][NVV];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = q0 + u * kThreads;
+            const int64_t s0 = s_first + (int64_t)min(q, d.Nq - 1) * d.P;
+#pragma unroll
+            for (int v = 0; v < NVV; ++v) {
+                lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
+                if (MODE == kScatter) araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
+                else araw[u][v] = make_uint2(0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = q0 + u * kThreads;
+            if (q >= d.Nq) break;
+#pragma unroll
+            for (int v = 0; v < NVV; ++v) {
+                float l[VEC], a[VEC];
+                V::unpack(lraw[u][v], l);
+                V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
+#pragma unroll
+                for (int i = 0; i < VEC / 2; ++i)
+                    visit_sample<MODE>(l[2 * i], l[2 * i + 1], a[i], q, tl, tw, off, cur, list);
+            }
+        }
+    }
+}
+
+struct TileParams {
+    int tiles_bound;
+    int nt_min;
+};
+
+// ---------------------------------------------------------------- kernel A: sort by cell
+template <typename T, int NV>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 *__restrict__ records,
+                   uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
+                   const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride)
+{
+    __shared__ uint32_t off[kMaxTileCells + 1];
+    __shared__ uint32_t cur[kMaxTileCells];
+    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ uint32_t region;
+
+    const int bid = blockIdx.x;
+    const int h = bid % d.H;
+    const int t = (bid / d.H) % tp.tiles_bound;
+    const int b = (bid / d.H) / tp.tiles_bound;
+    if (t >= hdr->n_tiles) return;
+    const CTile tl = tiles_of(hdr, d.L)[t];
+
+    const int tid = threadIdx.x;
+    const int tw = tl.xb - tl.xa;
+    const int ncell = (tl.yb - tl.ya) * tw;
+
+    for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
+    __syncthreads();
+    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
+    __syncthreads();
+    block_exclusive_scan(off, ncell, wave_tot);
+    const uint32_t total = off[ncell];
+    // this tile's slice of the (b, h, level) record area: the level's tiles share Nq*P slots
+    const int64_t slot = ((int64_t)b * d.H + h) * d.L + tl.level;
+    if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
+    __syncthreads();
+    const int64_t base = slot * ((int64_t)d.Nq * d.P) + region;
+    if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, records + base);
+    uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + tl.cbase;
+    for (int p = tid; p < ncell; p += kThreads) {
+        const int cg = (tl.ya + p / tw) * (tl.Wl + 1) + tl.xa + p % tw;
+        tab[cg] = make_uint2((uint32_t)(base + off[p]), off[p + 1] - off[p]);
+    }
+}
+
+// ---------------------------------------------------------------- kernel B: reduce by 2x2 block
+constexpr int kRThreads = 256;
+#ifndef MMFS_BLK_WAVES
+#define MMFS_BLK_WAVES 3          // waves per SIMD the register allocation must leave room for
+#endif
+#ifndef MMFS_BLK_UNROLL
+#define MMFS_BLK_UNROLL 4
+#endif
+constexpr int kUnroll = MMFS_BLK_UNROLL;
+
+// The 9 runs of a block, seen as one list: run k holds [pre[k], pre[k+1]) of it.  Kept in LDS
+// (one per lane group; every group reads the others' in phase 2).
+struct BlockRuns {
+    uint32_t first[9];
+    int pre[10];
+    int pad;
+};
+
+struct BlkRec { uint32_t off; float w[4]; };      // row offset ("outside" past the end), weights of the 2x2 pixels
+
+// Record e of the block's list -> its grad_out row offset and the weights it adds to the block's
+// four pixels (zero where the corner is another block's).
+__device__ __forceinline__ BlkRec fetch_record(const uint4 *__restrict__ records, const BlockRuns *__restrict__ brp,
+                                               int e, int end, uint32_t row_bytes)
+{
+    BlkRec r;
+    r.off = kOobOffset; r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+    if (e < end) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 9; ++j) k += e >= brp->pre[j] ? 1 : 0;     // pre[] is non-decreasing
+        const int p = brp->pre[k];
+        const uint32_t f = brp->first[k];
+        const uint4 rec = records[f + (uint32_t)(e - p)];
+        const float fy = __uint_as_float(rec.y), fx = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+        const int dy = k / 3, dx = k - dy * 3;                     // the cell is (2by + dy, 2bx + dx): y0 = 2by + dy - 1
+        // block pixel row ry takes the sample's corner cy = ry - (dy - 1): weight 1-fy (cy = 0), fy (cy = 1)
+        const float wy0 = dy == 0 ? fy : (dy == 1 ? 1.f - fy : 0.f);
+        const float wy1 = dy == 1 ? fy : (dy == 2 ? 1.f - fy : 0.f);
+        const float wx0 = dx == 0 ? fx : (dx == 1 ? 1.f - fx : 0.f);
+        const float wx1 = dx == 1 ? fx : (dx == 2 ? 1.f - fx : 0.f);
+        r.off = rec.x * row_bytes;
+        r.w[0] = wy0 * wx0 * a; r.w[1] = wy0 * wx1 * a; r.w[2] = wy1 * wx0 * a; r.w[3] = wy1 * wx1 * a;
+    }
+    return r;
+}
+
+// acc[px][:] += sum over one batch of LPS records (every lane fetched one; all lanes of the group
+// read each row together: records go through the group's LDS slots -- the row offsets are read
+// when the rows are requested, the weights only when they are used).  Rows are requested kUnroll
+// at a time, one group of kUnroll ahead of the FMAs, in a ROLLED loop: unrolled over the whole
+// batch the compiler turns the sums into one chain per accumulator across all the rows and keeps
+// every row unpacked at once (208 VGPRs).
+template <typename T, int LPS, bool BUF>
+__device__ __forceinline__ void consume_batch(const BlkRec &mine, int lig, uint32_t *__restrict__ slot_off,
+                                              uint4 *__restrict__ slot_w, const T *__restrict__ gslice, int64_t HD,
+                                              __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
+                                              float (&acc)[4][Vec16<T>::N])
+{
+    typedef Vec16<T> V;
+    constexpr int U = LPS < kUnroll ? LPS : kUnroll;
+    slot_off[lig] = mine.off;
+    slot_w[lig] = make_uint4(__float_as_uint(mine.w[0]), __float_as_uint(mine.w[1]), __float_as_uint(mine.w[2]),
+                             __float_as_uint(mine.w[3]));
+    __builtin_amdgcn_wave_barrier();
+    auto request = [&](int u) {
+        const uint32_t off = slot_off[u];
+        if (BUF) return buffer_load16(rsrc, off + lane_off);
+        const bool ok = off != kOobOffset;
+        uint4 r = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? off / row_bytes : 0u) * HD);
+        if (!ok) r = make_uint4(0u, 0u, 0u, 0u);
+        return r;
+    };
+    uint4 cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cur[u] = request(u); nxt[u] = cur[u]; }
+#pragma unroll 1
+    for (int u0 = 0; u0 < LPS; u0 += U) {
+        if (u0 + U < LPS) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = request(u0 + U + u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4 ww = slot_w[u0 + u];
+            const float w[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
+            float g[V::N];
+            V::unpack(cur[u], g);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+#pragma unroll
+                for (int i = 0; i < V::N; ++i) acc[px][i] = fmaf(w[px], g[i], acc[px][i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int LPS, bool BUF>
+__global__ void __launch_bounds__(kRThreads, MMFS_BLK_WAVES)
+msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
+                      const uint4 *__restrict__ records, const uint2 *__restrict__ celltab,
+                      const CellHeader *__restrict__ hdr, const Dims d, const int chunks, const int cell_stride)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int GROUPS = kRThreads / LPS;          // lane groups per workgroup
+    constexpr int D = LPS * VEC;
+    static_assert(GROUPS % kMaxSplit == 0, "a block's lane groups must share a workgroup");
+    __shared__ LevelRow lvs[kMaxLevels];
+    __shared__ BlockRuns runs[GROUPS];
+    __shared__ float scratch[GROUPS * 4 * D];        // partial sums of split blocks
+    __shared__ uint32_t slots_off[GROUPS * (LPS + 1)];
+    __shared__ uint4 slots_w[GROUPS * (LPS + 1)];
+
+    const int bid = blockIdx.x;
+    const int h = bid % d.H;
+    const int chunk = (bid / d.H) % chunks;
+    const int b = (bid / d.H) / chunks;
+    const int tid = threadIdx.x;
+    const int gid = tid / LPS, lig = tid % LPS;
+    const int n_blocks = hdr->n_blocks;              // virtual blocks: block x split
+    if (chunk * GROUPS >= n_blocks) return;          // whole workgroup beyond the last block
+    for (int i = tid; i < d.L; i += kRThreads) lvs[i] = level_rows(hdr)[i];
+    __syncthreads();
+
+    uint32_t *slot = slots_off + gid * (LPS + 1);
+    uint4 *slot4 = slots_w + gid * (LPS + 1);
+    const int vb = chunk * GROUPS + gid;
+
+    // virtual block -> (level, block, part)
+    int l = 0;
+    while (l + 1 < d.L && vb >= lvs[l + 1].bbase) ++l;
+    const LevelRow lr = lvs[l];
+    const int rel = vb - lr.bbase;
+    const int split = lr.split;
+    const int blk = rel / split, part = rel - blk * split;
+    const bool act = vb < n_blocks && lr.nbx > 0 && blk < lr.nbx * lr.nby;      // (padding between levels: idle)
+    const int by = act ? blk / lr.nbx : 0, bx = act ? blk - by * lr.nbx : 0;
+
+    const int64_t HD = (int64_t)d.H * d.D;
+    const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    __amdgpu_buffer_rsrc_t rsrc;
+    if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
+                                   ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
+
+    // the 9 cell runs of the block, as one list (lane 0 of the group builds the prefix)
+    const uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + lr.cbase;
+    if (lig == 0) {
+        int run = 0;
+        runs[gid].pre[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            uint2 r = make_uint2(0u, 0u);
+            const int cy = 2 * by + k / 3, cx = 2 * bx + k % 3;
+            if (act && cy <= lr.Hl && cx <= lr.Wl) r = tab[cy * (lr.Wl + 1) + cx];
+            runs[gid].first[k] = r.x;
+            run += (int)r.y;
+            runs[gid].pre[k + 1] = run;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const BlockRuns *br = &runs[gid];
+    const int n = br->pre[9];
+
+    float acc[4][VEC];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
+
+    // this group's batches of the list: part, part + split, ...
+    const int batches = (n + LPS - 1) / LPS;
+    int nb = batches > part ? (batches - part + split - 1) / split : 0;
+#pragma unroll
+    for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));    // wave-uniform trip count
+    BlkRec pre = fetch_record(records, br, part * LPS + lig, n, row_bytes);
+    for (int j = 0; j < nb; ++j) {
+        const BlkRec cur_rec = pre;
+        if (j + 1 < nb) pre = fetch_record(records, br, (part + (j + 1) * split) * LPS + lig, n, row_bytes);
+        consume_batch<T, LPS, BUF>(cur_rec, lig, slot, slot4, gslice, HD, rsrc, row_bytes, lane_off, acc);
+    }
+    // split blocks: the parts meet in LDS, part 0 adds them up (uniform decision per workgroup is not
+    // possible -- levels may change inside a workgroup -- so every workgroup passes the two barriers)
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) scratch[(gid * 4 + px) * D + lig * VEC + i] = acc[px][i];
+    __syncthreads();
+    if (act && part == 0) {
+        for (int s2 = 1; s2 < split; ++s2) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[px][i] += scratch[((gid + s2) * 4 + px) * D + lig * VEC + i];
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int y = 2 * by + (px >> 1), x = 2 * bx + (px & 1);
+            if (y < lr.Hl && x < lr.Wl) {
+                T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + lig * VEC;
+                *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+            }
+        }
+    }
+}
+
+TileParams make_params(const Dims &d)
+{
+    TileParams tp;
+    const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
+    int64_t nt = std::max<int64_t>(1, (512 + slices - 1) / slices);
+    if (const char *e = getenv("MMFS_NT_MIN")) nt = std::max(1, atoi(e));
+    tp.nt_min = (int)std::min<int64_t>(nt, 256);
+    // cells per level <= 2 * pixels + 2; tiles per level <= 2 * nt_l + 1
+    const int64_t cells = 2LL * d.S + 2LL * d.L;
+    const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((cells + kMaxTileCells - 1) / kMaxTileCells) + d.L;
+    tp.tiles_bound = (int)std::min<int64_t>(bound, 0x3fffffff);
+    return tp;
+}
+
+int cell_stride_of(const Dims &d) { return 2 * d.S + 2 * d.L; }      // >= sum (H+1)(W+1)
+// >= sum over levels of blocks * split, each level padded to kMaxSplit:
+// blocks <= pixels + 1, and split * blocks <= blocks + 2 * (2.25 * Nq * P) / 128 + kMaxSplit
+int64_t block_bound_of(const Dims &d)
+{
+    return (int64_t)d.S + (int64_t)d.L * (2 * kMaxSplit + 2 + ((int64_t)d.Nq * d.P * 9 / 4) / 64);
+}
+
+struct Scratch {
+    char *loc_t, *attn_t;
+    uint32_t *cursor;
+    CellHeader *hdr;
+    uint2 *celltab;            // [B, H, cell_stride] {first record, count}
+    uint4 *records;            // [B, H, L, Nq*P] {query, fy, fx, attention}, cell-sorted inside each tile
+    int64_t cursor_bytes, total;
+};
+
+Scratch carve(void *workspace, int dtype, const Dims &d)
+{
+    const int64_t es = dtype == 0 ? 4 : 2;
+    const int64_t pts = (int64_t)d.B * d.Nq * d.H * d.L * d.P;
+    auto up = [](int64_t v) { return (v + 15) / 16 * 16; };
+    Scratch s;
+    char *p = (char *)workspace;
+    s.loc_t = p;                 p += up(pts * 2 * es);
+    s.attn_t = p;                p += up(pts * es);
+    s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.hdr = (CellHeader *)p;
+    p += up((int64_t)sizeof(CellHeader) + (int64_t)d.L * sizeof(LevelRow) + (int64_t)make_params(d).tiles_bound * sizeof(CTile));
+    s.celltab = (uint2 *)p;      p += up((int64_t)d.B * d.H * cell_stride_of(d) * 8);
+    s.records = (uint4 *)p;      p += up(pts * 16);
+    s.total = p - (char *)workspace;
+    return s;
+}
+
+template <typename T, int NV>
+hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, hipStream_t st)
+{
+    const TileParams tp = make_params(d);
+    const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
+    hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min, tp.tiles_bound,
+                       (int64_t)d.Nq * d.P, sc.hdr);
+    hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                       (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
+                       cell_stride_of(d));
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, hipStream_t st)
+{
+    const int loc_bytes = d.P * 2 * (int)sizeof(T);
+    int nv = 0;
+    if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
+    switch (nv) {
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, st);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, st);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, st);
+    }
+}
+
+template <typename T, int LPS>
+hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims &d, hipStream_t st)
+{
+    constexpr int GROUPS = kRThreads / LPS;
+    const int64_t chunks64 = (block_bound_of(d) + GROUPS - 1) / GROUPS;
+    if (chunks64 > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int chunks = (int)chunks64;
+    const int64_t blocks = (int64_t)d.B * d.H * chunks;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
+        hipLaunchKernelGGL((msda_bwd_block_reduce<T, LPS, true>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d));
+    else
+        hipLaunchKernelGGL((msda_bwd_block_reduce<T, LPS, false>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d));
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t dispatch_reduce(const Scratch &sc, const void *go, void *gv, const Dims &d, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    switch (d.D / VEC) {
+#define MMFS_CASE(n) case n: return launch_reduce<T, n>(sc, go, gv, d, st);
+        MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32)
+#undef MMFS_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// Block-stationary grad_value: same preconditions as the pixel-stationary kernels plus a level
+// count that fits the reduce's LDS table and lane groups of 4..32 lanes (D * sizeof(T) = 64..512 B).
+bool bwd_value_block_supported(int dtype, const Dims &d)
+{
+    if (!bwd_value_tiled_supported(dtype, d)) return false;
+    if (d.L > kMaxLevels) return false;
+    const int vec = dtype == 0 ? 4 : 8;
+    const int lps = d.D / vec;
+    if (lps < 4 || lps > 32) return false;
+    if (2LL * d.S + 2LL * d.L > 0x3fffffffLL) return false;
+    if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'p') return false;     // "pixel"
+    const TileParams tp = make_params(d);
+    return (int64_t)d.B * d.H * tp.tiles_bound <= 0x7fffffffLL;
+}
+
+int64_t bwd_value_block_workspace_bytes(int dtype, const Dims &d)
+{
+    return carve(nullptr, dtype, d).total;
+}
+
+// (the workspace starts with the same three pieces as the pixel-stationary layout -- re-packed
+// loc, re-packed attn, level cursors -- so backward_value_prepare serves both)
+
+hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
+                                     const Dims &d, hipStream_t st)
+{
+    if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
+    const Scratch sc = carve(workspace, dtype, d);
+    switch (dtype) {
+        case 0: return dispatch_sort<float>(shapes, start, sc, d, st);
+        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, st);
+        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
+                                       const Dims &d, hipStream_t st)
+{
+    if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
+    const Scratch sc = carve(workspace, dtype, d);
+    switch (dtype) {
+        case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);
+        case 1: return dispatch_reduce<half_t>(sc, grad_out, grad_value, d, st);
+        case 2: return dispatch_reduce<bf16_t>(sc, grad_out, grad_value, d, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mmfs

@@ -593,7 +593,8 @@ bool bwd_value_tiled_supported(int dtype, const Dims &d)
 
 int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d)
 {
-    return carve(nullptr, dtype, d).total;
+    // room for either generation (they share the leading pieces: re-packed loc / attn, cursors)
+    return std::max<int64_t>(carve(nullptr, dtype, d).total, bwd_value_block_workspace_bytes(dtype, d));
 }
 
 // Stage 2a: re-pack loc/attn into the workspace and clear the per-level cursors.
@@ -615,6 +616,8 @@ hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *
                                const Dims &d, hipStream_t st, uint64_t skip_levels)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
+    if (skip_levels == 0 && bwd_value_block_supported(dtype, d))
+        return backward_value_block_sort(dtype, shapes, start, workspace, d, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
         case 0: return dispatch_sort<float>(shapes, start, sc, d, skip_levels, st);
@@ -626,9 +629,11 @@ hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *
 
 // Stage 2c: reduce every pixel's run into its grad_value row.
 hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                 const Dims &d, hipStream_t st)
+                                 const Dims &d, hipStream_t st, uint64_t skip_levels)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
+    if (skip_levels == 0 && bwd_value_block_supported(dtype, d))      // must mirror backward_value_sort
+        return backward_value_block_reduce(dtype, grad_out, grad_value, workspace, d, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
         case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);

@@ -395,7 +395,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
         e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, dense_value ? plan.coarse_mask : 0);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
-        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
+        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, dense_value ? plan.coarse_mask : 0);
     if (e == hipSuccess && dense_value && (stages & MMFS_HYB_BWD_VALUE_COARSE))
         e = mmfs::backward_value_coarse(dtype, loc, attn, grad_out, grad_value, partial, d, plan, st);
     return (int)e;
