@@ -44,6 +44,16 @@ struct LevelRow {
     int bbase, nbx, nby, split;         // first (virtual) block index, blocks per row / column, lane groups per block
 };
 constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
+#ifndef MMFS_BLK_H
+#define MMFS_BLK_H 2
+#endif
+#ifndef MMFS_BLK_W
+#define MMFS_BLK_W 2
+#endif
+constexpr int kBH = MMFS_BLK_H, kBW = MMFS_BLK_W;      // pixels of a block (rows x columns)
+constexpr int kNC = (kBH + 1) * (kBW + 1);              // cells whose footprints touch a block
+constexpr int kNPX = kBH * kBW;
+static_assert(kNPX % 4 == 0, "block weights travel as 16-byte vectors");
 
 struct CellHeader {
     int n_tiles, n_blocks, n_cells, L;
@@ -56,11 +66,12 @@ __device__ __host__ inline const LevelRow *level_rows(const CellHeader *h) { ret
 __device__ __host__ inline CTile *tiles_of(CellHeader *h, int L) { return reinterpret_cast<CTile *>(level_rows(h) + L); }
 __device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { return reinterpret_cast<const CTile *>(level_rows(h) + L); }
 
-// Lane groups per 2x2 block of a level: the block's list holds ~2.25 * Nq * P / blocks records
-// (every sample is visited by 2.25 blocks on average); aim at <= 128 records per lane group.
+// Lane groups per block of a level: aim at <= 128 records of the block's list per lane group.
 __device__ __host__ inline int split_of(int64_t samples, int64_t blocks)
 {
-    const int64_t per_block = blocks > 0 ? (samples * 9 / 4 + blocks - 1) / blocks : 0;
+    // every sample is visited by (1 + 1/BH)(1 + 1/BW) blocks on average
+    const int64_t visits = samples * (kBH + 1) * (kBW + 1) / (kBH * kBW);
+    const int64_t per_block = blocks > 0 ? (visits + blocks - 1) / blocks : 0;
     int s = 1;
     while (s < kMaxSplit && per_block > 128LL * s) s <<= 1;
     return s;
@@ -78,7 +89,7 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         LevelRow r;
         r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l]; r.cbase = cbase; r.bbase = bbase;
-        r.nbx = (Wl + 1) / 2; r.nby = (Hl + 1) / 2; r.split = 1;
+        r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1;
         if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = 0; lv[l] = r; continue; }
         r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
         lv[l] = r;
@@ -267,12 +278,11 @@ constexpr int kUnroll = MMFS_BLK_UNROLL;
 // The 9 runs of a block, seen as one list: run k holds [pre[k], pre[k+1]) of it.  Kept in LDS
 // (one per lane group; every group reads the others' in phase 2).
 struct BlockRuns {
-    uint32_t first[9];
-    int pre[10];
-    int pad;
+    uint32_t first[kNC];
+    int pre[kNC + 1];
 };
 
-struct BlkRec { uint32_t off; float w[4]; };      // row offset ("outside" past the end), weights of the 2x2 pixels
+struct BlkRec { uint32_t off; float w[kNPX]; };   // row offset ("outside" past the end), weights of the block's pixels
 
 // Record e of the block's list -> its grad_out row offset and the weights it adds to the block's
 // four pixels (zero where the corner is another block's).
@@ -280,23 +290,30 @@ __device__ __forceinline__ BlkRec fetch_record(const uint4 *__restrict__ records
                                                int e, int end, uint32_t row_bytes)
 {
     BlkRec r;
-    r.off = kOobOffset; r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+    r.off = kOobOffset;
+#pragma unroll
+    for (int i = 0; i < kNPX; ++i) r.w[i] = 0.f;
     if (e < end) {
         int k = 0;
 #pragma unroll
-        for (int j = 1; j < 9; ++j) k += e >= brp->pre[j] ? 1 : 0;     // pre[] is non-decreasing
+        for (int j = 1; j < kNC; ++j) k += e >= brp->pre[j] ? 1 : 0;   // pre[] is non-decreasing
         const int p = brp->pre[k];
         const uint32_t f = brp->first[k];
         const uint4 rec = records[f + (uint32_t)(e - p)];
         const float fy = __uint_as_float(rec.y), fx = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
-        const int dy = k / 3, dx = k - dy * 3;                     // the cell is (2by + dy, 2bx + dx): y0 = 2by + dy - 1
-        // block pixel row ry takes the sample's corner cy = ry - (dy - 1): weight 1-fy (cy = 0), fy (cy = 1)
-        const float wy0 = dy == 0 ? fy : (dy == 1 ? 1.f - fy : 0.f);
-        const float wy1 = dy == 1 ? fy : (dy == 2 ? 1.f - fy : 0.f);
-        const float wx0 = dx == 0 ? fx : (dx == 1 ? 1.f - fx : 0.f);
-        const float wx1 = dx == 1 ? fx : (dx == 2 ? 1.f - fx : 0.f);
+        // the cell is (BH*by + dy, BW*bx + dx), i.e. the sample's top row is y0 = BH*by + dy - 1: block
+        // pixel row ry takes its corner cy = ry - (dy - 1), weight 1-fy for cy = 0, fy for cy = 1
+        const int dy = k / (kBW + 1), dx = k - dy * (kBW + 1);
+        float wy[kBH], wx[kBW];
+#pragma unroll
+        for (int ry = 0; ry < kBH; ++ry) wy[ry] = ry == dy - 1 ? 1.f - fy : (ry == dy ? fy : 0.f);
+#pragma unroll
+        for (int rx = 0; rx < kBW; ++rx) wx[rx] = rx == dx - 1 ? 1.f - fx : (rx == dx ? fx : 0.f);
         r.off = rec.x * row_bytes;
-        r.w[0] = wy0 * wx0 * a; r.w[1] = wy0 * wx1 * a; r.w[2] = wy1 * wx0 * a; r.w[3] = wy1 * wx1 * a;
+#pragma unroll
+        for (int ry = 0; ry < kBH; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < kBW; ++rx) r.w[ry * kBW + rx] = wy[ry] * wx[rx] * a;
     }
     return r;
 }
@@ -311,13 +328,16 @@ template <typename T, int LPS, bool BUF>
 __device__ __forceinline__ void consume_batch(const BlkRec &mine, int lig, uint32_t *__restrict__ slot_off,
                                               uint4 *__restrict__ slot_w, const T *__restrict__ gslice, int64_t HD,
                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t lane_off,
-                                              float (&acc)[4][Vec16<T>::N])
+                                              float (&acc)[kNPX][Vec16<T>::N])
 {
     typedef Vec16<T> V;
     constexpr int U = LPS < kUnroll ? LPS : kUnroll;
+    constexpr int WV = kNPX / 4;                     // weight vectors per record
     slot_off[lig] = mine.off;
-    slot_w[lig] = make_uint4(__float_as_uint(mine.w[0]), __float_as_uint(mine.w[1]), __float_as_uint(mine.w[2]),
-                             __float_as_uint(mine.w[3]));
+#pragma unroll
+    for (int v = 0; v < WV; ++v)
+        slot_w[lig * WV + v] = make_uint4(__float_as_uint(mine.w[4 * v]), __float_as_uint(mine.w[4 * v + 1]),
+                                          __float_as_uint(mine.w[4 * v + 2]), __float_as_uint(mine.w[4 * v + 3]));
     __builtin_amdgcn_wave_barrier();
     auto request = [&](int u) {
         const uint32_t off = slot_off[u];
@@ -338,14 +358,17 @@ __device__ __forceinline__ void consume_batch(const BlkRec &mine, int lig, uint3
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint4 ww = slot_w[u0 + u];
-            const float w[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
             float g[V::N];
             V::unpack(cur[u], g);
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
+            for (int v = 0; v < WV; ++v) {
+                const uint4 ww = slot_w[(u0 + u) * WV + v];
+                const float w[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
 #pragma unroll
-                for (int i = 0; i < V::N; ++i) acc[px][i] = fmaf(w[px], g[i], acc[px][i]);
+                for (int px = 0; px < 4; ++px) {
+#pragma unroll
+                    for (int i = 0; i < V::N; ++i) acc[4 * v + px][i] = fmaf(w[px], g[i], acc[4 * v + px][i]);
+                }
             }
         }
 #pragma unroll
@@ -367,9 +390,9 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     static_assert(GROUPS % kMaxSplit == 0, "a block's lane groups must share a workgroup");
     __shared__ LevelRow lvs[kMaxLevels];
     __shared__ BlockRuns runs[GROUPS];
-    __shared__ float scratch[GROUPS * 4 * D];        // partial sums of split blocks
+    __shared__ float scratch[GROUPS * 4 * D];        // partial sums of split blocks, 4 pixels per round
     __shared__ uint32_t slots_off[GROUPS * (LPS + 1)];
-    __shared__ uint4 slots_w[GROUPS * (LPS + 1)];
+    __shared__ uint4 slots_w[GROUPS * (LPS + 1) * (kNPX / 4)];
 
     const int bid = blockIdx.x;
     const int h = bid % d.H;
@@ -383,7 +406,7 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     __syncthreads();
 
     uint32_t *slot = slots_off + gid * (LPS + 1);
-    uint4 *slot4 = slots_w + gid * (LPS + 1);
+    uint4 *slot4 = slots_w + gid * (LPS + 1) * (kNPX / 4);
     const int vb = chunk * GROUPS + gid;
 
     // virtual block -> (level, block, part)
@@ -404,15 +427,15 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
                                    ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
 
-    // the 9 cell runs of the block, as one list (lane 0 of the group builds the prefix)
+    // the cell runs of the block, as one list (lane 0 of the group builds the prefix)
     const uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + lr.cbase;
     if (lig == 0) {
         int run = 0;
         runs[gid].pre[0] = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < kNC; ++k) {
             uint2 r = make_uint2(0u, 0u);
-            const int cy = 2 * by + k / 3, cx = 2 * bx + k % 3;
+            const int cy = kBH * by + k / (kBW + 1), cx = kBW * bx + k % (kBW + 1);
             if (act && cy <= lr.Hl && cx <= lr.Wl) r = tab[cy * (lr.Wl + 1) + cx];
             runs[gid].first[k] = r.x;
             run += (int)r.y;
@@ -421,11 +444,11 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     }
     __builtin_amdgcn_wave_barrier();
     const BlockRuns *br = &runs[gid];
-    const int n = br->pre[9];
+    const int n = br->pre[kNC];
 
-    float acc[4][VEC];
+    float acc[kNPX][VEC];
 #pragma unroll
-    for (int px = 0; px < 4; ++px)
+    for (int px = 0; px < kNPX; ++px)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
 
@@ -443,20 +466,26 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     // split blocks: the parts meet in LDS, part 0 adds them up (uniform decision per workgroup is not
     // possible -- levels may change inside a workgroup -- so every workgroup passes the two barriers)
 #pragma unroll
-    for (int px = 0; px < 4; ++px)
+    for (int r0 = 0; r0 < kNPX; r0 += 4) {
+        if (r0 > 0) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) scratch[(gid * 4 + px) * D + lig * VEC + i] = acc[px][i];
-    __syncthreads();
-    if (act && part == 0) {
-        for (int s2 = 1; s2 < split; ++s2) {
+        for (int px = 0; px < 4; ++px)
 #pragma unroll
-            for (int px = 0; px < 4; ++px)
+            for (int i = 0; i < VEC; ++i) scratch[(gid * 4 + px) * D + lig * VEC + i] = acc[r0 + px][i];
+        __syncthreads();
+        if (act && part == 0) {
+            for (int s2 = 1; s2 < split; ++s2) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[px][i] += scratch[((gid + s2) * 4 + px) * D + lig * VEC + i];
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[r0 + px][i] += scratch[((gid + s2) * 4 + px) * D + lig * VEC + i];
+            }
         }
+    }
+    if (act && part == 0) {
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            const int y = 2 * by + (px >> 1), x = 2 * bx + (px & 1);
+        for (int px = 0; px < kNPX; ++px) {
+            const int y = kBH * by + px / kBW, x = kBW * bx + px % kBW;
             if (y < lr.Hl && x < lr.Wl) {
                 T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + lig * VEC;
                 *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
@@ -484,7 +513,7 @@ int cell_stride_of(const Dims &d) { return 2 * d.S + 2 * d.L; }      // >= sum (
 // blocks <= pixels + 1, and split * blocks <= blocks + 2 * (2.25 * Nq * P) / 128 + kMaxSplit
 int64_t block_bound_of(const Dims &d)
 {
-    return (int64_t)d.S + (int64_t)d.L * (2 * kMaxSplit + 2 + ((int64_t)d.Nq * d.P * 9 / 4) / 64);
+    return (int64_t)d.S + (int64_t)d.L * (2 * kMaxSplit + 2 + ((int64_t)d.Nq * d.P * (kBH + 1) * (kBW + 1) / (kBH * kBW)) / 64);
 }
 
 struct Scratch {

@@ -136,6 +136,25 @@ def test_hybrid_dense_levels_match_oracle(case, dtype, parts, monkeypatch):
     check(got, run_oracle(x), dtype, f"hybrid[{parts}] {case[:5]}")
 
 
+@pytest.mark.parametrize("algo", ["block", "pixel"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grad_value_generations_agree_with_oracle(algo, dtype, monkeypatch):
+    """grad_value: block-stationary / cell-sorted (csrc/msda_bwd_block.hip, default) and
+    pixel-stationary (csrc/msda_bwd_value.hip, MMFS_VALUE_ALGO=pixel and the fallback for L > 128)
+    on a shape with odd extents, a 1-pixel-wide level, hot spots and many taps outside the map."""
+    monkeypatch.setenv("MMFS_VALUE_ALGO", algo)
+    x = make_inputs(2, 4, 64, 150, 4, [(13, 9), (1, 7), (6, 1), (16, 16), (2, 2)], seed=21,
+                    loc_range=(-0.3, 1.3), dtype=dtype)
+    x["loc"][:, :40, :, 3] = x["loc"][:, :40, :, 3] * 0.05 + 0.5       # hot spot: long lists on a few blocks
+    check(run_hip(x, dtype), run_oracle(x), dtype, f"value algo {algo}")
+
+
+def test_many_levels_fall_back_to_pixel_stationary():
+    """L = 130 > the block reduce's level table: the pixel-stationary kernels take over."""
+    x = make_inputs(1, 2, 32, 12, 2, [(3, 2)] * 130, seed=4, dtype=torch.bfloat16)
+    check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "L=130")
+
+
 def test_hybrid_off_uses_plain_kernels(monkeypatch):
     import MultiScaleDeformableAttention as MSDA
     monkeypatch.setattr(MSDA, "_hybrid", False)
