@@ -28,7 +28,10 @@ shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(dst, f"{prefix}_p
 
 names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_reduce": "msda_bwd_value_reduce",
          "msda_bwd_value_sort": "msda_bwd_value_sort", "msda_bwd_vec_taps": "msda_bwd_taps",
-         "msda_bwd_vec_atomic": "msda_bwd_atomic"}
+         "msda_bwd_vec_atomic": "msda_bwd_atomic",
+         # second-generation grad_value kernels answer to the same stage names in bench.py
+         "msda_bwd_block_reduce": "msda_bwd_value_reduce", "msda_bwd_cell_sort": "msda_bwd_value_sort",
+         "msda_taps_coarse": "msda_bwd_taps_coarse"}
 traffic = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
     kern, _, rest = line.partition(": ")
