@@ -346,8 +346,8 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
     constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row (D / 8)
     constexpr int GS = VPR + 1;                     // row stride of the staged tile, in vectors
     constexpr int TQ = 32 * MB;                     // queries per tile
-    __shared__ __attribute__((aligned(16))) float G[TQ * kAStride];
-    __shared__ uint4 gtile[2][TQ * GS];
+    __shared__ __attribute__((aligned(16))) float G[2][TQ * kAStride];     // products of this / the previous step
+    __shared__ uint4 gtile[TQ * GS];
 
     int bid = blockIdx.x;
     const int h = bid % d.H; bid /= d.H;
@@ -387,12 +387,47 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
         }
     };
 
+    // One thread per (query, point) of a step's tile: four look-ups in the step's products and the
+    // per-sample algebra.  A step's look-ups run during the NEXT step, between the issue of that
+    // step's MFMAs and the parking of their results, so the matrix pipe and the VALU / LDS work of
+    // the look-ups overlap (serialised, the look-ups and their barrier were 2/3 of a step).
+    struct Pending { int t, level, Hl, Wl, own0, own1, pix0; };
+    auto lookups = [&](const Pending &p, uint32_t xy, uint32_t aw, const float *__restrict__ Gp) {
+        if (tid < items && p.t * TQ + iq < d.Nq) {
+            const int64_t s = sample_index(p.t, p.level);
+            float l[Vec16<T>::N];
+            Vec16<T>::unpack(make_uint4(xy, aw, 0u, 0u), l);               // {x, y, a, -}
+            const float a = l[2];
+            const Tap<float> tp = locate<float>(l[0], l[1], p.Hl, p.Wl, 0);
+            // the chunk that owns the sample's top row finishes it (same arithmetic as locate)
+            const float yy = l[1] * (float)p.Hl - 0.5f, xx = l[0] * (float)p.Wl - 0.5f;
+            const bool inside = (yy > -1.f) && (xx > -1.f) && (yy < (float)p.Hl) && (xx < (float)p.Wl);
+            const int y0 = inside ? (int)floorf(yy) : -1;
+            if (y0 >= p.own0 && y0 < p.own1) {
+                const float *g = Gp + iq * kAStride - p.pix0;
+                float dot[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dot[c] = tp.row[c] >= 0 ? g[tp.row[c]] : 0.f;
+                const float fx = tp.fx, fy = tp.fy, gy = 1.f - fy, gx = 1.f - fx;
+                const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+                const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
+                const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
+                const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
+                grad_attn[s] = (T)ga;
+                grad_loc[2 * s] = (T)((float)p.Wl * dw * a);
+                grad_loc[2 * s + 1] = (T)((float)p.Hl * dh * a);
+            }
+        }
+    };
+
     PROF_DECL;
-    uint32_t nxy = 0, na = 0;
-    if (stager) gtile[0][vq * GS + vc] = go_vector(t_begin);
+    uint32_t nxy = 0, na = 0, cxy = 0, ca = 0, pxy = 0, pa = 0;     // samples: being fetched / this step's / pending
+    if (stager) gtile[vq * GS + vc] = go_vector(t_begin);
     sample_load(t_begin, uni(cp.c[0].level), nxy, na);
     __syncthreads();
-    int cur = 0;
+    int buf = 0;
+    bool have_pending = false;
+    Pending pend = {0, 0, 1, 1, 0, 0, 0};
     for (int ci = 0; ci < cp.n; ++ci) {
         const int level = uni(cp.c[ci].level), Hl = uni(cp.c[ci].Hl), Wl = uni(cp.c[ci].Wl);
         const int row0 = uni(cp.c[ci].row0), own0 = uni(cp.c[ci].own0), own1 = uni(cp.c[ci].own1);
@@ -411,56 +446,38 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
             const bool last_tile = t + 1 == t_end;
             const bool more = !(last_tile && ci + 1 == cp.n);
             const int nt = last_tile ? t_begin : t + 1;
-            const uint32_t sxy = nxy, sa = na;
+            cxy = nxy; ca = na;
             uint4 nv = make_uint4(0u, 0u, 0u, 0u);
             if (more) {
                 if (stager) nv = go_vector(nt);
                 sample_load(nt, last_tile ? next_level : level, nxy, na);
             }
+            f32x16 acc = zero16();
             if (prod) {
-                const uint4 *arow = &gtile[cur][(mb * 32 + l32) * GS + kg];
-                f32x16 acc = zero16();
+                const uint4 *arow = &gtile[(mb * 32 + l32) * GS + kg];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) acc = Mma<T>::run(arow[kb * 2], bf[kb], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) G[(mb * 32 + mfma_row(r, lane)) * kAStride + nbw * 32 + l32] = acc[r];
             }
             PROF(0);
-            if (more && stager) gtile[cur ^ 1][vq * GS + vc] = nv;
+            if (have_pending) lookups(pend, pxy, pa, G[buf ^ 1]);
             PROF(1);
-            __syncthreads();
-            PROF(2);
-            if (tid < items && t * TQ + iq < d.Nq) {
-                const int64_t s = sample_index(t, level);
-                float l[Vec16<T>::N];
-                Vec16<T>::unpack(make_uint4(sxy, sa, 0u, 0u), l);         // {x, y, a, -}
-                const float a = l[2];
-                const Tap<float> tp = locate<float>(l[0], l[1], Hl, Wl, 0);
-                // the chunk that owns the sample's top row finishes it (same arithmetic as locate)
-                const float yy = l[1] * (float)Hl - 0.5f, xx = l[0] * (float)Wl - 0.5f;
-                const bool inside = (yy > -1.f) && (xx > -1.f) && (yy < (float)Hl) && (xx < (float)Wl);
-                const int y0 = inside ? (int)floorf(yy) : -1;
-                if (y0 >= own0 && y0 < own1) {
-                    const float *g = G + iq * kAStride - pix0;
-                    float dot[4];
+            if (prod) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dot[c] = tp.row[c] >= 0 ? g[tp.row[c]] : 0.f;
-                    const float fx = tp.fx, fy = tp.fy, gy = 1.f - fy, gx = 1.f - fx;
-                    const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
-                    const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
-                    const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
-                    const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
-                    grad_attn[s] = (T)ga;
-                    grad_loc[2 * s] = (T)((float)Wl * dw * a);
-                    grad_loc[2 * s + 1] = (T)((float)Hl * dh * a);
-                }
+                for (int r = 0; r < 16; ++r) G[buf][(mb * 32 + mfma_row(r, lane)) * kAStride + nbw * 32 + l32] = acc[r];
             }
+            PROF(2);
+            __syncthreads();                        // tile read, products parked, previous look-ups done
+            if (more && stager) gtile[vq * GS + vc] = nv;
+            pend.t = t; pend.level = level; pend.Hl = Hl; pend.Wl = Wl; pend.own0 = own0; pend.own1 = own1; pend.pix0 = pix0;
+            pxy = cxy; pa = ca;
+            have_pending = true;
+            buf ^= 1;
             PROF(3);
-            __syncthreads();
+            __syncthreads();                        // next tile staged
             PROF(4);
-            cur ^= 1;
         }
     }
+    if (have_pending) lookups(pend, pxy, pa, G[buf ^ 1]);
     PROF_END(0);
 }
 
