@@ -42,6 +42,7 @@ struct CTile {
 struct LevelRow {
     int Hl, Wl, lstart, cbase;
     int bbase, nbx, nby, split;         // first (virtual) block index, blocks per row / column, lane groups per block
+    int cap, pad[3];                    // records of a block's list walked in place before the rest is queued
 };
 constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
 #ifndef MMFS_BLK_H
@@ -66,22 +67,78 @@ __device__ __host__ inline const LevelRow *level_rows(const CellHeader *h) { ret
 __device__ __host__ inline CTile *tiles_of(CellHeader *h, int L) { return reinterpret_cast<CTile *>(level_rows(h) + L); }
 __device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { return reinterpret_cast<const CTile *>(level_rows(h) + L); }
 
+
+// The 9 runs of a block, seen as one list: run k holds [pre[k], pre[k+1]) of it.  Kept in LDS
+// (one per lane group; every group reads the others' in phase 2).
+struct BlockRuns {
+    uint32_t first[kNC];
+    int pre[kNC + 1];
+};
+
+// The queue has one lane per XCD: workgroup w of the chunk kernel runs on XCD w % 8 (round-robin
+// dispatch) and takes its chunks from lane w % 8, which holds the heads h with h % 8 == w % 8 -- the
+// same head -> XCD affinity as every other kernel here, so a (b, h) slice of grad_out is pulled into
+// ONE L2 instead of all eight.
+constexpr int kOvfLanes = 8;
+struct OvfHeader { uint32_t n_slots, cap_slots, cap_entries, n_partials, cap_partials, pad[3]; uint32_t n_entries[kOvfLanes]; };
+
+// Long lists.  The plan sizes `split` for uniformly spread samples; real MMFS inputs are not: every
+// text token of the LLM path samples around the SAME reference point (the image centre), so a handful
+// of blocks own almost every record of a level.  A block whose list is longer than twice what
+// uniformly spread samples would give it (LevelRow::cap) is cut into chunks of kOvfChunk records and
+// queued whole; a second kernel spreads the queued chunks over the whole chip (one fp32 partial each;
+// float atomics into a common accumulator were tried first: 3x slower, the few hot addresses
+// serialise) and a third adds a block's partials and rounds them into grad_value.  With uniformly
+// spread samples the queue stays empty and the two extra launches return at once.
+// Measured with every query on one reference point (tools/block_bench.py, SD geometry): 256 and 512
+// give 147 / 144 us for the in-place kernel; 1024 gave 9.1 ms (not understood yet) -- keep <= 512.
+#ifndef MMFS_BLK_CAP
+#define MMFS_BLK_CAP 512
+#endif
+constexpr int kCapRecords = MMFS_BLK_CAP;   // smallest in-place share of a block's list (LevelRow::cap)
+constexpr int kOvfChunk = 512;          // records per queued chunk
+
+
+struct OvfSlot {
+    BlockRuns runs;                     // where the block's records are
+    int b, h, by, bx;
+    int Hl, Wl, lstart;
+    uint32_t pbase, n_partials;         // its partial sums: [pbase + c] is chunk c's
+    int pad;
+};
+struct OvfEntry { uint32_t slot, start, count, pidx; };
+
 // Lane groups per block of a level: aim at <= 128 records of the block's list per lane group.
-__device__ __host__ inline int split_of(int64_t samples, int64_t blocks)
+__device__ __host__ inline int64_t expected_list(int64_t samples, int64_t blocks)
 {
     // every sample is visited by (1 + 1/BH)(1 + 1/BW) blocks on average
     const int64_t visits = samples * (kBH + 1) * (kBW + 1) / (kBH * kBW);
-    const int64_t per_block = blocks > 0 ? (visits + blocks - 1) / blocks : 0;
+    return blocks > 0 ? (visits + blocks - 1) / blocks : 0;
+}
+__device__ __host__ inline int split_of(int64_t samples, int64_t blocks)
+{
+    const int64_t per_block = expected_list(samples, blocks);
     int s = 1;
     while (s < kMaxSplit && per_block > 128LL * s) s <<= 1;
     return s;
 }
+// Records of a block's list that are walked in place; a list longer than twice what uniformly spread
+// samples would give (hot spots: the LLM path's common reference point) has its rest queued.
+__device__ __host__ inline int cap_of(int64_t samples, int64_t blocks)
+{
+    const int64_t c = 2 * expected_list(samples, blocks);
+    return (int)(c < kCapRecords ? kCapRecords : (c > 0x3fffffff ? 0x3fffffff : c));
+}
 
 __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                                   int L, int nt_min, int cap, int64_t samples_per_level,
-                                  CellHeader *__restrict__ hdr)
+                                  CellHeader *__restrict__ hdr, uint32_t *__restrict__ ovf_header,
+                                  uint32_t cap_slots, uint32_t cap_entries)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ovf_header[0] = 0u; ovf_header[1] = cap_slots; ovf_header[2] = cap_entries;                         // OvfHeader
+    ovf_header[3] = 0u; ovf_header[4] = cap_entries; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
+    for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
     LevelRow *lv = level_rows(hdr);
     CTile *tile = tiles_of(hdr, L);
     int n = 0, cbase = 0, bbase = 0;
@@ -89,9 +146,11 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         LevelRow r;
         r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l]; r.cbase = cbase; r.bbase = bbase;
-        r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1;
+        r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
         if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = 0; lv[l] = r; continue; }
         r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
+        r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
         lv[l] = r;
         const int Hc = Hl + 1, Wc = Wl + 1, cells = Hc * Wc;
         int nt = max(nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
@@ -275,14 +334,9 @@ constexpr int kRThreads = 256;
 #endif
 constexpr int kUnroll = MMFS_BLK_UNROLL;
 
-// The 9 runs of a block, seen as one list: run k holds [pre[k], pre[k+1]) of it.  Kept in LDS
-// (one per lane group; every group reads the others' in phase 2).
-struct BlockRuns {
-    uint32_t first[kNC];
-    int pre[kNC + 1];
-};
 
 struct BlkRec { uint32_t off; float w[kNPX]; };   // row offset ("outside" past the end), weights of the block's pixels
+
 
 // Record e of the block's list -> its grad_out row offset and the weights it adds to the block's
 // four pixels (zero where the corner is another block's).
@@ -342,8 +396,9 @@ __device__ __forceinline__ void consume_batch(const BlkRec &mine, int lig, uint3
     auto request = [&](int u) {
         const uint32_t off = slot_off[u];
         if (BUF) return buffer_load16(rsrc, off + lane_off);
+        // flat addresses: the records were fetched with a row pitch of 1, so off is the row index
         const bool ok = off != kOobOffset;
-        uint4 r = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? off / row_bytes : 0u) * HD);
+        uint4 r = *reinterpret_cast<const uint4 *>(gslice + (int64_t)(ok ? off : 0u) * HD);
         if (!ok) r = make_uint4(0u, 0u, 0u, 0u);
         return r;
     };
@@ -381,7 +436,9 @@ template <typename T, int LPS, bool BUF>
 __global__ void __launch_bounds__(kRThreads, MMFS_BLK_WAVES)
 msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
                       const uint4 *__restrict__ records, const uint2 *__restrict__ celltab,
-                      const CellHeader *__restrict__ hdr, const Dims d, const int chunks, const int cell_stride)
+                      const CellHeader *__restrict__ hdr, const Dims d, const int chunks, const int cell_stride,
+                      OvfHeader *__restrict__ ovf, OvfSlot *__restrict__ oslots, OvfEntry *__restrict__ oentries,
+                      float *__restrict__ oacc)
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
@@ -421,7 +478,7 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
 
     const int64_t HD = (int64_t)d.H * d.D;
     const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t row_bytes = BUF ? (uint32_t)(HD * sizeof(T)) : 1u;     // pitch of a record's row offset
     const uint32_t lane_off = (uint32_t)(lig * 16);
     __amdgpu_buffer_rsrc_t rsrc;
     if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
@@ -452,15 +509,20 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
 
-    // this group's batches of the list: part, part + split, ...
-    const int batches = (n + LPS - 1) / LPS;
+    // this group's batches of the list: part, part + split, ... -- at most kCapRecords records of it;
+    // what lies beyond the covered prefix of a long list is queued below
+    // A list longer than the level's cap (hot spot) is not walked here at all: its few owners would
+    // be the only busy lane groups of the chip.  It is queued whole, in chunks (below).
+    const bool hot = n > lr.cap;
+    const int covered = hot ? 0 : n;
+    const int batches = (covered + LPS - 1) / LPS;
     int nb = batches > part ? (batches - part + split - 1) / split : 0;
 #pragma unroll
     for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));    // wave-uniform trip count
-    BlkRec pre = fetch_record(records, br, part * LPS + lig, n, row_bytes);
+    BlkRec pre = fetch_record(records, br, part * LPS + lig, covered, row_bytes);
     for (int j = 0; j < nb; ++j) {
         const BlkRec cur_rec = pre;
-        if (j + 1 < nb) pre = fetch_record(records, br, (part + (j + 1) * split) * LPS + lig, n, row_bytes);
+        if (j + 1 < nb) pre = fetch_record(records, br, (part + (j + 1) * split) * LPS + lig, covered, row_bytes);
         consume_batch<T, LPS, BUF>(cur_rec, lig, slot, slot4, gslice, HD, rsrc, row_bytes, lane_off, acc);
     }
     // split blocks: the parts meet in LDS, part 0 adds them up (uniform decision per workgroup is not
@@ -483,12 +545,157 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
         }
     }
     if (act && part == 0) {
+        bool queued = false;
+        if (n > covered) {
+            // queue the rest of the list in chunks; the block's sums so far go to an accumulator slot
+            const int rest = n - covered, nchunks = (rest + kOvfChunk - 1) / kOvfChunk;
+            uint32_t sl = 0, base = 0, pb = 0;
+            const int qlane = h % kOvfLanes;
+            if (lig == 0) {
+                sl = atomicAdd(&ovf->n_slots, 1u);
+                base = atomicAdd(&ovf->n_entries[qlane], (uint32_t)nchunks);
+                pb = atomicAdd(&ovf->n_partials, (uint32_t)nchunks);
+            }
+            sl = __shfl(sl, 0, LPS); base = __shfl(base, 0, LPS); pb = __shfl(pb, 0, LPS);
+            if (sl < ovf->cap_slots && base + (uint32_t)nchunks <= ovf->cap_entries &&
+                pb + (uint32_t)nchunks <= ovf->cap_partials) {
+                queued = true;
+                if (lig == 0) {
+                    OvfSlot os;
+                    os.runs = *br;
+                    os.b = b; os.h = h; os.by = by; os.bx = bx;
+                    os.Hl = lr.Hl; os.Wl = lr.Wl; os.lstart = lr.lstart; os.pad = 0;
+                    os.pbase = pb; os.n_partials = (uint32_t)nchunks;
+                    oslots[sl] = os;
+                }
+                for (int c = lig; c < nchunks; c += LPS) {
+                    OvfEntry e;
+                    e.slot = sl; e.start = (uint32_t)(covered + c * kOvfChunk);
+                    e.count = (uint32_t)min(kOvfChunk, rest - c * kOvfChunk); e.pidx = pb + (uint32_t)c;
+                    oentries[(size_t)qlane * ovf->cap_entries + base + c] = e;
+                }
+            } else {
+                // Queue full (more hot blocks than the host provided for): whatever this block did
+                // reserve must still read as empty to the two kernels that walk the queue, then the
+                // list is finished here, slowly.
+                if (lig == 0 && sl < ovf->cap_slots) {
+                    OvfSlot os;
+                    os.runs = *br;
+                    os.b = os.h = os.by = os.bx = 0;
+                    os.Hl = os.Wl = 0; os.lstart = 0; os.pbase = 0; os.n_partials = 0; os.pad = 0;
+                    oslots[sl] = os;
+                }
+                for (int c = lig; c < nchunks; c += LPS) {
+                    if (base + (uint32_t)c < ovf->cap_entries) {
+                        OvfEntry e;
+                        e.slot = 0; e.start = 0; e.count = 0; e.pidx = 0;
+                        oentries[(size_t)qlane * ovf->cap_entries + base + c] = e;
+                    }
+                }
+                for (int e0 = covered; e0 < n; e0 += LPS) {
+                    const BlkRec r = fetch_record(records, br, e0 + lig, n, row_bytes);
+                    consume_batch<T, LPS, BUF>(r, lig, slot, slot4, gslice, HD, rsrc, row_bytes, lane_off, acc);
+                }
+            }
+        }
+        if (!queued) {
 #pragma unroll
-        for (int px = 0; px < kNPX; ++px) {
-            const int y = kBH * by + px / kBW, x = kBW * bx + px % kBW;
-            if (y < lr.Hl && x < lr.Wl) {
-                T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + lig * VEC;
-                *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+            for (int px = 0; px < kNPX; ++px) {
+                const int y = kBH * by + px / kBW, x = kBW * bx + px % kBW;
+                if (y < lr.Hl && x < lr.Wl) {
+                    T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + lig * VEC;
+                    *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- kernel C: queued chunks of long lists
+// One lane group per queued chunk, any (b, h) next to any other in a wave (so flat addresses, no
+// buffer descriptor); sums go into the block's accumulator slot with float atomics.
+template <typename T, int LPS>
+__global__ void __launch_bounds__(kRThreads, MMFS_BLK_WAVES)
+msda_bwd_block_overflow(const T *__restrict__ grad_out, const uint4 *__restrict__ records,
+                        const OvfHeader *__restrict__ ovf, const OvfSlot *__restrict__ oslots,
+                        const OvfEntry *__restrict__ oentries, float *__restrict__ oacc, const Dims d)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int GROUPS = kRThreads / LPS;
+    constexpr int D = LPS * VEC;
+    __shared__ BlockRuns runs[GROUPS];
+    __shared__ uint32_t slots_off[GROUPS * (LPS + 1)];
+    __shared__ uint4 slots_w[GROUPS * (LPS + 1) * (kNPX / 4)];
+
+    const int tid = threadIdx.x, gid = tid / LPS, lig = tid % LPS;
+    const int qlane = blockIdx.x % kOvfLanes;
+    const uint32_t n_entries = min(ovf->n_entries[qlane], ovf->cap_entries);
+    // a fixed grid walks the queue lane with a stride (an empty queue costs one small launch)
+    const uint32_t e_step = (uint32_t)(gridDim.x / kOvfLanes) * GROUPS;
+    for (uint32_t e0 = (uint32_t)(blockIdx.x / kOvfLanes) * GROUPS; e0 < n_entries; e0 += e_step) {
+    const uint32_t ei = e0 + gid;
+    const bool act = ei < n_entries;
+    OvfEntry en;
+    en.slot = 0; en.start = 0; en.count = 0; en.pidx = 0;
+    if (act) en = oentries[(size_t)qlane * ovf->cap_entries + ei];
+    const bool live = act && en.count > 0;            // (count 0: a reservation its owner could not use)
+    const OvfSlot *os = oslots + en.slot;
+    if (lig == 0) runs[gid] = os->runs;
+    __builtin_amdgcn_wave_barrier();
+    const BlockRuns *br = &runs[gid];
+
+    const int64_t HD = (int64_t)d.H * d.D;
+    const T *gslice = grad_out + ((int64_t)os->b * d.Nq * d.H + os->h) * d.D + lig * VEC;
+    const uint32_t row_bytes = 1u;                    // flat addresses: a record's offset is its row index
+    uint32_t *slot = slots_off + gid * (LPS + 1);
+    uint4 *slot4 = slots_w + gid * (LPS + 1) * (kNPX / 4);
+    __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(grad_out, 0);          // unused (flat addresses)
+
+    float acc[kNPX][VEC];
+#pragma unroll
+    for (int px = 0; px < kNPX; ++px)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
+
+    const int first = (int)en.start, end = live ? (int)(en.start + en.count) : 0;
+    int nb = live ? ((int)en.count + LPS - 1) / LPS : 0;
+#pragma unroll
+    for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
+    BlkRec pre = fetch_record(records, br, first + lig, end, row_bytes);
+    for (int j = 0; j < nb; ++j) {
+        const BlkRec cur_rec = pre;
+        if (j + 1 < nb) pre = fetch_record(records, br, first + (j + 1) * LPS + lig, end, row_bytes);
+        consume_batch<T, LPS, false>(cur_rec, lig, slot, slot4, gslice, HD, rsrc, row_bytes, 0u, acc);
+    }
+    if (live) {
+        float *oa = oacc + (size_t)en.pidx * (kNPX * D) + lig * VEC;
+#pragma unroll
+        for (int px = 0; px < kNPX; ++px)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) oa[px * D + i] = acc[px][i];
+    }
+    __builtin_amdgcn_wave_barrier();                  // the group's LDS pieces are reused by the next entry
+    }
+}
+
+// ---------------------------------------------------------------- kernel D: accumulator slots -> grad_value rows
+template <typename T>
+__global__ void __launch_bounds__(256)
+msda_bwd_block_ovf_store(T *__restrict__ grad_value, const OvfHeader *__restrict__ ovf,
+                         const OvfSlot *__restrict__ oslots, const float *__restrict__ oacc, const Dims d)
+{
+    const uint32_t n_slots = min(ovf->n_slots, ovf->cap_slots);
+    for (uint32_t sl = blockIdx.x; sl < n_slots; sl += gridDim.x) {
+        const OvfSlot os = oslots[sl];
+        const float *oa = oacc + (size_t)os.pbase * (kNPX * d.D);
+        for (int i = threadIdx.x; i < kNPX * d.D; i += 256) {
+            const int px = i / d.D, ch = i - px * d.D;
+            const int y = kBH * os.by + px / kBW, x = kBW * os.bx + px % kBW;
+            if (y < os.Hl && x < os.Wl) {
+                float sum = 0.f;
+                for (uint32_t c = 0; c < os.n_partials; ++c) sum += oa[(size_t)c * (kNPX * d.D) + i];
+                grad_value[(((int64_t)os.b * d.S + os.lstart + y * os.Wl + x) * d.H + os.h) * d.D + ch] = (T)sum;
             }
         }
     }
@@ -522,6 +729,11 @@ struct Scratch {
     CellHeader *hdr;
     uint2 *celltab;            // [B, H, cell_stride] {first record, count}
     uint4 *records;            // [B, H, L, Nq*P] {query, fy, fx, attention}, cell-sorted inside each tile
+    OvfHeader *ovf;            // long lists: counters, slots, queued chunks, fp32 accumulators
+    OvfSlot *oslots;
+    OvfEntry *oentries;
+    float *oacc;
+    uint32_t cap_slots, cap_entries;
     int64_t cursor_bytes, total;
 };
 
@@ -539,6 +751,18 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     p += up((int64_t)sizeof(CellHeader) + (int64_t)d.L * sizeof(LevelRow) + (int64_t)make_params(d).tiles_bound * sizeof(CTile));
     s.celltab = (uint2 *)p;      p += up((int64_t)d.B * d.H * cell_stride_of(d) * 8);
     s.records = (uint4 *)p;      p += up(pts * 16);
+    // every sample is visited (kBH+1)(kBW+1)/(kBH kBW) times; a block is queued only after kCapRecords
+    // of its records were walked in place, in chunks of kOvfChunk
+    // a block is queued only after >= kCapRecords of its records were walked in place, in chunks of kOvfChunk
+    const int64_t visits = pts * (kBH + 1) * (kBW + 1) / (kBH * kBW);
+    // a queued block holds > kCapRecords records and is cut into ceil(n / kOvfChunk) chunks: these
+    // bounds cannot be exceeded (the kernels nevertheless survive it: the owner then finishes in place)
+    s.cap_slots = (uint32_t)std::min<int64_t>(visits / kCapRecords + 64, 0x3fffffff);
+    s.cap_entries = (uint32_t)std::min<int64_t>(visits / kOvfChunk + s.cap_slots, 0x3fffffff);
+    s.ovf = (OvfHeader *)p;      p += up(sizeof(OvfHeader));
+    s.oslots = (OvfSlot *)p;     p += up((int64_t)s.cap_slots * sizeof(OvfSlot));
+    s.oentries = (OvfEntry *)p;  p += up((int64_t)kOvfLanes * s.cap_entries * sizeof(OvfEntry));   // any lane may take all
+    s.oacc = (float *)p;         p += up((int64_t)s.cap_entries * kNPX * d.D * 4);                        // partial sums
     s.total = p - (char *)workspace;
     return s;
 }
@@ -551,7 +775,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
     hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min, tp.tiles_bound,
-                       (int64_t)d.Nq * d.P, sc.hdr);
+                       (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries);
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                        cell_stride_of(d));
@@ -582,10 +806,18 @@ hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
         hipLaunchKernelGGL((msda_bwd_block_reduce<T, LPS, true>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
-                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d));
+                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d),
+                           sc.ovf, sc.oslots, sc.oentries, sc.oacc);
     else
         hipLaunchKernelGGL((msda_bwd_block_reduce<T, LPS, false>), dim3((unsigned)blocks), dim3(kRThreads), 0, st,
-                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d));
+                           (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d),
+                           sc.ovf, sc.oslots, sc.oentries, sc.oacc);
+    // long lists (normally none: both kernels read the queue length on the device and return)
+    const unsigned oblocks = std::min<unsigned>((unsigned)((sc.cap_entries + GROUPS - 1) / GROUPS), 1024u) * kOvfLanes;
+    hipLaunchKernelGGL((msda_bwd_block_overflow<T, LPS>), dim3(oblocks), dim3(kRThreads), 0, st,
+                       (const T *)go, sc.records, sc.ovf, sc.oslots, sc.oentries, sc.oacc, d);
+    hipLaunchKernelGGL((msda_bwd_block_ovf_store<T>), dim3(std::min<unsigned>(sc.cap_slots, 1024u)), dim3(256), 0, st,
+                       (T *)gv, sc.ovf, sc.oslots, sc.oacc, d);
     return hipGetLastError();
 }
 

@@ -150,6 +150,16 @@ def test_grad_value_generations_agree_with_oracle(algo, dtype, monkeypatch):
     check(run_hip(x, dtype), run_oracle(x), dtype, f"value algo {algo}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_every_query_on_one_spot_overflows_the_block_lists(dtype):
+    """The LLM path's distribution: every token samples around the SAME reference point, so a few
+    2x2 blocks own nearly all records.  Lists beyond the in-place cap are queued, spread over the
+    chip and added into accumulator slots (msda_bwd_block_overflow / _ovf_store)."""
+    x = make_inputs(1, 2, 64, 1500, 4, [(8, 8), (4, 4)], seed=5, dtype=dtype)
+    x["loc"] = (x["loc"] * 0.04 + 0.48).to(dtype).to(torch.float64)     # all 6000 samples of a level in ~1 cell
+    check(run_hip(x, dtype), run_oracle(x), dtype, "hot spot overflow")
+
+
 def test_many_levels_fall_back_to_pixel_stationary():
     """L = 130 > the block reduce's level table: the pixel-stationary kernels take over."""
     x = make_inputs(1, 2, 32, 12, 2, [(3, 2)] * 130, seed=4, dtype=torch.bfloat16)
