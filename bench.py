@@ -79,7 +79,7 @@ def algorithmic_bytes(w, e):
                 msda_bwd_taps_coarse=taps_dense, msda_bwd_taps_fine=taps_fine)
 
 
-def make_inputs(w, device, seed):
+def make_inputs(w, device, seed, loc_dist="uniform"):
     g = torch.Generator(device=device).manual_seed(seed)
     dt = DTYPES[w["dtype"]]
     shapes = torch.tensor(w["shapes"] * w["n"], dtype=torch.long, device=device)
@@ -87,7 +87,12 @@ def make_inputs(w, device, seed):
     B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
     S, L = int(shapes.prod(1).sum()), shapes.shape[0]
     value = torch.rand(B, S, H, D, device=device, generator=g).to(dt)
-    loc = torch.rand(B, Nq, H, L, P, 2, device=device, generator=g).to(dt)
+    loc = torch.rand(B, Nq, H, L, P, 2, device=device, generator=g)
+    if loc_dist == "centre":
+        # the LLM path's distribution: every query samples within a few pixels of ONE reference point
+        px = (shapes.float().flip(-1)).view(1, 1, 1, L, 1, 2)               # (W, H) per level
+        loc = 0.5 + (loc - 0.5) * 16.0 / px                                    # +-8 pixels around the centre
+    loc = loc.to(dt)
     attn = torch.rand(B, Nq, H, L, P, device=device, generator=g) + 1e-5
     attn = (attn / attn.sum((-1, -2), keepdim=True)).to(dt)
     grad = torch.randn(B, Nq, H * D, device=device, generator=g).to(dt)
@@ -133,6 +138,9 @@ def main():
     ap.add_argument("--nq", type=int, default=None, help="override Nq (parity/sweep use)")
     ap.add_argument("--dtype", default=None, choices=sorted(DTYPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loc-dist", default="uniform", choices=["uniform", "centre"],
+                    help="sampling locations: uniform over each level (the contract workload) or clustered "
+                         "around one reference point (what the LLM path produces)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +164,7 @@ def main():
         w["Nq"] = args.nq
     if args.dtype:
         w["dtype"] = args.dtype
-    value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank)
+    value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank, loc_dist=args.loc_dist)
     value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
 
     def step():
@@ -212,7 +220,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": w["dtype"], "data": "synthetic",
-            "config": {"workload": f"{args.workload}: ms_deform_attn fwd+bwd, per-GPU B={w['B']} Nq={w['Nq']} "
+            "config": {"workload": f"{args.workload}{'' if args.loc_dist == 'uniform' else '@' + args.loc_dist}: ms_deform_attn fwd+bwd, per-GPU B={w['B']} Nq={w['Nq']} "
                                    f"L={Leff} H={w['H']} P={w['P']} C={w['H'] * w['D']} S={sum(h * x for h, x in w['shapes']) * w['n']}",
                        "global_batch": world * w["B"], "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -83,30 +83,34 @@ constexpr int kOvfLanes = 8;
 struct OvfHeader { uint32_t n_slots, cap_slots, cap_entries, n_partials, cap_partials, pad[3]; uint32_t n_entries[kOvfLanes]; };
 
 // Long lists.  The plan sizes `split` for uniformly spread samples; real MMFS inputs are not: every
-// text token of the LLM path samples around the SAME reference point (the image centre), so a handful
-// of blocks own almost every record of a level.  A block whose list is longer than twice what
-// uniformly spread samples would give it (LevelRow::cap) is cut into chunks of kOvfChunk records and
-// queued whole; a second kernel spreads the queued chunks over the whole chip (one fp32 partial each;
-// float atomics into a common accumulator were tried first: 3x slower, the few hot addresses
-// serialise) and a third adds a block's partials and rounds them into grad_value.  With uniformly
-// spread samples the queue stays empty and the two extra launches return at once.
-// Measured with every query on one reference point (tools/block_bench.py, SD geometry): 256 and 512
-// give 147 / 144 us for the in-place kernel; 1024 gave 9.1 ms (not understood yet) -- keep <= 512.
+// text token of the LLM path samples around the SAME reference point (the image centre), so a few
+// blocks own most records of a level.  A block whose list is longer than twice what uniformly spread
+// samples would give it (LevelRow::cap, at least kCapRecords) is not walked in place -- its owner
+// would be one of the few busy lane groups of the chip -- but queued whole, in chunks of kOvfChunk
+// records.  A second kernel gives every chunk a whole workgroup (its lane groups interleave the
+// chunk's batches and meet in LDS): a block of one chunk gets its rows stored right there, a longer
+// one leaves an fp32 partial per chunk for a third kernel to add up and round.  (Float atomics into
+// one accumulator per block were tried first: 3x slower, the few hot addresses serialise.)  With
+// uniformly spread samples the queue stays empty and the two extra launches return at once.
 #ifndef MMFS_BLK_CAP
-#define MMFS_BLK_CAP 512
+#define MMFS_BLK_CAP 128
 #endif
-constexpr int kCapRecords = MMFS_BLK_CAP;   // smallest in-place share of a block's list (LevelRow::cap)
-constexpr int kOvfChunk = 512;          // records per queued chunk
+#ifndef MMFS_OVF_CHUNK
+#define MMFS_OVF_CHUNK 2048
+#endif
+constexpr int kCapRecords = MMFS_BLK_CAP;   // smallest LevelRow::cap: lists up to here are always walked in place
+constexpr int kOvfChunk = MMFS_OVF_CHUNK;   // records per queued chunk = per WORKGROUP of the chunk kernel
 
 
 struct OvfSlot {
     BlockRuns runs;                     // where the block's records are
     int b, h, by, bx;
     int Hl, Wl, lstart;
-    uint32_t pbase, n_partials;         // its partial sums: [pbase + c] is chunk c's
+    uint32_t pbase, n_partials;         // its partial sums: [pbase + c] is chunk c's; 0 when the block is one chunk
     int pad;
 };
-struct OvfEntry { uint32_t slot, start, count, pidx; };
+struct OvfEntry { uint32_t slot, start, count, pidx; };      // pidx = kNoPartial: store the rows directly
+constexpr uint32_t kNoPartial = 0xffffffffu;
 
 // Lane groups per block of a level: aim at <= 128 records of the block's list per lane group.
 __device__ __host__ inline int64_t expected_list(int64_t samples, int64_t blocks)
@@ -133,11 +137,11 @@ __device__ __host__ inline int cap_of(int64_t samples, int64_t blocks)
 __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                                   int L, int nt_min, int cap, int64_t samples_per_level,
                                   CellHeader *__restrict__ hdr, uint32_t *__restrict__ ovf_header,
-                                  uint32_t cap_slots, uint32_t cap_entries)
+                                  uint32_t cap_slots, uint32_t cap_entries, uint32_t cap_partials)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ovf_header[0] = 0u; ovf_header[1] = cap_slots; ovf_header[2] = cap_entries;                         // OvfHeader
-    ovf_header[3] = 0u; ovf_header[4] = cap_entries; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
+    ovf_header[3] = 0u; ovf_header[4] = cap_partials; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
     for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
     LevelRow *lv = level_rows(hdr);
     CTile *tile = tiles_of(hdr, L);
@@ -551,27 +555,29 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
             const int rest = n - covered, nchunks = (rest + kOvfChunk - 1) / kOvfChunk;
             uint32_t sl = 0, base = 0, pb = 0;
             const int qlane = h % kOvfLanes;
+            const uint32_t npart = nchunks > 1 ? (uint32_t)nchunks : 0u;     // one chunk: rows stored by the chunk kernel
             if (lig == 0) {
                 sl = atomicAdd(&ovf->n_slots, 1u);
                 base = atomicAdd(&ovf->n_entries[qlane], (uint32_t)nchunks);
-                pb = atomicAdd(&ovf->n_partials, (uint32_t)nchunks);
+                if (npart) pb = atomicAdd(&ovf->n_partials, npart);
             }
             sl = __shfl(sl, 0, LPS); base = __shfl(base, 0, LPS); pb = __shfl(pb, 0, LPS);
             if (sl < ovf->cap_slots && base + (uint32_t)nchunks <= ovf->cap_entries &&
-                pb + (uint32_t)nchunks <= ovf->cap_partials) {
+                pb + npart <= ovf->cap_partials) {
                 queued = true;
                 if (lig == 0) {
                     OvfSlot os;
                     os.runs = *br;
                     os.b = b; os.h = h; os.by = by; os.bx = bx;
                     os.Hl = lr.Hl; os.Wl = lr.Wl; os.lstart = lr.lstart; os.pad = 0;
-                    os.pbase = pb; os.n_partials = (uint32_t)nchunks;
+                    os.pbase = pb; os.n_partials = npart;
                     oslots[sl] = os;
                 }
                 for (int c = lig; c < nchunks; c += LPS) {
                     OvfEntry e;
                     e.slot = sl; e.start = (uint32_t)(covered + c * kOvfChunk);
-                    e.count = (uint32_t)min(kOvfChunk, rest - c * kOvfChunk); e.pidx = pb + (uint32_t)c;
+                    e.count = (uint32_t)min(kOvfChunk, rest - c * kOvfChunk);
+                    e.pidx = npart ? pb + (uint32_t)c : kNoPartial;
                     oentries[(size_t)qlane * ovf->cap_entries + base + c] = e;
                 }
             } else {
@@ -612,70 +618,101 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
 }
 
 // ---------------------------------------------------------------- kernel C: queued chunks of long lists
-// One lane group per queued chunk, any (b, h) next to any other in a wave (so flat addresses, no
-// buffer descriptor); sums go into the block's accumulator slot with float atomics.
-template <typename T, int LPS>
+// One WORKGROUP per queued chunk (a fixed grid walks its queue lane with a stride): the lane groups
+// interleave the chunk's batches, meet in LDS, and group 0 either stores the block's rows (a block
+// of one chunk) or leaves the chunk's fp32 partial.
+template <typename T, int LPS, bool BUF>
 __global__ void __launch_bounds__(kRThreads, MMFS_BLK_WAVES)
-msda_bwd_block_overflow(const T *__restrict__ grad_out, const uint4 *__restrict__ records,
-                        const OvfHeader *__restrict__ ovf, const OvfSlot *__restrict__ oslots,
-                        const OvfEntry *__restrict__ oentries, float *__restrict__ oacc, const Dims d)
+msda_bwd_block_overflow(const T *__restrict__ grad_out, T *__restrict__ grad_value,
+                        const uint4 *__restrict__ records, const OvfHeader *__restrict__ ovf,
+                        const OvfSlot *__restrict__ oslots, const OvfEntry *__restrict__ oentries,
+                        float *__restrict__ oacc, const Dims d)
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
     constexpr int GROUPS = kRThreads / LPS;
     constexpr int D = LPS * VEC;
-    __shared__ BlockRuns runs[GROUPS];
+    __shared__ BlockRuns runs;
+    __shared__ float scratch[GROUPS * 4 * D];
     __shared__ uint32_t slots_off[GROUPS * (LPS + 1)];
     __shared__ uint4 slots_w[GROUPS * (LPS + 1) * (kNPX / 4)];
 
     const int tid = threadIdx.x, gid = tid / LPS, lig = tid % LPS;
     const int qlane = blockIdx.x % kOvfLanes;
     const uint32_t n_entries = min(ovf->n_entries[qlane], ovf->cap_entries);
-    // a fixed grid walks the queue lane with a stride (an empty queue costs one small launch)
-    const uint32_t e_step = (uint32_t)(gridDim.x / kOvfLanes) * GROUPS;
-    for (uint32_t e0 = (uint32_t)(blockIdx.x / kOvfLanes) * GROUPS; e0 < n_entries; e0 += e_step) {
-    const uint32_t ei = e0 + gid;
-    const bool act = ei < n_entries;
-    OvfEntry en;
-    en.slot = 0; en.start = 0; en.count = 0; en.pidx = 0;
-    if (act) en = oentries[(size_t)qlane * ovf->cap_entries + ei];
-    const bool live = act && en.count > 0;            // (count 0: a reservation its owner could not use)
-    const OvfSlot *os = oslots + en.slot;
-    if (lig == 0) runs[gid] = os->runs;
-    __builtin_amdgcn_wave_barrier();
-    const BlockRuns *br = &runs[gid];
-
-    const int64_t HD = (int64_t)d.H * d.D;
-    const T *gslice = grad_out + ((int64_t)os->b * d.Nq * d.H + os->h) * d.D + lig * VEC;
-    const uint32_t row_bytes = 1u;                    // flat addresses: a record's offset is its row index
+    const uint32_t e_step = (uint32_t)(gridDim.x / kOvfLanes);
     uint32_t *slot = slots_off + gid * (LPS + 1);
     uint4 *slot4 = slots_w + gid * (LPS + 1) * (kNPX / 4);
-    __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(grad_out, 0);          // unused (flat addresses)
+    const int64_t HD = (int64_t)d.H * d.D;
+    const uint32_t row_bytes = BUF ? (uint32_t)(HD * sizeof(T)) : 1u;
+    const uint32_t lane_off = (uint32_t)(lig * 16);
 
-    float acc[kNPX][VEC];
-#pragma unroll
-    for (int px = 0; px < kNPX; ++px)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
+    for (uint32_t ei = (uint32_t)(blockIdx.x / kOvfLanes); ei < n_entries; ei += e_step) {
+        const OvfEntry en = oentries[(size_t)qlane * ovf->cap_entries + ei];     // uniform over the workgroup
+        if (en.count == 0) continue;                  // a reservation its owner could not use
+        const OvfSlot *os = oslots + en.slot;
+        __syncthreads();                              // the previous chunk's LDS pieces are free
+        if (tid == 0) runs = os->runs;
+        __syncthreads();
+        const int b = os->b, h = os->h;
+        const T *gslice = grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D + lig * VEC;
+        __amdgpu_buffer_rsrc_t rsrc;
+        if (BUF) rsrc = make_slab_rsrc(grad_out + ((int64_t)b * d.Nq * d.H + h) * d.D,
+                                       ((int64_t)d.Nq * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
+        else rsrc = make_slab_rsrc(grad_out, 0);
 
-    const int first = (int)en.start, end = live ? (int)(en.start + en.count) : 0;
-    int nb = live ? ((int)en.count + LPS - 1) / LPS : 0;
-#pragma unroll
-    for (int o = LPS; o < 64; o <<= 1) nb = max(nb, __shfl_xor(nb, o, 64));
-    BlkRec pre = fetch_record(records, br, first + lig, end, row_bytes);
-    for (int j = 0; j < nb; ++j) {
-        const BlkRec cur_rec = pre;
-        if (j + 1 < nb) pre = fetch_record(records, br, first + (j + 1) * LPS + lig, end, row_bytes);
-        consume_batch<T, LPS, false>(cur_rec, lig, slot, slot4, gslice, HD, rsrc, row_bytes, 0u, acc);
-    }
-    if (live) {
-        float *oa = oacc + (size_t)en.pidx * (kNPX * D) + lig * VEC;
+        float acc[kNPX][VEC];
 #pragma unroll
         for (int px = 0; px < kNPX; ++px)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) oa[px * D + i] = acc[px][i];
-    }
-    __builtin_amdgcn_wave_barrier();                  // the group's LDS pieces are reused by the next entry
+            for (int i = 0; i < VEC; ++i) acc[px][i] = 0.f;
+
+        const int first = (int)en.start, end = (int)(en.start + en.count);
+        const int batches = ((int)en.count + LPS - 1) / LPS;
+        const int nb = (batches + GROUPS - 1) / GROUPS;                     // uniform: every group runs nb rounds
+        BlkRec pre = fetch_record(records, &runs, first + gid * LPS + lig, end, row_bytes);
+        for (int j = 0; j < nb; ++j) {
+            const BlkRec cur_rec = pre;
+            if (j + 1 < nb) pre = fetch_record(records, &runs, first + (gid + (j + 1) * GROUPS) * LPS + lig, end, row_bytes);
+            consume_batch<T, LPS, BUF>(cur_rec, lig, slot, slot4, gslice, HD, rsrc, row_bytes, lane_off, acc);
+        }
+        // the groups meet in LDS, 4 pixels per round; group 0 adds them up
+#pragma unroll
+        for (int r0 = 0; r0 < kNPX; r0 += 4) {
+            if (r0 > 0) __syncthreads();
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) scratch[(gid * 4 + px) * D + lig * VEC + i] = acc[r0 + px][i];
+            __syncthreads();
+            if (gid == 0) {
+#pragma unroll 1
+                for (int g2 = 1; g2 < GROUPS; ++g2) {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[r0 + px][i] += scratch[(g2 * 4 + px) * D + lig * VEC + i];
+                }
+            }
+        }
+        if (gid == 0) {
+            if (en.pidx == kNoPartial) {
+#pragma unroll
+                for (int px = 0; px < kNPX; ++px) {
+                    const int y = kBH * os->by + px / kBW, x = kBW * os->bx + px % kBW;
+                    if (y < os->Hl && x < os->Wl) {
+                        T *o = grad_value + (((int64_t)b * d.S + os->lstart + y * os->Wl + x) * d.H + h) * d.D + lig * VEC;
+                        *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+                    }
+                }
+            } else {
+                float *oa = oacc + (size_t)en.pidx * (kNPX * D) + lig * VEC;
+#pragma unroll
+                for (int px = 0; px < kNPX; ++px)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) oa[px * D + i] = acc[px][i];
+            }
+        }
     }
 }
 
@@ -688,6 +725,7 @@ msda_bwd_block_ovf_store(T *__restrict__ grad_value, const OvfHeader *__restrict
     const uint32_t n_slots = min(ovf->n_slots, ovf->cap_slots);
     for (uint32_t sl = blockIdx.x; sl < n_slots; sl += gridDim.x) {
         const OvfSlot os = oslots[sl];
+        if (os.n_partials == 0) continue;             // one chunk: the chunk kernel stored the rows itself
         const float *oa = oacc + (size_t)os.pbase * (kNPX * d.D);
         for (int i = threadIdx.x; i < kNPX * d.D; i += 256) {
             const int px = i / d.D, ch = i - px * d.D;
@@ -733,7 +771,7 @@ struct Scratch {
     OvfSlot *oslots;
     OvfEntry *oentries;
     float *oacc;
-    uint32_t cap_slots, cap_entries;
+    uint32_t cap_slots, cap_entries, cap_partials;
     int64_t cursor_bytes, total;
 };
 
@@ -755,14 +793,16 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     // of its records were walked in place, in chunks of kOvfChunk
     // a block is queued only after >= kCapRecords of its records were walked in place, in chunks of kOvfChunk
     const int64_t visits = pts * (kBH + 1) * (kBW + 1) / (kBH * kBW);
-    // a queued block holds > kCapRecords records and is cut into ceil(n / kOvfChunk) chunks: these
-    // bounds cannot be exceeded (the kernels nevertheless survive it: the owner then finishes in place)
+    // a queued block holds > kCapRecords records and is cut into ceil(n / kOvfChunk) chunks; only blocks
+    // of >= 2 chunks need partials.  These bounds cannot be exceeded (the kernels nevertheless survive it:
+    // the owner then finishes in place)
     s.cap_slots = (uint32_t)std::min<int64_t>(visits / kCapRecords + 64, 0x3fffffff);
     s.cap_entries = (uint32_t)std::min<int64_t>(visits / kOvfChunk + s.cap_slots, 0x3fffffff);
+    s.cap_partials = (uint32_t)std::min<int64_t>(2 * (visits / kOvfChunk) + 64, 0x3fffffff);
     s.ovf = (OvfHeader *)p;      p += up(sizeof(OvfHeader));
     s.oslots = (OvfSlot *)p;     p += up((int64_t)s.cap_slots * sizeof(OvfSlot));
     s.oentries = (OvfEntry *)p;  p += up((int64_t)kOvfLanes * s.cap_entries * sizeof(OvfEntry));   // any lane may take all
-    s.oacc = (float *)p;         p += up((int64_t)s.cap_entries * kNPX * d.D * 4);                        // partial sums
+    s.oacc = (float *)p;         p += up((int64_t)s.cap_partials * kNPX * d.D * 4);                       // partial sums
     s.total = p - (char *)workspace;
     return s;
 }
@@ -775,7 +815,8 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
     hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min, tp.tiles_bound,
-                       (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries);
+                       (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries,
+                       sc.cap_partials);
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                        cell_stride_of(d));
@@ -813,9 +854,13 @@ hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims
                            (const T *)go, (T *)gv, sc.records, sc.celltab, sc.hdr, d, chunks, cell_stride_of(d),
                            sc.ovf, sc.oslots, sc.oentries, sc.oacc);
     // long lists (normally none: both kernels read the queue length on the device and return)
-    const unsigned oblocks = std::min<unsigned>((unsigned)((sc.cap_entries + GROUPS - 1) / GROUPS), 1024u) * kOvfLanes;
-    hipLaunchKernelGGL((msda_bwd_block_overflow<T, LPS>), dim3(oblocks), dim3(kRThreads), 0, st,
-                       (const T *)go, sc.records, sc.ovf, sc.oslots, sc.oentries, sc.oacc, d);
+    const unsigned oblocks = std::min<unsigned>(sc.cap_entries, 512u) * kOvfLanes;
+    if ((int64_t)d.Nq * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes)
+        hipLaunchKernelGGL((msda_bwd_block_overflow<T, LPS, true>), dim3(oblocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.ovf, sc.oslots, sc.oentries, sc.oacc, d);
+    else
+        hipLaunchKernelGGL((msda_bwd_block_overflow<T, LPS, false>), dim3(oblocks), dim3(kRThreads), 0, st,
+                           (const T *)go, (T *)gv, sc.records, sc.ovf, sc.oslots, sc.oentries, sc.oacc, d);
     hipLaunchKernelGGL((msda_bwd_block_ovf_store<T>), dim3(std::min<unsigned>(sc.cap_slots, 1024u)), dim3(256), 0, st,
                        (T *)gv, sc.ovf, sc.oslots, sc.oacc, d);
     return hipGetLastError();
