@@ -152,10 +152,17 @@ int mmfs_msda_backward_value(int dtype,
                              int64_t L, int64_t Nq, int64_t P, void *stream);
 
 /* mmfs_msda_backward_value == _prepare (re-pack loc/attn into the workspace, clear the level
- * cursors), then _sort (count / prefix / scatter the tap contributions by pixel: kernel
- * msda_bwd_value_sort), then _reduce (one lane group per pixel gathers its run of grad_out rows:
- * kernel msda_bwd_value_reduce).  _run == _sort + _reduce.  Exported separately so each kernel can
- * be timed / profiled on its own. */
+ * cursors), then _sort, then _reduce (_run == _sort + _reduce); exported separately so each kernel
+ * can be timed / profiled on its own.  Two generations answer to _sort / _reduce:
+ *   block-stationary (csrc/msda_bwd_block.hip; default for L <= 128 and head rows of 64..512 bytes):
+ *     _sort keys every SAMPLE by the cell of its top-left corner (kernel msda_bwd_cell_sort, one
+ *     16-byte record per sample); _reduce lets a lane group own a 2x2 pixel block and walk the 9
+ *     cell runs that touch it (kernel msda_bwd_block_reduce: 2.25 instead of 4 grad_out row reads
+ *     per sample), queues the lists of hot blocks whole and finishes them with
+ *     msda_bwd_block_overflow / msda_bwd_block_ovf_store;
+ *   pixel-stationary (csrc/msda_bwd_value.hip; the fallback, or MMFS_VALUE_ALGO=pixel): _sort writes
+ *     one record per tap corner sorted by pixel (kernel msda_bwd_value_sort), _reduce lets a lane
+ *     group own one pixel (kernel msda_bwd_value_reduce). */
 int mmfs_msda_backward_value_prepare(int dtype, const void *loc, const void *attn,
                                      void *workspace, int64_t workspace_bytes,
                                      int64_t B, int64_t S, int64_t H, int64_t D,
