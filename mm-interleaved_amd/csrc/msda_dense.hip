@@ -802,9 +802,11 @@ template <typename T, int NS>
 hipError_t launch_value_coarse(const void *loc, const void *attn, const void *go, void *gv, void *partial,
                                const Dims &d, const CoarsePlan &cp, hipStream_t st)
 {
-    const int chunks = value_chunks(d, cp);
     const int q_tiles = (d.Nq + kTileQ - 1) / kTileQ;
-    const int tpc = (q_tiles + chunks - 1) / chunks;
+    const int tpc = (q_tiles + value_chunks(d, cp) - 1) / value_chunks(d, cp);
+    // only chunks that own a tile: the epilogue adds every chunk's partial rows, and a chunk
+    // without tiles would never write its own (e.g. 65 tiles over 32 chunks of 3 -> 22 chunks)
+    const int chunks = (q_tiles + tpc - 1) / tpc;
     const int64_t blocks = (int64_t)d.B * d.H * chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((msda_value_coarse<T, NS>), dim3((unsigned)blocks), dim3(kBT), 0, st,

@@ -110,6 +110,7 @@ HYBRID_CASES = [
     (1, 2, 32, 130, 4, [(16, 16), (3, 3)]),                        # every level dense, D = 32 (idle waves)
     (1, 8, 128, 64, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),    # the north-star pyramid, one full tile
     (1, 2, 64, 97, 16, [(1, 1), (2, 9), (16, 16)]),                # P = 16, degenerate levels
+    (1, 8, 32, 4097, 4, [(16, 13), (40, 6)]),                      # 65 query tiles: the chunking leaves some chunks idle
 ]
 
 

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP op against the CPU oracle (run on the GPU box):
+    python tools/fuzz_op.py [n_cases] [seed] [big]
+Random shapes (every dispatch path: vector / scalar head widths, hybrid routing on and off, both
+grad_value generations, hot spots that overflow the block lists), random location distributions
+(uniform, out of range, clustered on a point, NaN / Inf sprinkled in), all storage types."""
+import os
+import sys
+import random
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd"), os.path.join(ROOT, "tests")]
+import MultiScaleDeformableAttention as MSDA  # noqa: E402
+from oracle import msda_oracle  # noqa: E402
+
+TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+BIG = False
+
+
+def one_case(rng, idx):
+    dtype = rng.choice([torch.float32, torch.float16, torch.bfloat16, torch.bfloat16, torch.float64])
+    B = rng.randint(1, 3)
+    H = rng.choice([1, 2, 3, 4, 8, 16])
+    D = rng.choice([8, 16, 24, 32, 64, 64, 128, 128, 256])
+    P = rng.choice([1, 2, 3, 4, 4, 8, 8, 16])
+    L = rng.randint(1, 6)
+    shapes = [(rng.randint(1, 24), rng.randint(1, 24)) for _ in range(L)]
+    if rng.random() < 0.3:
+        shapes[rng.randrange(L)] = (rng.choice([32, 40]), rng.choice([32, 33]))
+    Nq = rng.choice([1, 7, 31, 32, 33, 64, 100, 257, 600])
+    if BIG:         # enough samples for level splits, chunked hot lists and full queue lanes
+        B, H, D, P = rng.randint(1, 2), rng.choice([4, 8, 16]), rng.choice([32, 64, 128]), rng.choice([4, 8])
+        shapes = [(rng.randint(1, 64), rng.randint(1, 64)) for _ in range(L)]
+        Nq = rng.choice([1024, 3000, 4097])
+    elif B * Nq * H * L * P * D > 6e7:
+        Nq = 33
+    g = torch.Generator().manual_seed(idx)
+    sh = torch.tensor(shapes, dtype=torch.long)
+    st = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    S = int(sh.prod(1).sum())
+    dist = rng.choice(["uniform", "wide", "point", "point", "edge"])
+    loc = torch.rand(B, Nq, H, L, P, 2, generator=g)
+    if dist == "wide":
+        loc = loc * 1.6 - 0.3
+    elif dist == "point":
+        loc = loc * rng.choice([0.02, 0.1, 0.3]) + rng.choice([0.0, 0.45, 0.9])
+    elif dist == "edge":
+        loc = torch.round(loc * 8) / 4 - 0.5      # exact pixel centres / edges, in and out of range
+    if rng.random() < 0.3 and loc.numel() > 8:
+        flat = loc.view(-1)
+        for _ in range(4):
+            flat[rng.randrange(flat.numel())] = rng.choice([float("nan"), float("inf"), -float("inf"), 1e30])
+    value = torch.rand(B, S, H, D, generator=g) - 0.3
+    attn = torch.rand(B, Nq, H, L, P, generator=g) + 1e-5
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    grad = torch.randn(B, Nq, H * D, generator=g)
+    rt = lambda t: t.to(dtype).to(torch.float64)
+    value, loc, attn, grad = rt(value), rt(loc), rt(attn), rt(grad)
+    hybrid = rng.random() < 0.7
+    parts = rng.choice(["taps", "taps", "taps,value", "fwd,taps,value", "fwd"])
+    algo = rng.choice(["block", "block", "pixel"])
+    os.environ["MMFS_VALUE_ALGO"] = algo
+    MSDA._hybrid = hybrid
+    MSDA._hybrid_parts = set(parts.split(","))
+    MSDA._bwd_algo = "atomic" if rng.random() < 0.08 else "auto"
+    dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
+    desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid}:{parts} "
+            f"value={algo} bwd={MSDA._bwd_algo}")
+    out = MSDA.ms_deform_attn_forward(dev(value), dev(sh), dev(st), dev(loc), dev(attn), 1)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(dev(value), dev(sh), dev(st), dev(loc), dev(attn), dev(grad), 1)
+    torch.cuda.synchronize()
+    want = msda_oracle.forward(value, sh, st, loc, attn)
+    wgv, wgl, wga = msda_oracle.backward(value, sh, st, loc, attn, grad)
+    # grad_loc is discontinuous where a pixel coordinate crosses an integer (the bilinear cell
+    # changes); fp32 and fp64 arithmetic can land on different sides, so samples within 1e-4 of a
+    # crossing are left out of the grad_loc comparison (their other outputs are continuous and stay in)
+    pix = loc.numpy() * sh.numpy()[None, None, None, :, None, ::-1] - 0.5
+    with np.errstate(invalid="ignore"):
+        near = (np.abs(pix - np.round(pix)) < 1e-4).any(-1, keepdims=True)
+    near = np.broadcast_to(near, pix.shape)
+    worst = 0.0
+    for name, got, ref in (("out", out, want), ("grad_value", gv, wgv), ("grad_loc", gl, wgl), ("grad_attn", ga, wga)):
+        got = got.double().cpu().numpy().reshape(ref.shape)
+        ok = np.isfinite(ref)
+        if name == "grad_loc":
+            got = np.where(near, ref, got)
+        if not np.array_equal(np.isfinite(got), ok):
+            return f"FAIL {desc}: {name} finiteness differs"
+        err = float(np.abs(got[ok] - ref[ok]).max()) if ok.any() else 0.0
+        scale = max(1.0, float(np.abs(ref[ok]).max())) if ok.any() else 1.0
+        worst = max(worst, err / (TOL[dtype] * scale))
+        if err > TOL[dtype] * scale:
+            return f"FAIL {desc}: {name} err {err:.3e} > {TOL[dtype]:.0e} * {scale:.3g}"
+    return f"ok   {desc}  ({worst:.2f} of the bar)"
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+    rng = random.Random(seed)
+    fails = 0
+    for i in range(n):
+        try:
+            r = one_case(rng, seed * 100000 + i)
+        except Exception as e:          # noqa: BLE001
+            r = f"FAIL #{i}: exception {type(e).__name__}: {e}"
+        if r.startswith("FAIL"):
+            fails += 1
+            print(r, flush=True)
+        elif i % (5 if BIG else 20) == 0:
+            print(r, flush=True)
+    print(f"{n - fails}/{n} cases within the bars", flush=True)
+    sys.exit(1 if fails else 0)
