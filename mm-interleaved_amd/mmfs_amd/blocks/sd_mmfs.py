@@ -99,28 +99,81 @@ class MMFSBlock(nn.Module):
     def _reset_parameters(self):
         self.mmfs._reset_parameters()
 
-    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes):
+    def _pos_table(self, n_tokens):
+        """The position table at this block's resolution.  The reference interpolates it on every
+        call (sd_mmfs.py:127-131); the table is a frozen parameter, so the result only changes when
+        the parameter does -- and the framework's bicubic kernel on a [1, C, 64, 64] map is slow
+        (2.4 ms per call measured on MI355X, 80 % of a whole MMFSNet forward): keep it."""
+        pe = self.pos_embed
+        if pe.requires_grad:                      # someone is training it: stay in the graph
+            return resize_pos_embed(pe, n_tokens)
+        key = (n_tokens, pe.data_ptr(), pe._version, pe.dtype, pe.device)
+        hit = self.__dict__.get("_pos_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, resize_pos_embed(pe, n_tokens))
+            self.__dict__["_pos_cache"] = hit
+        return hit[1]
+
+    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None):
         B, C, H, W = sample.shape
         n_images = ms_feat_mask.shape[-1]
         ref, shapes, start = deform_inputs(sample, spatial_shapes, n_images)
         query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
-        query = query + resize_pos_embed(self.pos_embed, H * W)
-        out = self.mmfs(query, ref, self.feat_norm(ms_feat), shapes, start,
-                        input_padding_mask=None, attention_mask=ms_feat_mask)
+        query = query + self._pos_table(H * W)
+        out = self.mmfs(query, ref, self.feat_norm(ms_feat) if value is None else ms_feat, shapes, start,
+                        input_padding_mask=None, attention_mask=ms_feat_mask, value=value)
+        # the zero-initialised 1x1 convolution (sd_mmfs.py:88-94, 146) is a per-token linear map:
+        # applied on the token-major tensor it is one GEMM each way (the convolution library's 1x1
+        # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
+        if self.conv.kernel_size == (1, 1):
+            out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
+            return out.transpose(1, 2).reshape(B, C, H, W)
         return self.conv(out.transpose(1, 2).reshape(B, C, H, W))
 
-    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes):
+    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None):
         """sample [B, C_q, H, W]; ms_feat [B, n, sum_l H_l*W_l, C_v]; ms_feat_mask [B, n];
-        spatial_shapes: the levels of ONE image, list of (H_l, W_l)  ->  [B, C_q, H, W]."""
+        spatial_shapes: the levels of ONE image, list of (H_l, W_l)  ->  [B, C_q, H, W].
+        ``value`` (an addition to sd_mmfs.py:121-146): this block's
+        ``mmfs.value_proj(feat_norm(ms_feat))`` when the caller already has it (``MMFSNet``)."""
         spatial_shapes = [tuple(int(v) for v in s) for s in spatial_shapes]
         if self.gradient_checkpointing and self.training:
             # the op is stateless and re-entrant: the forward is simply re-run in backward
-            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes,
+            # (a projected ``value`` is an input of the checkpoint: kept, not recomputed)
+            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value,
                                  use_reentrant=False)
-        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes)
+        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value)
+
+
+class ProjectedFeatures:
+    """``value_proj(feat_norm(bank))`` of every block of an ``MMFSNet`` for one feature bank:
+    ``values[k]`` is block k's [B, n, sum_l H_l*W_l, d_inner] (the mid block last).  Made by
+    ``MMFSNet.project_features``; accepted by ``MMFSNet.forward`` in place of the feature list."""
+
+    def __init__(self, values, bank, shapes, sources=None, weights=None):
+        self.values, self.bank, self.shapes = values, bank, shapes
+        # what it was computed from (identity cache of MMFSNet.forward): the feature tensors with
+        # their versions, and (storage, version) of every parameter that went in
+        self.sources, self.weights = sources, weights
+
+    def matches(self, feats, weights):
+        return (self.sources is not None and len(feats) == len(self.sources) and weights == self.weights
+                and all(f is s and f._version == v for f, (s, v) in zip(feats, self.sources)))
 
 
 class MMFSNet(nn.Module):
+    # The 13 blocks read the SAME feature bank (sd_mmfs.py:247-270).  With ``fused_schedule`` the
+    # bank is normalised once -- LayerNorm statistics do not depend on the block, only the affine
+    # does, and that folds into the projection:
+    #     value_proj_k(gamma_k * xhat + beta_k) = (W_k diag(gamma_k)) xhat + (W_k beta_k + b_k)
+    # -- and each block gets its value projection from the shared xhat: 1 normalisation pass over
+    # the [B, n, 5440, 1024] bank instead of 13.  ``cache_projected_features``: outside autograd
+    # (sampling: 30 denoising steps x the same feature tensors, sd_pipeline_monkey_patch.py:172-200)
+    # the projections of the last bank are kept and reused while the caller passes the same,
+    # unmodified feature tensors.  Both are additions; off -> the reference's schedule.
+    fused_schedule = True
+    cache_projected_features = True
+
     def __init__(self, input_channel, block_out_channels, layers_per_block, downsample_factor=1,
                  n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]):
         super().__init__()
@@ -154,14 +207,61 @@ class MMFSNet(nn.Module):
             blk._reset_parameters()
         self.mmfs_mid_block._reset_parameters()
 
-    def forward(self, sample, down_block_res_samples, mmfs_features, mmfs_mask):
-        """sample: mid-block input; down_block_res_samples: the UNet's down residuals;
-        mmfs_features: per level [B, n, C, h_l, w_l]; mmfs_mask [B, n]
-        -> (sample', tuple of residuals')   (sd_mmfs.py:230-272)."""
-        assert len(down_block_res_samples) == len(self.mmfs_down_blocks)
+    def _blocks(self):
+        return list(self.mmfs_down_blocks) + [self.mmfs_mid_block]
+
+    def _can_fuse(self):
+        blocks = self._blocks()
+        n0, v0 = blocks[0].feat_norm, blocks[0].mmfs.value_proj
+        return all(isinstance(b.feat_norm, nn.LayerNorm) and b.feat_norm.elementwise_affine
+                   and b.feat_norm.bias is not None
+                   and b.feat_norm.normalized_shape == n0.normalized_shape and b.feat_norm.eps == n0.eps
+                   and b.mmfs.value_proj.weight.shape == v0.weight.shape for b in blocks)
+
+    def project_features(self, mmfs_features):
+        """Per level [B, n, C, h_l, w_l] -> ``ProjectedFeatures``: the bank normalised ONCE, then
+        every block's value projection with its LayerNorm affine folded into the weights."""
         shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
         bank = torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)   # b n (h w) c
-        new_res = tuple(r + blk(r, bank, mmfs_mask, shapes)
-                        for r, blk in zip(down_block_res_samples, self.mmfs_down_blocks))
-        sample = sample + self.mmfs_mid_block(sample, bank, mmfs_mask, shapes)
+        norm = self.mmfs_mid_block.feat_norm
+        xhat = F.layer_norm(bank, norm.normalized_shape, None, None, norm.eps)
+        values = []
+        for blk in self._blocks():
+            proj, ln = blk.mmfs.value_proj, blk.feat_norm
+            bias = F.linear(ln.bias, proj.weight, proj.bias)
+            values.append(F.linear(xhat, proj.weight * ln.weight, bias))
+        return ProjectedFeatures(values, bank, shapes, [(f, f._version) for f in mmfs_features],
+                                 self._projection_weights())
+
+    def _projection_weights(self):
+        return tuple((p.data_ptr(), p._version) for b in self._blocks()
+                     for p in (b.feat_norm.weight, b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias))
+
+    def clear_feature_cache(self):
+        self.__dict__.pop("_projected", None)
+
+    def forward(self, sample, down_block_res_samples, mmfs_features, mmfs_mask):
+        """sample: mid-block input; down_block_res_samples: the UNet's down residuals;
+        mmfs_features: per level [B, n, C, h_l, w_l] (or a ``ProjectedFeatures``); mmfs_mask [B, n]
+        -> (sample', tuple of residuals')   (sd_mmfs.py:230-272)."""
+        assert len(down_block_res_samples) == len(self.mmfs_down_blocks)
+        proj = mmfs_features if isinstance(mmfs_features, ProjectedFeatures) else None
+        if proj is None and self.fused_schedule and self._can_fuse():
+            keep = self.cache_projected_features and not torch.is_grad_enabled()
+            proj = self.__dict__.get("_projected") if keep else None
+            if proj is None or not proj.matches(mmfs_features, self._projection_weights()):
+                proj = self.project_features(mmfs_features)
+            if keep:
+                self.__dict__["_projected"] = proj
+            else:
+                self.clear_feature_cache()
+        if proj is not None:
+            bank, shapes, values = proj.bank, proj.shapes, proj.values
+        else:
+            shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
+            bank = torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)   # b n (h w) c
+            values = [None] * (len(self.mmfs_down_blocks) + 1)
+        new_res = tuple(r + blk(r, bank, mmfs_mask, shapes, value=v)
+                        for r, blk, v in zip(down_block_res_samples, self.mmfs_down_blocks, values))
+        sample = sample + self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1])
         return sample, new_res

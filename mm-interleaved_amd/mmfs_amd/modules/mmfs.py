@@ -171,8 +171,10 @@ class MMFS(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, attention_mask=None):
-        """Arguments and result as mmfs.py:120-141:
+                input_level_start_index, input_padding_mask=None, attention_mask=None, value=None):
+        """Arguments and result as mmfs.py:120-141 (``value`` is an addition: the caller's own
+        ``value_proj(input_flatten)`` [N, n, hw, d_inner], e.g. one an ``MMFSNet`` projected for
+        all its blocks at once; ``input_flatten`` is then only looked at for its shape):
         query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
         input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
         input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
@@ -184,7 +186,10 @@ class MMFS(nn.Module):
             assert int((host[:, 0] * host[:, 1]).sum()) == n * hw, (host.tolist(), n * hw)
         assert input_spatial_shapes.shape[0] == n * self.n_levels
 
-        value = self.value_proj(input_flatten)
+        if value is None:
+            value = self.value_proj(input_flatten)
+        else:
+            assert value.shape == (N, n, hw, self.d_inner), (value.shape, (N, n, hw, self.d_inner))
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.reshape(N, n * hw, self.n_heads, self.d_inner // self.n_heads).contiguous()

@@ -181,6 +181,83 @@ def test_sd_mmfs_net_matches_reference(oracle_op):
         close(r, z[f"new_res.{i}"], 1e-10)
 
 
+def _tiny_net(z, **kw):
+    from mmfs_amd.blocks import MMFSNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                      downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                      spatial_shapes=[64, 32, 16], **kw).double()
+    load_params(net, z)
+    torch.manual_seed(3)
+    with torch.no_grad():                         # the fixture's conv is the reference's zero init
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    return net
+
+
+def test_sd_mmfs_net_fused_schedule_equals_the_references(oracle_op):
+    """One normalisation of the bank + folded affines (MMFSNet.fused_schedule) against the
+    reference's schedule (13 LayerNorms + 13 projections): outputs, input grads, every parameter grad."""
+    z = load_golden("block_sd_mmfs_net")
+    outs = []
+    for fused in (False, True):
+        net = _tiny_net(z)
+        net.fused_schedule = fused
+        res = [T(z[f"res.{i}"]).requires_grad_(True) for i in range(6)]
+        feats = [T(z[f"feat.{i}"]).requires_grad_(True) for i in range(3)]
+        mid = T(z["mid"]).requires_grad_(True)
+        new_mid, new_res = net(mid, res, feats, T(z["ms_mask"]))
+        g = torch.Generator().manual_seed(5)
+        loss = (new_mid * torch.randn(new_mid.shape, generator=g, dtype=torch.float64)).sum()
+        for r in new_res:
+            loss = loss + (r * torch.randn(r.shape, generator=g, dtype=torch.float64)).sum()
+        loss.backward()
+        outs.append(dict(mid=new_mid.detach(), res=[r.detach() for r in new_res],
+                         gfeat=[f.grad for f in feats], gres=[r.grad for r in res],
+                         gparam={k: p.grad for k, p in net.named_parameters() if p.grad is not None}))
+    a, b = outs
+    close(b["mid"], a["mid"], 1e-11)
+    for x, y in zip(b["res"] + b["gfeat"] + b["gres"], a["res"] + a["gfeat"] + a["gres"]):
+        close(x, y, 1e-10)
+    assert sorted(a["gparam"]) == sorted(b["gparam"])
+    assert any("feat_norm.weight" in k for k in a["gparam"])
+    for k in a["gparam"]:
+        close(b["gparam"][k], a["gparam"][k], 1e-9)
+
+
+def test_sd_mmfs_net_reuses_projections_while_sampling(oracle_op):
+    """Outside autograd the projected bank is kept for as long as the caller passes the same,
+    unmodified feature tensors and the parameters do not move (denoising loop); anything else
+    recomputes.  ProjectedFeatures can also be made once and handed in."""
+    z = load_golden("block_sd_mmfs_net")
+    net = _tiny_net(z).eval()
+    calls = []
+    inner = net.project_features
+    net.project_features = lambda feats: (calls.append(1), inner(feats))[1]
+    res = [T(z[f"res.{i}"]) for i in range(6)]
+    feats = [T(z[f"feat.{i}"]) for i in range(3)]
+    mask, mid = T(z["ms_mask"]), T(z["mid"])
+    with torch.no_grad():
+        first = net(mid, res, feats, mask)
+        again = net(mid * 0.5, [r * 2 for r in res], feats, mask)       # next denoising step: new samples
+        assert len(calls) == 1
+        close(net(mid, res, feats, mask)[0], first[0], 0.0)
+        assert len(calls) == 1
+        feats[1].add_(torch.randn(feats[1].shape, dtype=torch.float64))    # features changed in place
+        changed = net(mid, res, feats, mask)
+        assert len(calls) == 2 and float((changed[0] - first[0]).abs().max()) > 1e-6
+        net.mmfs_mid_block.mmfs.value_proj.weight.mul_(0.9)             # parameters moved
+        net(mid, res, feats, mask)
+        assert len(calls) == 3
+        net(mid, res, [f.clone() for f in feats], mask)                 # other tensors, same content
+        assert len(calls) == 4
+        proj = inner(feats)                                             # explicit hand-over
+        close(net(mid, res, proj, mask)[0], net(mid, res, feats, mask)[0], 0.0)
+    net(mid, res, feats, mask)                                          # under autograd: no cache kept
+    assert "_projected" not in net.__dict__
+    del again
+
+
 def test_ms_deform_attn_module(oracle_op):
     """Encoder twin: shapes, init (directional bias, zero weights) and agreement with a
     by-hand evaluation through the oracle."""

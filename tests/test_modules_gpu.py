@@ -172,3 +172,33 @@ def test_fused_sampling_plan_matches_framework_ops(n, mask_kind):
     for a, b in zip(res[True], res[False]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 2e-4 * scale, float((a - b).abs().max())
+
+
+def test_graphed_mmfs_net_replays_the_eager_schedule():
+    """mmfs_amd.graphs.GraphedMMFSNet: the 7-block toy net recorded into a HIP graph, replayed on
+    new residuals, against the eager call -- bit-equal (same kernels, same order)."""
+    from mmfs_amd.blocks import MMFSNet
+    from mmfs_amd.graphs import GraphedMMFSNet
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV).eval()
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    mid = T(z["mid"], torch.float32)
+    res = [T(z[f"res.{i}"], torch.float32) for i in range(6)]
+    feats = [T(z[f"feat.{i}"], torch.float32) for i in range(3)]
+    mask = T(z["ms_mask"], None)
+    graphed = GraphedMMFSNet(net, mid, res, feats, mask)
+    for step in range(3):                           # new residuals each denoising step
+        mid2 = mid * (1.0 + 0.5 * step) + step
+        res2 = [r.flip(0) * (step + 1) for r in res]
+        with torch.no_grad():
+            want = net(mid2, res2, feats, mask)
+        got = graphed(mid2, res2)
+        assert torch.equal(got[0], want[0])
+        assert all(torch.equal(a, b) for a, b in zip(got[1], want[1]))
+        assert float((want[0] - mid2).abs().max()) > 1e-4       # the blocks did contribute
