@@ -50,6 +50,12 @@ WORKLOADS = {
                          shapes=[(64, 64), (32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
     "cfg5_llm_n4": dict(B=4, Nq=2048, H=16, D=64, P=8,
                         shapes=[(32, 32), (16, 16), (8, 8)], n=4, dtype="bf16"),
+    # the ViT-Adapter's encoder-side calls at 224 px (vit_adapter_hf.py:112-133,
+    # adapter_modules.py:30-49: ViT-L, deform_ratio 0.5 -> D=32, P=4), 32 images per GPU: the injector
+    # (256 ViT tokens sample the 32^2/16^2/8^2 pyramid) and the extractor (the 1344 pyramid tokens
+    # sample the 16^2 ViT map); 5 of each per ViT forward
+    "enc_injector": dict(B=32, Nq=256, H=16, D=32, P=4, shapes=[(32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
+    "enc_extractor": dict(B=32, Nq=1344, H=16, D=32, P=4, shapes=[(16, 16)], n=1, dtype="bf16"),
 }
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 

@@ -385,7 +385,9 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     void *partial = (char *)workspace + base;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE))
+    // (every level dense -- e.g. the ViT-Adapter extractor's single 16x16 map -- leaves the row-gather
+    // kernel nothing to write: not launched)
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && !(dense_taps && plan.fine_taps.n == 0))
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
                                 d, false, st, dense_taps ? &plan.fine_taps : nullptr);
     if (e == hipSuccess && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
