@@ -280,6 +280,28 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
                        int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
                        int64_t Lr, int64_t Nr, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-image feature bank: MMFS's ``input_flatten`` built in one pass.
+ * Replaces the Python loops of mm_interleaved/models/mm_interleaved.py:223-250 (zero-filled
+ * [B, n, C, h, w] buffers per level, per-sequence slice copies, "b n c h w -> b n (h w) c", concatenation
+ * over levels) and the rearrange + concatenation of decoders/sd_mmfs.py:241-245.
+ *   level_ptrs [n_levels]  HOST array of DEVICE pointers: level l is [n_img, C, hw_l] (channel-major,
+ *                          contiguous), storage dtype;   level_hw [n_levels]  HOST array: hw_l = h_l * w_l
+ *   src_index  [n_slots]   device int64: the image a bank slot shows; < 0 or >= n_img -> a zero slot
+ *   bank       [n_slots, sum_l hw_l, C]   token-major, levels in list order, fully written
+ * mmfs_bank_scatter is the adjoint (needed when the image encoder is trained):
+ *   grad_level_ptrs[l] [n_img, C, hw_l] = sum over the slots s with src_index[s] == image of
+ *   grad_bank[s] (fp32 accumulation, slots in ascending order, rounded once); fully written, images
+ *   no slot shows get zeros.  No atomics: bit-reproducible.
+ * Limits: n_levels <= 8, n_slots <= 65535 (gather) / n_img <= 65535 (scatter); dtypes f32, f16, bf16.
+ */
+int mmfs_bank_gather(int dtype, int n_levels, const void *const *level_ptrs, const int64_t *level_hw,
+                     const int64_t *src_index, void *bank, int64_t n_img, int64_t C, int64_t n_slots,
+                     void *stream);
+int mmfs_bank_scatter(int dtype, int n_levels, void *const *grad_level_ptrs, const int64_t *level_hw,
+                      const int64_t *src_index, const void *grad_bank, int64_t n_img, int64_t C,
+                      int64_t n_slots, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,8 +10,25 @@ have been encoded on other ranks; ``all_gather_image_features`` brings the per-i
 multiscale features together with ONE all_gather_into_tensor (RCCL over xGMI; the
 reference has no counterpart, its ranks never exchange features) and the builders then
 index into the gathered tensor exactly as they would on a single rank.
+
+On device tensors the bank itself -- gather over images, channel-major -> token-major transposition,
+concatenation over levels, zero slots -- is ONE kernel pass (``gather_bank``: csrc/mmfs_bank.hip,
+SURVEY.md 8f N2); host tensors (the gloo tests) take the same steps with framework ops.
 """
 import torch
+
+
+def gather_bank(levels, src_index):
+    """levels: per-level [N_img, C, h_l, w_l]; src_index [n_slots] long (negative: empty slot)
+    -> [n_slots, sum_l h_l*w_l, C], levels in list order, empty slots zero."""
+    from .functions.bank_func import BankGatherFunction, bank_gather_supported
+    if bank_gather_supported(levels, src_index.numel()):
+        return BankGatherFunction.apply(src_index, *levels)
+    packed = torch.cat([f.flatten(2).transpose(1, 2) for f in levels], dim=1)
+    idx = src_index.to(packed.device)
+    valid = (idx >= 0) & (idx < packed.shape[0])
+    rows = packed.index_select(0, idx.clamp(0, max(packed.shape[0] - 1, 0)))
+    return rows * valid[:, None, None].to(rows.dtype)
 
 
 # ------------------------------------------------------------------ LLM side
@@ -40,6 +57,8 @@ def pack_image_levels(multiscale_features, spatial_sides=None):
     """List of per-level [N_img, C, h, w] -> [N_img, sum_l h*w, C] (levels in list order).
     ``spatial_sides``: keep only levels whose side is listed (mm_interleaved.py:223-227)."""
     keep = [f for f in multiscale_features if spatial_sides is None or int(f.shape[-1]) in spatial_sides]
+    if keep[0].is_cuda:                           # one transposing pass instead of a strided concatenation
+        return gather_bank(keep, torch.arange(keep[0].shape[0], device=keep[0].device))
     return torch.cat([f.flatten(2).transpose(1, 2) for f in keep], dim=1)
 
 
@@ -55,14 +74,27 @@ def llm_feature_bank(packed, num_image_per_seq, max_num_image):
     return bank * valid[:, :, None, None].to(bank.dtype)
 
 
+def llm_feature_bank_from_levels(levels, num_image_per_seq, max_num_image):
+    """Per-level [N_img, C, h, w] (images of all sequences, in order) -> [B, N, sum hw, C]: the
+    same bank as ``llm_feature_bank(pack_image_levels(levels), ...)`` without the packed
+    intermediate -- slot (b, k) shows image first_b + k, or nothing."""
+    dev = levels[0].device
+    num = num_image_per_seq.to(dev).long()
+    first = num.cumsum(0) - num
+    k = torch.arange(max_num_image, device=dev)
+    src = torch.where(k[None, :] < num[:, None], first[:, None] + k[None, :], torch.full_like(k, -1)[None, :])
+    bank = gather_bank(levels, src.reshape(-1))
+    return bank.reshape(num.shape[0], max_num_image, *bank.shape[1:])
+
+
 def prepare_mmfs_features_for_mm_decoder(text_ids, num_image_per_seq, multiscale_features, *,
                                          bos_token_id, soi_token_id, spatial_shapes, max_num_image=None):
     """Drop-in for the reference method: returns {'cross_attention_mask', 'mmfs_features_mm'}."""
     if max_num_image is None:
         max_num_image = int(num_image_per_seq.max())                     # sync; pass it to avoid
     mask = llm_cross_attention_mask(text_ids, max_num_image, bos_token_id, soi_token_id)
-    bank = llm_feature_bank(pack_image_levels(multiscale_features, spatial_shapes), num_image_per_seq,
-                            max_num_image)
+    keep = [f for f in multiscale_features if spatial_shapes is None or int(f.shape[-1]) in spatial_shapes]
+    bank = llm_feature_bank_from_levels(keep, num_image_per_seq, max_num_image)
     return {"cross_attention_mask": mask, "mmfs_features_mm": bank}
 
 

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 from torch import nn
 
+from ..bank import gather_bank
 from ..levels import make_level_tables
 from ..modules.mmfs import MMFS
 
@@ -222,7 +223,7 @@ class MMFSNet(nn.Module):
         """Per level [B, n, C, h_l, w_l] -> ``ProjectedFeatures``: the bank normalised ONCE, then
         every block's value projection with its LayerNorm affine folded into the weights."""
         shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
-        bank = torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)   # b n (h w) c
+        bank = self._pack(mmfs_features)
         norm = self.mmfs_mid_block.feat_norm
         xhat = F.layer_norm(bank, norm.normalized_shape, None, None, norm.eps)
         values = []
@@ -236,6 +237,17 @@ class MMFSNet(nn.Module):
     def _projection_weights(self):
         return tuple((p.data_ptr(), p._version) for b in self._blocks()
                      for p in (b.feat_norm.weight, b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias))
+
+    @staticmethod
+    def _pack(mmfs_features):
+        """Per level [B, n, C, h, w] -> [B, n, sum_l h*w, C] ("b n c h w -> b n (h w) c" + concatenation,
+        sd_mmfs.py:241-245); on the device one transposing pass (csrc/mmfs_bank.hip)."""
+        f0 = mmfs_features[0]
+        B, n = f0.shape[:2]
+        if f0.is_cuda:
+            bank = gather_bank([f.flatten(0, 1) for f in mmfs_features], torch.arange(B * n, device=f0.device))
+            return bank.view(B, n, *bank.shape[1:])
+        return torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)
 
     def clear_feature_cache(self):
         self.__dict__.pop("_projected", None)
@@ -259,7 +271,7 @@ class MMFSNet(nn.Module):
             bank, shapes, values = proj.bank, proj.shapes, proj.values
         else:
             shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
-            bank = torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)   # b n (h w) c
+            bank = self._pack(mmfs_features)
             values = [None] * (len(self.mmfs_down_blocks) + 1)
         new_res = tuple(r + blk(r, bank, mmfs_mask, shapes, value=v)
                         for r, blk, v in zip(down_block_res_samples, self.mmfs_down_blocks, values))
