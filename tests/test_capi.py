@@ -56,6 +56,29 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.mmfs_msda_status_string(-99) is not None
 
 
+def test_bank_entry_points_validate_on_the_host():
+    """mmfs_bank_gather / mmfs_bank_scatter: argument errors and empty problems return before any launch."""
+    lib = ctypes.CDLL(LIB)
+    i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+    for f in (lib.mmfs_bank_gather, lib.mmfs_bank_scatter):
+        f.restype = ci
+        f.argtypes = [ci, ci, vp, vp, vp, vp, i64, i64, i64, vp]
+    ptrs = (vp * 2)(0x1000, 0x2000)                   # never dereferenced on these paths
+    hw = (i64 * 2)(64, 16)
+    P, H = ctypes.cast(ptrs, vp), ctypes.cast(hw, vp)
+    for f in (lib.mmfs_bank_gather, lib.mmfs_bank_scatter):
+        assert f(3, 2, P, H, None, None, 4, 8, 4, None) == -1          # fp64 is not a bank dtype
+        assert f(2, 0, P, H, None, None, 4, 8, 4, None) == -5          # no levels
+        assert f(2, 9, P, H, None, None, 4, 8, 4, None) == -5          # more than 8 levels
+        assert f(2, 2, None, H, None, None, 4, 8, 4, None) == -3       # no level table
+        assert f(2, 2, P, H, None, None, 4, -8, 4, None) == -2         # negative width
+        assert f(2, 2, P, ctypes.cast((i64 * 2)(64, 0), vp), None, None, 4, 8, 4, None) == -2   # empty level
+        assert f(2, 2, P, H, None, None, 4, 8, 4, None) == -3          # non-empty problem, null tensors
+    assert lib.mmfs_bank_gather(2, 2, P, H, None, None, 4, 8, 0, None) == 0      # no slots
+    assert lib.mmfs_bank_gather(2, 2, P, H, None, None, 4, 8, 70000, None) == -2  # slot axis exceeds the grid
+    assert lib.mmfs_bank_scatter(2, 2, P, H, None, None, 0, 8, 4, None) == 0     # no images
+
+
 def test_shim_has_the_reference_surface_and_no_cpu_path():
     import MultiScaleDeformableAttention as MSDA
     assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
