@@ -32,7 +32,12 @@ constexpr int kThreads = 1024;          // sort: 16 waves per workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTileCells = 4096;     // cells per sort tile (two counter arrays of 16 KiB)
 constexpr int kScanUnroll = 4;
-constexpr int kMaxLevels = 128;         // level rows cached in LDS by the reduce
+constexpr int kMaxLevels = 128;         // levels the block path takes
+constexpr int kLdsLevels = 32;          // level rows the reduce keeps in LDS (beyond: read from the table)
+#ifndef MMFS_BLK_ROUND
+#define MMFS_BLK_ROUND 2
+#endif
+constexpr int kRoundPx = MMFS_BLK_ROUND; // pixels per LDS round when split blocks add up their parts
 
 struct CTile {
     int level, Hl, Wl, cbase;           // cbase: the level's first entry in the cell table
@@ -449,9 +454,9 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     constexpr int GROUPS = kRThreads / LPS;          // lane groups per workgroup
     constexpr int D = LPS * VEC;
     static_assert(GROUPS % kMaxSplit == 0, "a block's lane groups must share a workgroup");
-    __shared__ LevelRow lvs[kMaxLevels];
+    __shared__ LevelRow lvs[kLdsLevels];
     __shared__ BlockRuns runs[GROUPS];
-    __shared__ float scratch[GROUPS * 4 * D];        // partial sums of split blocks, 4 pixels per round
+    __shared__ float scratch[GROUPS * kRoundPx * D];  // partial sums of split blocks, kRoundPx pixels per round
     __shared__ uint32_t slots_off[GROUPS * (LPS + 1)];
     __shared__ uint4 slots_w[GROUPS * (LPS + 1) * (kNPX / 4)];
 
@@ -463,7 +468,8 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     const int gid = tid / LPS, lig = tid % LPS;
     const int n_blocks = hdr->n_blocks;              // virtual blocks: block x split
     if (chunk * GROUPS >= n_blocks) return;          // whole workgroup beyond the last block
-    for (int i = tid; i < d.L; i += kRThreads) lvs[i] = level_rows(hdr)[i];
+    const LevelRow *grows = level_rows(hdr);
+    for (int i = tid; i < min(d.L, kLdsLevels); i += kRThreads) lvs[i] = grows[i];
     __syncthreads();
 
     uint32_t *slot = slots_off + gid * (LPS + 1);
@@ -472,8 +478,8 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
 
     // virtual block -> (level, block, part)
     int l = 0;
-    while (l + 1 < d.L && vb >= lvs[l + 1].bbase) ++l;
-    const LevelRow lr = lvs[l];
+    while (l + 1 < d.L && vb >= (l + 1 < kLdsLevels ? lvs[l + 1].bbase : grows[l + 1].bbase)) ++l;
+    const LevelRow lr = l < kLdsLevels ? lvs[l] : grows[l];
     const int rel = vb - lr.bbase;
     const int split = lr.split;
     const int blk = rel / split, part = rel - blk * split;
@@ -532,19 +538,19 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     // split blocks: the parts meet in LDS, part 0 adds them up (uniform decision per workgroup is not
     // possible -- levels may change inside a workgroup -- so every workgroup passes the two barriers)
 #pragma unroll
-    for (int r0 = 0; r0 < kNPX; r0 += 4) {
+    for (int r0 = 0; r0 < kNPX; r0 += kRoundPx) {
         if (r0 > 0) __syncthreads();
 #pragma unroll
-        for (int px = 0; px < 4; ++px)
+        for (int px = 0; px < kRoundPx; ++px)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) scratch[(gid * 4 + px) * D + lig * VEC + i] = acc[r0 + px][i];
+            for (int i = 0; i < VEC; ++i) scratch[(gid * kRoundPx + px) * D + lig * VEC + i] = acc[r0 + px][i];
         __syncthreads();
         if (act && part == 0) {
             for (int s2 = 1; s2 < split; ++s2) {
 #pragma unroll
-                for (int px = 0; px < 4; ++px)
+                for (int px = 0; px < kRoundPx; ++px)
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[r0 + px][i] += scratch[((gid + s2) * 4 + px) * D + lig * VEC + i];
+                    for (int i = 0; i < VEC; ++i) acc[r0 + px][i] += scratch[((gid + s2) * kRoundPx + px) * D + lig * VEC + i];
             }
         }
     }
