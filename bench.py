@@ -85,7 +85,7 @@ def algorithmic_bytes(w, e):
                 msda_bwd_taps_coarse=taps_dense, msda_bwd_taps_fine=taps_fine)
 
 
-def make_inputs(w, device, seed, loc_dist="uniform"):
+def make_inputs(w, device, seed, loc_dist="uniform", visible="all"):
     g = torch.Generator(device=device).manual_seed(seed)
     dt = DTYPES[w["dtype"]]
     shapes = torch.tensor(w["shapes"] * w["n"], dtype=torch.long, device=device)
@@ -100,6 +100,13 @@ def make_inputs(w, device, seed, loc_dist="uniform"):
         loc = 0.5 + (loc - 0.5) * 16.0 / px                                    # +-8 pixels around the centre
     loc = loc.to(dt)
     attn = torch.rand(B, Nq, H, L, P, device=device, generator=g) + 1e-5
+    if visible == "causal" and w["n"] > 1:
+        # the LLM path's mask (mm_interleaved.py:199-221): token q sees image k only if the image
+        # comes before it -- here image k of n enters at query k * Nq / n; what a token cannot see
+        # gets exactly 0 from MMFS's masked softmax (mmfs.py:203-231)
+        img = torch.arange(L, device=device) // (L // w["n"])
+        vis = torch.arange(Nq, device=device)[:, None] * w["n"] >= img[None, :] * Nq            # [Nq, L]
+        attn = attn * vis[None, :, None, :, None]
     attn = (attn / attn.sum((-1, -2), keepdim=True)).to(dt)
     grad = torch.randn(B, Nq, H * D, device=device, generator=g).to(dt)
     return value, shapes, start, loc, attn, grad
@@ -146,6 +153,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel events (one C call per pass); prints ms/step only")
+    ap.add_argument("--visible", default="all", choices=["all", "causal"],
+                    help="causal: image k of n is visible to the queries after k/n of the sequence, zero attention elsewhere")
     ap.add_argument("--loc-dist", default="uniform", choices=["uniform", "centre"],
                     help="sampling locations: uniform over each level (the contract workload) or clustered "
                          "around one reference point (what the LLM path produces)")
@@ -172,7 +181,7 @@ def main():
         w["Nq"] = args.nq
     if args.dtype:
         w["dtype"] = args.dtype
-    value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank, loc_dist=args.loc_dist)
+    value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank, loc_dist=args.loc_dist, visible=args.visible)
     value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
 
     def step():
@@ -237,7 +246,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": w["dtype"], "data": "synthetic",
-            "config": {"workload": f"{args.workload}{'' if args.loc_dist == 'uniform' else '@' + args.loc_dist}: ms_deform_attn fwd+bwd, per-GPU B={w['B']} Nq={w['Nq']} "
+            "config": {"workload": f"{args.workload}{'' if args.loc_dist == 'uniform' else '@' + args.loc_dist}{'' if args.visible == 'all' else '@' + args.visible}: ms_deform_attn fwd+bwd, per-GPU B={w['B']} Nq={w['Nq']} "
                                    f"L={Leff} H={w['H']} P={w['P']} C={w['H'] * w['D']} S={sum(h * x for h, x in w['shapes']) * w['n']}",
                        "global_batch": world * w["B"], "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -223,7 +223,9 @@ __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q,
 {
     const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
     const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
-    if (!inside) return;
+    // a sample whose attention weight is exactly zero adds nothing to grad_value (images a token
+    // cannot see get exactly 0 from the masked softmax, mmfs.py:203-231): no record for it
+    if (!inside || a == 0.f) return;
     const float yf = floorf(y), xf = floorf(x);
     const int cy = (int)yf + 1, cx = (int)xf + 1;
     if (cy < tl.ya || cy >= tl.yb || cx < tl.xa || cx >= tl.xb) return;
@@ -248,7 +250,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
             const int64_t s0 = s_first + (int64_t)q * d.P;
             for (int p = 0; p < d.P; ++p)
                 visit_sample<MODE>(to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]),
-                                   MODE == kScatter ? to_f32(attn[s0 + p]) : 0.f, q, tl, tw, off, cur, list);
+                                   to_f32(attn[s0 + p]), q, tl, tw, off, cur, list);
         }
         return;
     }
@@ -265,8 +267,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
 #pragma unroll
             for (int v = 0; v < NVV; ++v) {
                 lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
-                if (MODE == kScatter) araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
-                else araw[u][v] = make_uint2(0u, 0u);
+                araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];     // (both passes: zero weights are skipped)
             }
         }
 #pragma unroll

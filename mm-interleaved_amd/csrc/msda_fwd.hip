@@ -109,7 +109,11 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 const Tap<float> t = locate<float>(lx, ly, (int)shapes[2 * l], (int)shapes[2 * l + 1],
                                                    (int)start[l]);
                 const float gy = 1.f - t.fy, gx = 1.f - t.fx;
-                rec.row[0] = t.row[0]; rec.row[1] = t.row[1]; rec.row[2] = t.row[2]; rec.row[3] = t.row[3];
+                // a zero attention weight (an image the token cannot see: the masked softmax gives
+                // exactly 0, mmfs.py:203-231) reads no rows at all -- it is marked "outside"
+                if (a != 0.f) {
+                    rec.row[0] = t.row[0]; rec.row[1] = t.row[1]; rec.row[2] = t.row[2]; rec.row[3] = t.row[3];
+                }
                 rec.w[0] = gy * gx * a; rec.w[1] = gy * t.fx * a;
                 rec.w[2] = t.fy * gx * a; rec.w[3] = t.fy * t.fx * a;
             }
@@ -131,13 +135,24 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 uint4 raw[kUnroll][4];
                 float w[kUnroll][4];
                 bool ok[kUnroll][4];
+                uint4 rrs[kUnroll];
+                uint32_t any_w = 0u;
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    const uint4 rr = recs[2 * (kk + u)];
+                    rrs[u] = recs[2 * (kk + u)];
                     const uint4 ww = recs[2 * (kk + u) + 1];
-                    const int rows[4] = {(int)rr.x, (int)rr.y, (int)rr.z, (int)rr.w};
+                    any_w |= (ww.x | ww.y | ww.z | ww.w) << 1;          // (sign bit aside: -0 is zero too)
                     w[u][0] = __uint_as_float(ww.x); w[u][1] = __uint_as_float(ww.y);
                     w[u][2] = __uint_as_float(ww.z); w[u][3] = __uint_as_float(ww.w);
+                }
+                // every tap of every query of this wave weighs zero (consecutive tokens share what
+                // they can see, so whole waves are blind to an image): nothing to read, nothing to add.
+                // An "outside" row costs no data but its load still costs the address path its cycles.
+                if (__builtin_amdgcn_ballot_w64(any_w != 0u) == 0ull) continue;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const uint4 rr = rrs[u];
+                    const int rows[4] = {(int)rr.x, (int)rr.y, (int)rr.z, (int)rr.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (BUF) {

@@ -336,3 +336,22 @@ def test_full_size_properties(name, cfg, dtype):
     # (4) determinism of the forward (no atomics there)
     out2 = MSDeformAttnFunction.apply(value, sh, start, loc, attn, 1)
     assert torch.equal(out2, out.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_zero_attention_samples_are_skipped_not_miscounted(dtype):
+    """Images a token cannot see carry exactly zero attention (MMFS's masked softmax): the forward
+    reads no rows for them and the grad_value sort makes no records -- outputs and all three
+    gradients (grad_attn of a zero-weight sample is NOT zero) still match the oracle."""
+    x = make_inputs(2, 4, 64, 300, 4, [(32, 32), (16, 16), (8, 8)] * 2, seed=21, dtype=dtype)
+    g = torch.Generator().manual_seed(2)
+    keep = (torch.rand(2, 300, 1, 6, 1, generator=g) < 0.5).double()
+    keep[:, :, :, 0] = 1.0
+    keep[1, :150] = 0.0                             # a stretch of queries that sees nothing at all
+    x["attn"] = (x["attn"] * keep).to(dtype).to(torch.float64)
+    got = run_hip(x, dtype, use_autograd=False)
+    want = run_oracle(x)
+    check(got, want, dtype, "zero attention")
+    assert np.abs(want[3][keep.expand_as(x["attn"]).numpy() == 0]).max() > 1e-3     # the case is not vacuous
+    assert np.abs(got[0][1, :150]).max() == 0.0

@@ -57,6 +57,10 @@ def one_case(rng, idx):
             flat[rng.randrange(flat.numel())] = rng.choice([float("nan"), float("inf"), -float("inf"), 1e30])
     value = torch.rand(B, S, H, D, generator=g) - 0.3
     attn = torch.rand(B, Nq, H, L, P, generator=g) + 1e-5
+    if rng.random() < 0.35:         # images a token cannot see: whole levels at exactly zero weight, per query
+        keep = (torch.rand(B, Nq, 1, L, 1, generator=g) < 0.5).to(attn.dtype)
+        keep[:, :, :, rng.randrange(L)] = 1.0
+        attn = attn * keep
     attn = attn / attn.sum((-1, -2), keepdim=True)
     grad = torch.randn(B, Nq, H * D, generator=g)
     rt = lambda t: t.to(dtype).to(torch.float64)
