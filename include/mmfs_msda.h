@@ -90,6 +90,12 @@ int mmfs_msda_forward(int dtype,
 #define MMFS_BWD_FORCE_ATOMIC 2u      /* testing/measurement: always take the atomic path */
 #define MMFS_BWD_DENSE_TAPS   4u      /* mmfs_msda_backward_hybrid: small levels' grad_loc / grad_attn by MFMA */
 #define MMFS_BWD_DENSE_VALUE  8u      /* mmfs_msda_backward_hybrid: small levels' grad_value by MFMA */
+/* The caller does not read grad_attn (nor grad_loc, which is 0 anyway) of samples whose attention
+ * weight is exactly 0: they may be written as 0 without reading the value rows.  True for MMFS: the
+ * weights come out of its masked softmax (mmfs.py:203-231), whose backward multiplies every
+ * incoming gradient by the weight itself, and images a token cannot see have weight exactly 0.
+ * Honoured by mmfs_msda_backward and mmfs_msda_backward_hybrid (row-gather kernel); a hint. */
+#define MMFS_BWD_LAZY_ZERO_ATTN 16u
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.

@@ -221,6 +221,7 @@ _BWD_CANONICAL_LEVELS = 1
 _BWD_FORCE_ATOMIC = 2
 _BWD_DENSE_TAPS = 4
 _BWD_DENSE_VALUE = 8
+_BWD_LAZY_ZERO_ATTN = 16
 _E_UNSUPPORTED = -5
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
@@ -338,10 +339,12 @@ def register_level_tables(spatial_shapes, level_start_index, S, host_shapes=None
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step):
+                            grad_output, im2col_step, lazy_zero_attn=False):
     """Reference: ms_deform_attn_cuda_backward, src/cuda/ms_deform_attn_cuda.cu:84-166.
     Returns [grad_value, grad_sampling_loc, grad_attn_weight] shaped and typed like the
-    corresponding inputs."""
+    corresponding inputs.  ``lazy_zero_attn`` (an addition, MMFS_BWD_LAZY_ZERO_ATTN): the caller
+    never reads grad_attn_weight where attn_weight is exactly 0 (MMFS's masked softmax multiplies it
+    by the weight), so those entries may come back as 0 without their value rows being read."""
     _require(isinstance(value, torch.Tensor) and value.is_cuda, "Not implemented on the CPU")
     _validate([("value", value), ("spatial_shapes", spatial_shapes),
                ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -359,7 +362,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     dt = value.dtype
     code = _DTYPE_CODE[dt]
     dims = (B, S, H, D, L, Nq, P)
-    flags = 0
+    flags = _BWD_LAZY_ZERO_ATTN if lazy_zero_attn else 0
     info = None
     if _bwd_algo == "atomic":
         flags |= _BWD_FORCE_ATOMIC

@@ -142,8 +142,11 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
                 const Tap<float> t = locate<float>(to_f32(loc[2 * s]), to_f32(loc[2 * s + 1]), Hl, Wl,
                                                    (int)start[l]);
-                row[0] = t.row[0]; row[1] = t.row[1]; row[2] = t.row[2]; row[3] = t.row[3];
                 fx = t.fx; fy = t.fy; a = to_f32(attn[s]);
+                // lazy_attn: nobody reads the gradients of a zero-weight sample -> no rows, zeros out
+                if (!(d.lazy_attn && !SCATTER && a == 0.f)) {
+                    row[0] = t.row[0]; row[1] = t.row[1]; row[2] = t.row[2]; row[3] = t.row[3];
+                }
                 wh = ((uint32_t)Hl << 16) | (uint32_t)Wl;
             }
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
@@ -158,6 +161,21 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 uint4 raw[kUnroll][4];
                 int rows[kUnroll][4];
                 uint4 meta[kUnroll];
+                if (!SCATTER && d.lazy_attn) {
+                    // whole wave on zero-weight samples (consecutive tokens are blind to the same
+                    // images): skip the loads -- an "outside" row moves no data but still costs the
+                    // address path its cycles -- and leave zeros for the store pass
+                    bool live = false;
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) live |= (recs[2 * (kk + u) + 1].z << 1) != 0u;
+                    if (__builtin_amdgcn_ballot_w64(live) == 0ull) {
+                        if (lig == 0) {
+#pragma unroll
+                            for (int u = 0; u < kUnroll; ++u) recs[2 * (kk + u)] = make_uint4(0u, 0u, 0u, 0u);
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const uint4 rr = recs[2 * (kk + u)];

@@ -32,6 +32,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->L = (int)L; d->Nq = (int)Nq; d->P = (int)P;
     d->K = (int)(L * P);
     d->q_tiles = 0;
+    d->lazy_attn = 0;
     return MMFS_OK;
 }
 
@@ -117,6 +118,7 @@ int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
     mmfs::Dims d;
     const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
     if (rc) return rc;
+    d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_samples = B * Nq * H * L * P;
     const int64_t n_value = B * S * H * D;
@@ -369,6 +371,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
     if (rc) return rc;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
+    d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
     const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;

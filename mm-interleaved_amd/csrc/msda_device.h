@@ -16,6 +16,7 @@ struct Dims {
     int B, S, H, D, L, Nq, P;
     int K;          // L * P samples per (b, q, h)
     int q_tiles;    // ceil(Nq / queries-per-block), filled by the launcher
+    int lazy_attn;  // backward: grad_attn / grad_loc of samples whose attention is exactly 0 may be written as 0
 };
 
 // ---------------------------------------------------------------- storage types

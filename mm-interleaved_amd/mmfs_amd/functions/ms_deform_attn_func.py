@@ -24,8 +24,12 @@ class MSDeformAttnFunction(Function):
     @staticmethod
     @_fwd
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
-                sampling_locations, attention_weights, im2col_step):
+                sampling_locations, attention_weights, im2col_step, lazy_zero_attn=False):
+        # ``lazy_zero_attn`` is an addition to the reference's six arguments (see
+        # MSDA.ms_deform_attn_backward): set by MMFS, whose softmax backward never looks at the
+        # gradient of a weight that is exactly zero
         ctx.im2col_step = im2col_step
+        ctx.lazy_zero_attn = bool(lazy_zero_attn)
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index,
             sampling_locations, attention_weights, ctx.im2col_step)
@@ -40,8 +44,8 @@ class MSDeformAttnFunction(Function):
         grad_output = grad_output.contiguous()
         value, shapes, start, loc, attn = ctx.saved_tensors
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, start, loc, attn, grad_output, ctx.im2col_step)
-        return grad_value, None, None, grad_loc, grad_attn, None
+            value, shapes, start, loc, attn, grad_output, ctx.im2col_step, ctx.lazy_zero_attn)
+        return grad_value, None, None, grad_loc, grad_attn, None, None
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):

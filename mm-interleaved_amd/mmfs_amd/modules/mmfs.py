@@ -196,8 +196,10 @@ class MMFS(nn.Module):
 
         loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes,
                                                attention_mask, n)
+        # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
+        # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                         loc.to(value.dtype).contiguous(), attn, self.im2col_step)
+                                         loc.to(value.dtype).contiguous(), attn, self.im2col_step, True)
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)

@@ -108,7 +108,7 @@ class OracleMSDAFunction(torch.autograd.Function):
     module-level code (MMFS and the blocks) on CPU tensors."""
 
     @staticmethod
-    def forward(ctx, value, shapes, start, loc, attn, im2col_step):
+    def forward(ctx, value, shapes, start, loc, attn, im2col_step, lazy_zero_attn=False):   # (hint ignored: everything is computed)
         ctx.save_for_backward(value, shapes, start, loc, attn)
         npdt = np.float64 if value.dtype == torch.float64 else np.float32
         out = forward(value, shapes, start, loc, attn, dtype=npdt)
@@ -120,4 +120,4 @@ class OracleMSDAFunction(torch.autograd.Function):
         npdt = np.float64 if value.dtype == torch.float64 else np.float32
         gv, gl, ga = backward(value, shapes, start, loc, attn, grad_out.contiguous(), dtype=npdt)
         cast = lambda x: torch.from_numpy(x).to(value.dtype)
-        return cast(gv), None, None, cast(gl), cast(ga), None
+        return cast(gv), None, None, cast(gl), cast(ga), None, None

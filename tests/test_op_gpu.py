@@ -355,3 +355,34 @@ def test_zero_attention_samples_are_skipped_not_miscounted(dtype):
     check(got, want, dtype, "zero attention")
     assert np.abs(want[3][keep.expand_as(x["attn"]).numpy() == 0]).max() > 1e-3     # the case is not vacuous
     assert np.abs(got[0][1, :150]).max() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lazy_zero_attention_only_changes_entries_nobody_reads(dtype):
+    """MMFS_BWD_LAZY_ZERO_ATTN (set by the MMFS module): grad_attn / grad_loc of zero-weight samples
+    come back as 0; every other output is bit-identical to the full backward."""
+    import MultiScaleDeformableAttention as MSDA
+    x = make_inputs(2, 4, 64, 300, 4, [(40, 40), (16, 16), (8, 8)] * 2, seed=23, dtype=dtype)
+    g = torch.Generator().manual_seed(4)
+    keep = (torch.rand(2, 300, 1, 6, 1, generator=g) < 0.5).double()
+    keep[0, 100:200] = 0.0
+    keep[0, 100:200, :, 2] = 1.0                   # whole waves blind to all but one level
+    x["attn"] = (x["attn"] * keep).to(dtype).to(torch.float64)
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
+    args = [dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn")] + [dev(x["grad"]).reshape(2, 300, -1), 1]
+    full = MSDA.ms_deform_attn_backward(*args)
+    lazy = MSDA.ms_deform_attn_backward(*args, lazy_zero_attn=True)
+    zero = (args[4] == 0)
+    # (grad_value: same records, but their order inside a cell -- and so the order of the fp32 sums --
+    # is not fixed from run to run)
+    assert float((lazy[0].double() - full[0].double()).abs().max()) <= TOL[dtype] * max(1.0, float(full[0].abs().max()))
+    assert torch.equal(lazy[2][~zero], full[2][~zero]) and torch.equal(lazy[1][~zero], full[1][~zero])
+    assert float(full[2][zero].abs().max()) > 1e-3
+    # a hint: honoured by the 16-bit route's row-gather kernel (here: the two 40x40 levels), ignored by
+    # the dense dot products of the small levels and by the fp32 route
+    assert bool(((lazy[2][zero] == 0) | (lazy[2][zero] == full[2][zero])).all())
+    if dtype == torch.bfloat16:
+        big = torch.zeros_like(zero)
+        big[:, :, :, [0, 3]] = True
+        assert float(lazy[2][zero & big].abs().max()) == 0.0 and float(lazy[1][zero & big].abs().max()) == 0.0
