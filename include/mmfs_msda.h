@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 3
+#define MMFS_MSDA_ABI_VERSION 4   /* 4: + mmfs_bank_gather / mmfs_bank_scatter, MMFS_BWD_LAZY_ZERO_ATTN */
 
 enum mmfs_dtype {
     MMFS_F32  = 0,
