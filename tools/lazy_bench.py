@@ -1,10 +1,16 @@
-import sys, time, torch
-sys.path[:0] = ["/root/repo", "/root/repo/mm-interleaved_amd"]
-import bench, MultiScaleDeformableAttention as MSDA
+#!/usr/bin/env python3
+"""Backward of the LLM geometry (4 images, causal visibility: bench.py --visible causal) with and
+without MMFS_BWD_LAZY_ZERO_ATTN, per-kernel HIP-event times."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd")]
+import torch  # noqa: E402
+import bench  # noqa: E402
+import MultiScaleDeformableAttention as MSDA  # noqa: E402
 w = dict(bench.WORKLOADS["cfg5_llm_n4"])
 value, shapes, start, loc, attn, grad = bench.make_inputs(w, "cuda", 0, visible="causal")
-S = value.shape[1]
-MSDA.register_level_tables(shapes, start, S) if hasattr(MSDA, "register_level_tables") else None
 for lazy in (False, True, False, True):
     MSDA._event_log = log = []
     for _ in range(30):
