@@ -400,17 +400,22 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     if st != 0:
                         break
                 return st
-            fork = _fork(value.device)
-            with fork:
-                status = run_stages(_HYB_BWD_STAGES[:2])         # grad_loc / grad_attn (side stream)
-            if status == 0:
-                status = run_stages(_HYB_BWD_STAGES[2:])         # grad_value
-            fork.join()
+            if _event_log is None and not _bwd_overlap:
+                status = _lib.mmfs_msda_backward_hybrid(*args, _HYB_BWD_ALL, stream)    # one call, one stream
+            else:
+                fork = _fork(value.device)
+                with fork:
+                    status = run_stages(_HYB_BWD_STAGES[:2])         # grad_loc / grad_attn (side stream)
+                if status == 0:
+                    status = run_stages(_HYB_BWD_STAGES[2:])         # grad_value
+                fork.join()
         ws_bytes = 0 if hyb_bytes > 0 else _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
-        if hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS):
-            # pixel-stationary backward, stage by stage (so each kernel can be timed)
+        if hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS) and _event_log is None and not _bwd_overlap:
+            pass                                 # the library's own sequence below: one call (same kernels)
+        elif hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS):
+            # sorted backward, stage by stage (so each kernel can be timed / the halves can overlap)
             fork = _fork(value.device)
             with fork:
                 status = _launch("msda_bwd_taps", value.device, _lib.mmfs_msda_backward_taps, code,
@@ -431,8 +436,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                                  *dims, stream)
             fork.join()
         if status == _E_UNSUPPORTED:
-            # head width without a vector path, fp64, or a non-canonical level table:
-            # the library's float-atomic path (needs an fp32 scratch for 16-bit storage)
+            # the library's own sequence: taps + sort + reduce when the level table is canonical and
+            # the head width has a vector path, else (odd head width, fp64, gapped or overlapping
+            # levels) float-atomic accumulation (needs an fp32 scratch for 16-bit storage)
             status = _launch("msda_bwd_atomic", value.device, _lib.mmfs_msda_backward, code,
                              value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                              sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
