@@ -71,6 +71,44 @@ __device__ __forceinline__ float group_sum(float v)
 // SCATTER = false: location / weight gradients only; grad_value comes from the
 //                  pixel-stationary kernel in msda_bwd_value.hip
 // BUF: value rows through a buffer descriptor (see msda_device.h); only without SCATTER
+// Dot product of two 16-byte channel vectors, fp32 result.  The taps kernel is VALU-bound (94 % busy
+// at the north-star shape, rocprofv3 SQ_ACTIVE_INST_VALU): unpacking 16-bit channels costs one
+// instruction per element and the multiply-adds another 0.5-1.  For 16-bit storage the packed dot
+// product instructions (v_dot2c_f32_bf16 / v_dot2c_f32_f16: two exact products + fp32 accumulate)
+// take the vectors as they are -- 4 instructions per row instead of ~13.
+template <typename T> struct RowDot {
+    static __device__ __forceinline__ float run(const uint4 &a, const uint4 &b) {
+        float x[Vec16<T>::N], y[Vec16<T>::N];
+        Vec16<T>::unpack(a, x); Vec16<T>::unpack(b, y);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < Vec16<T>::N; ++i) acc = fmaf(x[i], y[i], acc);
+        return acc;
+    }
+};
+template <> struct RowDot<bf16_t> {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float run(const uint4 &a, const uint4 &b) {
+        float acc = 0.f;
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a.x), __builtin_bit_cast(v2, b.x), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a.y), __builtin_bit_cast(v2, b.y), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a.z), __builtin_bit_cast(v2, b.z), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a.w), __builtin_bit_cast(v2, b.w), acc, false);
+        return acc;
+    }
+};
+template <> struct RowDot<half_t> {
+    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float run(const uint4 &a, const uint4 &b) {
+        float acc = 0.f;
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a.x), __builtin_bit_cast(v2, b.x), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a.y), __builtin_bit_cast(v2, b.y), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a.z), __builtin_bit_cast(v2, b.z), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a.w), __builtin_bit_cast(v2, b.w), acc, false);
+        return acc;
+    }
+};
+
 template <typename T, int LPI, bool SCATTER, bool BUF>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -110,12 +148,13 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     if (BUF) rsrc = make_slab_rsrc(value + slice, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
 
     // upstream gradient of this query: contiguous map for the dots, interleaved for atomics
-    float g[VEC], gat[VEC];
+    float gat[VEC];
+    uint4 graw = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { g[j] = 0.f; gat[j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) gat[j] = 0.f;
     if (q_ok) {
         const T *gp = grad_out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D;
-        V::unpack(*reinterpret_cast<const uint4 *>(gp + lig * VEC), g);
+        graw = *reinterpret_cast<const uint4 *>(gp + lig * VEC);
         if (SCATTER) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) gat[j] = to_f32(gp[j * LPI + lig]);
@@ -195,11 +234,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     float dot[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float v[VEC];
-                        V::unpack(raw[u][c], v);
-                        float acc = 0.f;
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) acc = fmaf(g[i], v[i], acc);
+                        const float acc = RowDot<T>::run(graw, raw[u][c]);
                         dot[c] = group_sum<LPI>((BUF || rows[u][c] >= 0) ? acc : 0.f);
                     }
                     const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
