@@ -25,6 +25,7 @@
 // (channel = j*LPI + lane) so one atomic instruction covers LPI consecutive floats.
 #include "msda_device.h"
 #include "msda_launch.h"
+#include <type_traits>
 
 namespace mmfs {
 
@@ -65,6 +66,34 @@ __device__ __forceinline__ float group_sum(float v)
 #pragma unroll
     for (int off = 16; off < LPI; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// Four values summed over a 16-lane group TOGETHER; the totals are valid in the group's lane 0 only
+// (the one lane that finishes the sample).  Instead of four butterflies of four steps each, the
+// value count halves with every step: the row mirror leaves each half-row with two of the four
+// sums, the half-row mirror each quad with one, two quad swaps finish it, and lane 0 collects the
+// other quads' totals -- 5 adds, 6 selects, 3 moves instead of 16 adds (+ their moves): the taps
+// kernel is bound by its vector instruction count.
+__device__ __forceinline__ void group_sum4_row(float (&d)[4], int lig)
+{
+    const bool hi = (lig & 8) != 0, odd = (lig & 4) != 0;
+    auto mv = [](float v, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    // lanes 0-7 keep (d0, d1), lanes 8-15 keep (d2, d3); partner = 15 - lane
+    const float k0 = hi ? d[2] : d[0], k1 = hi ? d[3] : d[1];
+    const float s0 = hi ? d[0] : d[2], s1 = hi ? d[1] : d[3];
+    const float r0 = k0 + mv(s0, std::integral_constant<int, 0x140>());
+    const float r1 = k1 + mv(s1, std::integral_constant<int, 0x140>());
+    // lanes with bit 2 clear keep the first, the others the second; partner = 7 - lane within the half
+    const float k = odd ? r1 : r0, s = odd ? r0 : r1;
+    float t = k + mv(s, std::integral_constant<int, 0x141>());
+    t = dpp_add<0xB1>(t);                            // lane ^ 1
+    t = dpp_add<0x4E>(t);                            // lane ^ 2: quad q now holds the total of d[q]
+    d[0] = t;
+    d[1] = mv(t, std::integral_constant<int, 0x104>());   // row_shl:4  -> lane 0 reads lane 4
+    d[2] = mv(t, std::integral_constant<int, 0x108>());   // row_shl:8  -> lane 8
+    d[3] = mv(t, std::integral_constant<int, 0x10C>());   // row_shl:12 -> lane 12
 }
 
 // SCATTER = true : also accumulates grad_value with global atomics (fallback path)
@@ -122,6 +151,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int QPB = kThreads / LPI;
     constexpr int KC = (kRecsPerBlock / QPB) > kUnroll ? (kRecsPerBlock / QPB) : kUnroll;
     constexpr int STRIDE = 2 * KC + 1;
+    constexpr bool PRE = BUF && !SCATTER;           // records carry byte offsets, not pixel rows
     __shared__ uint4 lds[QPB * STRIDE];
     __shared__ uint8_t sel_idx[kMaxSelLevels];
 
@@ -188,6 +218,11 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 }
                 wh = ((uint32_t)Hl << 16) | (uint32_t)Wl;
             }
+            if (PRE) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)      // pixel row -> byte offset in the slab, or "outside" (reads as zeros)
+                    row[c] = row[c] >= 0 ? (int)((uint32_t)row[c] * row_bytes) : (int)kOobOffset;
+            }
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
             dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
             dst[1] = make_uint4(__float_as_uint(fx), __float_as_uint(fy), __float_as_uint(a), wh);
@@ -222,7 +257,9 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     rows[u][0] = (int)rr.x; rows[u][1] = (int)rr.y; rows[u][2] = (int)rr.z; rows[u][3] = (int)rr.w;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        if (BUF)      // a corner outside the map reads as zeros -> its dot is 0
+                        if (PRE)      // offsets made when the record was staged; a corner outside the map reads as zeros
+                            raw[u][c] = buffer_load16(rsrc, (uint32_t)rows[u][c] + lane_off);
+                        else if (BUF)
                             raw[u][c] = buffer_load16(rsrc, rows[u][c] >= 0 ? (uint32_t)rows[u][c] * row_bytes + lane_off
                                                                            : kOobOffset);
                         else
@@ -235,7 +272,12 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float acc = RowDot<T>::run(graw, raw[u][c]);
-                        dot[c] = group_sum<LPI>((BUF || rows[u][c] >= 0) ? acc : 0.f);
+                        dot[c] = (BUF || rows[u][c] >= 0) ? acc : 0.f;
+                    }
+                    if (LPI == 16 && !SCATTER) group_sum4_row(dot, lig);      // totals in the group's lane 0
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dot[c] = group_sum<LPI>(dot[c]);
                     }
                     const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
                     const float a = __uint_as_float(meta[u].z);
