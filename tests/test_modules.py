@@ -309,3 +309,20 @@ def test_level_tables_are_cached_and_marked_canonical():
     assert a[0] is b[0] and a[2] == 240
     assert a[0].tolist() == [[8, 8], [4, 4]] * 3 and a[1].tolist() == [0, 64, 80, 144, 160, 224]
     assert MSDA.levels_are_canonical(a[0], a[1], 240)
+
+
+def test_bank_from_levels_equals_pack_then_gather():
+    """llm_feature_bank_from_levels (the one-pass route; framework ops on host tensors) builds the
+    same bank as packing the levels and gathering per sequence, padded slots zero."""
+    from mmfs_amd import bank
+    g = torch.Generator().manual_seed(5)
+    levels = [torch.randn(6, 8, s, s, generator=g, dtype=torch.float64) for s in (4, 2, 1)]
+    num = torch.tensor([2, 0, 3, 1])
+    a = bank.llm_feature_bank_from_levels(levels, num, 3)
+    b = bank.llm_feature_bank(bank.pack_image_levels(levels), num, 3)
+    assert a.shape == (4, 3, 21, 8) and torch.equal(a, b)
+    assert float(a[1].abs().max()) == 0.0 and float(a[0, 2].abs().max()) == 0.0
+    src = torch.tensor([5, -1, 0, 9])
+    got = bank.gather_bank(levels, src)
+    assert torch.equal(got[0], bank.pack_image_levels(levels)[5]) and float(got[1].abs().max()) == 0.0
+    assert float(got[3].abs().max()) == 0.0          # past the last image: an empty slot, not a clamp
