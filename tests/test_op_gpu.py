@@ -167,6 +167,17 @@ def test_many_levels_fall_back_to_pixel_stationary():
     check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "L=130")
 
 
+@pytest.mark.parametrize("n_levels", [33, 40, 72, 128])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_level_rows_beyond_the_cached_ones(n_levels, dtype):
+    """The block reduce keeps 32 level rows in LDS and reads the others from the table (a dozen
+    images of 3-4 levels each is ordinary for the LLM path): levels on both sides of that border, of
+    different sizes so that a wrong row shows."""
+    shapes = [((3, 2), (5, 4), (2, 7), (6, 6))[i % 4] for i in range(n_levels)]
+    x = make_inputs(1, 2, 32, 40, 2, shapes, seed=6, dtype=dtype)
+    check(run_hip(x, dtype), run_oracle(x), dtype, f"L={n_levels}")
+
+
 def test_hybrid_off_uses_plain_kernels(monkeypatch):
     import MultiScaleDeformableAttention as MSDA
     monkeypatch.setattr(MSDA, "_hybrid", False)
