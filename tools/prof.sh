@@ -8,8 +8,10 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# the trace pass runs the default command (20 warm-up + 100 timed steps: its per-kernel averages are
+# the ones bench.py's HIP-event timings must agree with); the counter passes are short
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $root/bench.py --no-cpu-baseline $* > $out/trace.log 2>&1
 args="--no-cpu-baseline --steps 10 --warmup 3 $*"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $root/bench.py $args > $out/trace.log 2>&1
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
