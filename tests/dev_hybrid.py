@@ -1,5 +1,5 @@
 """Development check of the hybrid (dense small levels) path against the plain kernels and the
-oracle, plus per-kernel timings.  Run on the GPU box:  python tools/dev_hybrid.py [--quick]"""
+oracle, plus per-kernel timings.  Run on the GPU box:  python tests/dev_hybrid.py [--quick]"""
 import os
 import sys
 import time

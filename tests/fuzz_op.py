@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP op against the CPU oracle (run on the GPU box):
-    python tools/fuzz_op.py [n_cases] [seed] [big]
+    python tests/fuzz_op.py [n_cases] [seed] [big]
 Random shapes (every dispatch path: vector / scalar head widths, hybrid routing on and off, both
 grad_value generations, hot spots that overflow the block lists), random location distributions
 (uniform, out of range, clustered on a point, NaN / Inf sprinkled in), all storage types."""

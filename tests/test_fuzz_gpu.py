@@ -1,4 +1,4 @@
-"""Randomised sweep of the op against the oracle (tools/fuzz_op.py) with fixed seeds: shapes,
+"""Randomised sweep of the op against the oracle (tests/fuzz_op.py) with fixed seeds: shapes,
 storage types, location distributions and routing knobs drawn at random, so that paths no
 hand-written case names (idle query chunks, ragged tiles next to hot spots, odd head widths)
 still meet the parity bars."""
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fuzz():
-    spec = importlib.util.spec_from_file_location("fuzz_op", os.path.join(ROOT, "tools", "fuzz_op.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_op", os.path.join(ROOT, "tests", "fuzz_op.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
