@@ -19,6 +19,23 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_library():
+    """The C-ABI library is a build artefact (git-ignored).  A checkout that has not run
+    ``__graft_entry__.build()`` yet gets it built here (hipcc cross-compiles without a GPU), so that the
+    load / symbol / host-logic tests do not fail for a missing file."""
+    lib = os.path.join(PKG, "libmmfs_msda.so")
+    if os.path.exists(lib):
+        return
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-j8", "-C", os.path.join(PKG, "csrc")], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+
+
+_ensure_library()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
 
