@@ -7,7 +7,7 @@
 // Here the unit of the sort is the SAMPLE, keyed by the cell of its top-left corner, and the unit of
 // the reduce is a 2x2 pixel block:
 //
-//   * one 16-byte record {query, fy, fx, attention} per sample instead of four 8-byte {query,
+//   * one 16-byte record {query, y, x, attention} (pixel coordinates) per sample instead of four 8-byte {query,
 //     weight} records: a quarter of the LDS atomics and of the scattered stores of the sort
 //     (those stores, ~1.3 lanes/clk/CU, bound it), half the record bytes;
 //   * a lane group owns a 2x2 block of one level's pixels and walks the runs of the 9 cells whose
@@ -22,56 +22,14 @@
 // ms_deform_attn_cuda.cu:122-165).
 #include "msda_device.h"
 #include "msda_launch.h"
+#include "msda_bwd_block.h"
 #include <cstdlib>
 
 namespace mmfs {
 
+using namespace blk;
+
 namespace {
-
-constexpr int kThreads = 1024;          // sort: 16 waves per workgroup
-constexpr int kWaves = kThreads / 64;
-constexpr int kMaxTileCells = 4096;     // cells per sort tile (two counter arrays of 16 KiB)
-constexpr int kScanUnroll = 4;
-constexpr int kMaxLevels = 128;         // levels the block path takes
-constexpr int kLdsLevels = 32;          // level rows the reduce keeps in LDS (beyond: read from the table)
-#ifndef MMFS_BLK_ROUND
-#define MMFS_BLK_ROUND 2
-#endif
-constexpr int kRoundPx = MMFS_BLK_ROUND; // pixels per LDS round when split blocks add up their parts
-
-struct CTile {
-    int level, Hl, Wl, cbase;           // cbase: the level's first entry in the cell table
-    int ya, yb, xa, xb;                 // cell coordinates [ya, yb) x [xa, xb)
-};
-
-struct LevelRow {
-    int Hl, Wl, lstart, cbase;
-    int bbase, nbx, nby, split;         // first (virtual) block index, blocks per row / column, lane groups per block
-    int cap, pad[3];                    // records of a block's list walked in place before the rest is queued
-};
-constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
-#ifndef MMFS_BLK_H
-#define MMFS_BLK_H 2
-#endif
-#ifndef MMFS_BLK_W
-#define MMFS_BLK_W 2
-#endif
-constexpr int kBH = MMFS_BLK_H, kBW = MMFS_BLK_W;      // pixels of a block (rows x columns)
-constexpr int kNC = (kBH + 1) * (kBW + 1);              // cells whose footprints touch a block
-constexpr int kNPX = kBH * kBW;
-static_assert(kNPX % 4 == 0, "block weights travel as 16-byte vectors");
-
-struct CellHeader {
-    int n_tiles, n_blocks, n_cells, L;
-    int pad[4];
-};
-
-// workspace table: CellHeader | LevelRow[L] | CTile[cap]
-__device__ __host__ inline LevelRow *level_rows(CellHeader *h) { return reinterpret_cast<LevelRow *>(h + 1); }
-__device__ __host__ inline const LevelRow *level_rows(const CellHeader *h) { return reinterpret_cast<const LevelRow *>(h + 1); }
-__device__ __host__ inline CTile *tiles_of(CellHeader *h, int L) { return reinterpret_cast<CTile *>(level_rows(h) + L); }
-__device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { return reinterpret_cast<const CTile *>(level_rows(h) + L); }
-
 
 // The 9 runs of a block, seen as one list: run k holds [pre[k], pre[k+1]) of it.  Kept in LDS
 // (one per lane group; every group reads the others' in phase 2).
@@ -142,22 +100,31 @@ __device__ __host__ inline int cap_of(int64_t samples, int64_t blocks)
 __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                                   int L, int nt_min, int cap, int64_t samples_per_level,
                                   CellHeader *__restrict__ hdr, uint32_t *__restrict__ ovf_header,
-                                  uint32_t cap_slots, uint32_t cap_entries, uint32_t cap_partials)
+                                  uint32_t cap_slots, uint32_t cap_entries, uint32_t cap_partials,
+                                  TileHeader *__restrict__ th, uint32_t tile_cap_extra, uint32_t tile_cap_partials)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    if (th != nullptr && threadIdx.x < 32) th->zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x != 0) return;
+    if (th != nullptr) {
+        for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
+        th->n_partials = 0u; th->cap_extra = tile_cap_extra; th->cap_partials = tile_cap_partials; th->pad = 0u;
+        th->null_rec = make_uint4(0u, __float_as_uint(-8.f), __float_as_uint(-8.f), 0u);
+    }
     ovf_header[0] = 0u; ovf_header[1] = cap_slots; ovf_header[2] = cap_entries;                         // OvfHeader
     ovf_header[3] = 0u; ovf_header[4] = cap_partials; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
     for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
     LevelRow *lv = level_rows(hdr);
     CTile *tile = tiles_of(hdr, L);
-    int n = 0, cbase = 0, bbase = 0;
+    int n = 0, cbase = 0, bbase = 0, bbase4 = 0;
     for (int l = 0; l < L; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         LevelRow r;
         r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l]; r.cbase = cbase; r.bbase = bbase;
         r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = 0; lv[l] = r; continue; }
+        r.bbase4 = bbase4; r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
+        if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = r.nbx4 = r.nby4 = 0; lv[l] = r; continue; }
+        bbase4 += r.nbx4 * r.nby4;
         r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
         r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
         lv[l] = r;
@@ -165,8 +132,10 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
         int nt = max(nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
         nt = min(nt, cells);
         const int tc = (cells + nt - 1) / nt;
+        // whole cell rows whenever one fits the tile's counters: the cells of a row that touch a block
+        // are then one contiguous run of the record list (the matrix-core reduce relies on it)
         int R, C;
-        if (Wc <= tc) { R = tc / Wc; C = Wc; } else { R = 1; C = tc; }
+        if (Wc <= kMaxTileCells) { R = min(max(tc / Wc, 1), kMaxTileCells / Wc); C = Wc; } else { R = 1; C = min(tc, kMaxTileCells); }
         for (int ya = 0; ya < Hc && n < cap; ya += R)
             for (int xa = 0; xa < Wc && n < cap; xa += C) {
                 CTile t;
@@ -179,6 +148,7 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
         bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
     }
     hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
+    hdr->n_blocks4 = bbase4; hdr->pad[0] = hdr->pad[1] = hdr->pad[2] = 0;
 }
 
 // Exclusive prefix sum over a[0..n) (n <= kMaxTileCells), total left in a[n].
@@ -216,7 +186,7 @@ enum ScanMode { kCount = 0, kScatter = 1 };
 
 // One sample against the tile: if its top-left cell is in the tile
 //   kCount  : off[cell] += 1
-//   kScatter: list[off[cell] + cur[cell]++] = {q, fy, fx, attention}
+//   kScatter: list[off[cell] + cur[cell]++] = {q, y, x, attention}
 template <int MODE>
 __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q, const CTile &tl, int tw,
                                              uint32_t *off, uint32_t *cur, uint4 *__restrict__ list)
@@ -234,7 +204,7 @@ __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q,
         atomicAdd(&off[pl], 1u);
     } else {
         const uint32_t slot = off[pl] + atomicAdd(&cur[pl], 1u);
-        list[slot] = make_uint4((uint32_t)q, __float_as_uint(y - yf), __float_as_uint(x - xf), __float_as_uint(a));
+        list[slot] = make_uint4((uint32_t)q, __float_as_uint(y), __float_as_uint(x), __float_as_uint(a));
     }
 }
 
@@ -364,7 +334,9 @@ __device__ __forceinline__ BlkRec fetch_record(const uint4 *__restrict__ records
         const int p = brp->pre[k];
         const uint32_t f = brp->first[k];
         const uint4 rec = records[f + (uint32_t)(e - p)];
-        const float fy = __uint_as_float(rec.y), fx = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+        // (records carry the pixel coordinates; the fractions are the same subtraction the sort would do)
+        const float py = __uint_as_float(rec.y), px_ = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+        const float fy = py - floorf(py), fx = px_ - floorf(px_);
         // the cell is (BH*by + dy, BW*bx + dx), i.e. the sample's top row is y0 = BH*by + dy - 1: block
         // pixel row ry takes its corner cy = ry - (dy - 1), weight 1-fy for cy = 0, fy for cy = 1
         const int dy = k / (kBW + 1), dx = k - dy * (kBW + 1);
@@ -773,12 +745,19 @@ struct Scratch {
     uint32_t *cursor;
     CellHeader *hdr;
     uint2 *celltab;            // [B, H, cell_stride] {first record, count}
-    uint4 *records;            // [B, H, L, Nq*P] {query, fy, fx, attention}, cell-sorted inside each tile
+    uint4 *records;            // [B, H, L, Nq*P] {query, y, x, attention}, cell-sorted inside each tile
     OvfHeader *ovf;            // long lists: counters, slots, queued chunks, fp32 accumulators
     OvfSlot *oslots;
     OvfEntry *oentries;
     float *oacc;
     uint32_t cap_slots, cap_entries, cap_partials;
+    // matrix-core reduce (msda_bwd_tile.hip): header, per-block info, queued extra items, fp32 partial tiles
+    TileHeader *th;
+    TileInfo *tinfo;
+    TileItem *titems;
+    float *tpartials;
+    uint32_t tile_cap_extra, tile_cap_partials;
+    int tile_blocks_bound;     // >= 4x4 blocks of one (b, h)
     int64_t cursor_bytes, total;
 };
 
@@ -810,6 +789,22 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     s.oslots = (OvfSlot *)p;     p += up((int64_t)s.cap_slots * sizeof(OvfSlot));
     s.oentries = (OvfEntry *)p;  p += up((int64_t)kOvfLanes * s.cap_entries * sizeof(OvfEntry));   // any lane may take all
     s.oacc = (float *)p;         p += up((int64_t)s.cap_partials * kNPX * d.D * 4);                       // partial sums
+    // matrix-core reduce: blocks <= sum ceil(H/4) ceil(W/4) <= S/4 + L; a block of n > kTileChunk records is cut into
+    // ceil(n / kTileChunk) items, so items and partial tiles are bounded by twice the visits / kTileChunk.  (The
+    // bounds assume the AVERAGE 25/16 visits per sample; a block whose items or tiles do not fit is walked by one
+    // wave alone -- slow, still correct.)
+    s.th = nullptr; s.tinfo = nullptr; s.titems = nullptr; s.tpartials = nullptr;
+    s.tile_cap_extra = s.tile_cap_partials = 0; s.tile_blocks_bound = 0;
+    if (tile_reduce_supported(dtype, d)) {
+        const int64_t tvisits = pts * (kTB + 1) * (kTB + 1) / (kTB * kTB);
+        s.tile_blocks_bound = (int)std::min<int64_t>((int64_t)d.S / 4 + d.L + 1, 0x3fffffff);
+        s.tile_cap_partials = (uint32_t)std::min<int64_t>(2 * (tvisits / kTileChunk) + 64, 0x3fffffff);
+        s.tile_cap_extra = (uint32_t)std::min<int64_t>((tvisits / kTileChunk) / kTileLanes * 2 + 64, 0x3fffffff);   // per lane
+        s.th = (TileHeader *)p;      p += up(sizeof(TileHeader));
+        s.tinfo = (TileInfo *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TileInfo));
+        s.titems = (TileItem *)p;    p += up((int64_t)kTileLanes * s.tile_cap_extra * sizeof(TileItem));
+        s.tpartials = (float *)p;    p += up((int64_t)s.tile_cap_partials * kTB * kTB * d.D * 4);
+    }
     s.total = p - (char *)workspace;
     return s;
 }
@@ -823,7 +818,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
     hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min, tp.tiles_bound,
                        (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries,
-                       sc.cap_partials);
+                       sc.cap_partials, sc.th, sc.tile_cap_extra, sc.tile_cap_partials);
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                        cell_stride_of(d));
@@ -928,6 +923,13 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
 {
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
+    if (sc.th != nullptr) {
+        TileReduceArgs a;
+        a.records = sc.records; a.celltab = sc.celltab; a.hdr = sc.hdr; a.cell_stride = cell_stride_of(d);
+        a.th = sc.th; a.tinfo = sc.tinfo; a.titems = sc.titems; a.tpartials = sc.tpartials;
+        a.blocks_bound = sc.tile_blocks_bound;
+        return tile_reduce(dtype, grad_out, grad_value, a, d, st);
+    }
     switch (dtype) {
         case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);
         case 1: return dispatch_reduce<half_t>(sc, grad_out, grad_value, d, st);

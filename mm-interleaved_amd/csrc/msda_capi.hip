@@ -33,6 +33,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->K = (int)(L * P);
     d->q_tiles = 0;
     d->lazy_attn = 0;
+    d->blocks4 = 0;
     return MMFS_OK;
 }
 
@@ -372,6 +373,13 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     if (rc) return rc;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
     d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
+    if (host_shapes) {          // exact grid for the matrix-core grad_value reduce (else a bound is launched)
+        int64_t nb4 = 0;
+        for (int64_t l = 0; l < L; ++l)
+            if (host_shapes[2 * l] > 0 && host_shapes[2 * l + 1] > 0)
+                nb4 += ((host_shapes[2 * l] + 3) / 4) * ((host_shapes[2 * l + 1] + 3) / 4);
+        d.blocks4 = (int)std::min<int64_t>(nb4, 0x3fffffff);
+    }
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
     const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;

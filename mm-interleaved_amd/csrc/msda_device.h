@@ -17,6 +17,7 @@ struct Dims {
     int K;          // L * P samples per (b, q, h)
     int q_tiles;    // ceil(Nq / queries-per-block), filled by the launcher
     int lazy_attn;  // backward: grad_attn / grad_loc of samples whose attention is exactly 0 may be written as 0
+    int blocks4;    // backward: 4x4 pixel blocks of all levels when the caller knows the level table on the host (else 0)
 };
 
 // ---------------------------------------------------------------- storage types

@@ -15,6 +15,7 @@ What is exercised in the reference (the only CPU-runnable statements of the path
       native extension cannot be built here)                          -> mmfs_*.npz
   * ``LlamaMMFSAttention``             decoders/modeling_llama_mmfs.py:311-367
     ``MMFSBlock`` / ``MMFSNet``        decoders/sd_mmfs.py:44-272    -> block_*.npz
+  * ``MSDeformAttn`` (encoder twin)    encoders/vit_adapter/ops/modules/ms_deform_attn.py:28-131 -> enc_*.npz
   * feature-bank builders              mm_interleaved.py:185-252, 306-340
       (the two methods are compiled from the file's AST without importing the
       module, whose imports need diffusers/timm/...)                  -> bank_*.npz
@@ -263,6 +264,30 @@ def make_mmfs_goldens(mods):
         # fp32 run of the LLM case (what an fp32 implementation should reproduce to ~1e-5)
         mmfs_case(mods, "mmfs_llm_mask3d_f32", cfg=llm, B=2, Lq=5, n=3, mask=mask3, seed=10,
                   dtype=torch.float32)
+        # ---- the point counts the decoders really use (modeling_llama_mmfs.py:326-339, sd_mmfs.py:50-53:
+        # n_points = 8) and the north star's 4: these reach the fused sampling-plan kernel of the build
+        llm8 = dict(llm, n_points=8, n_heads=4, base_spatial_shape=16)
+        llm4 = dict(llm, n_points=4, n_heads=8, d_model=128, d_out=48)
+        sd8 = dict(layer_idx=5, d_model=64, d_query=40, d_value=24, d_out=40, n_levels=4, n_heads=4,
+                   n_points=8, ratio=1.0, offset_init_magnitude=1, spatial_shapes=[8, 4, 2, 1],
+                   base_spatial_shape=4, max_num_image_per_seq=10)
+        mask4 = torch.tensor([[[0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [1, 1, 1, 0], [1, 1, 1, 1], [0, 1, 0, 1]],
+                              [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 1, 0], [1, 0, 1, 1], [1, 1, 1, 1], [1, 1, 1, 1]]],
+                             dtype=torch.float32)
+        mmfs_case(mods, "mmfs_p8_llm_n3", cfg=llm8, B=2, Lq=5, n=3, mask=mask3, seed=40)
+        mmfs_case(mods, "mmfs_p8_llm_n4", cfg=llm8, B=2, Lq=6, n=4, mask=mask4, seed=41)
+        mmfs_case(mods, "mmfs_p8_llm_n1", cfg=llm8, B=3, Lq=7, n=1, mask=torch.ones(3, 1, dtype=torch.long), seed=42)
+        mmfs_case(mods, "mmfs_p8_llm_decode", cfg=llm8, B=2, Lq=1, n=4, mask=mask4, seed=43)
+        mmfs_case(mods, "mmfs_p4_llm_n3", cfg=llm4, B=2, Lq=5, n=3, mask=mask3, seed=44)
+        mmfs_case(mods, "mmfs_p8_sd_grid", cfg=sd8, B=3, Lq=12, n=2,
+                  mask=torch.tensor([[1, 1], [0, 0], [0, 1]], dtype=torch.long), seed=45,
+                  ref_kind="grid", grid_hw=(4, 3))
+        mmfs_case(mods, "mmfs_p8_sd_n1", cfg=sd8, B=2, Lq=16, n=1, mask=torch.ones(2, 1, dtype=torch.long),
+                  seed=46, ref_kind="grid", grid_hw=(4, 4))
+        mmfs_case(mods, "mmfs_p8_llm_n3_f32", cfg=llm8, B=2, Lq=5, n=3, mask=mask3, seed=40, dtype=torch.float32)
+        mmfs_case(mods, "mmfs_p8_sd_grid_f32", cfg=sd8, B=3, Lq=12, n=2,
+                  mask=torch.tensor([[1, 1], [0, 0], [0, 1]], dtype=torch.long), seed=45,
+                  ref_kind="grid", grid_hw=(4, 3), dtype=torch.float32)
 
 
 # ----------------------------------------------------------------------------- G5: blocks
@@ -342,6 +367,73 @@ def make_block_goldens():
     save("block_sd_mmfs_net", **arrays)
 
 
+# ----------------------------------------------------------------------------- G7: encoder MSDeformAttn
+def import_reference_encoder_ops():
+    """encoders/vit_adapter/ops as its own package (a second package named ``ops`` in the reference)."""
+    name = "ref_vit_adapter_ops"
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, "mm_interleaved/models/encoders/vit_adapter/ops")]
+        sys.modules[name] = m
+    funcs = importlib.import_module(name + ".functions.ms_deform_attn_func")
+    mod = importlib.import_module(name + ".modules.ms_deform_attn")
+
+    class CoreAsFunction:
+        @staticmethod
+        def apply(value, shapes, start, loc, attn, im2col_step):
+            return funcs.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+
+    mod.MSDeformAttnFunction = CoreAsFunction
+    return mod
+
+
+def encoder_case(mod, name, *, d_model, n_levels, n_heads, n_points, ratio, shapes, B, Lq, seed, ref_dim=2,
+                 dtype=torch.float64, padding=False):
+    """encoders/vit_adapter/ops/modules/ms_deform_attn.py:28-131 as the ViT-Adapter calls it
+    (adapter_modules.py:108-154: injector = ViT tokens query the 3-level pyramid, extractor = pyramid
+    tokens query the single ViT map), parameters randomised (the module starts with zero weights)."""
+    import contextlib, io
+    gen = torch.Generator().manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = mod.MSDeformAttn(d_model=d_model, n_levels=n_levels, n_heads=n_heads, n_points=n_points, ratio=ratio).to(dtype)
+    randomise(m, gen)
+    sh, start = level_tables(shapes)
+    S = int(sh.prod(1).sum())
+    query = torch.randn(B, Lq, d_model, generator=gen).to(dtype).requires_grad_(True)
+    feat = torch.randn(B, S, d_model, generator=gen).to(dtype).requires_grad_(True)
+    ref = torch.rand(B, Lq, n_levels, ref_dim, generator=gen)
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+    pad = None
+    if padding:
+        pad = torch.rand(B, S, generator=gen) < 0.2
+    out = m(query, ref.to(dtype), feat, sh, start, pad)
+    g = torch.randn(out.shape, generator=gen).to(dtype)
+    out.backward(g)
+    arrays = dict(query=query, feat=feat, reference_points=ref, spatial_shapes=sh, level_start_index=start,
+                  grad_out=g, out=out, grad_query=query.grad, grad_feat=feat.grad,
+                  cfg=np.array(repr(dict(d_model=d_model, n_levels=n_levels, n_heads=n_heads, n_points=n_points, ratio=ratio))))
+    if pad is not None:
+        arrays["padding_mask"] = pad
+    arrays.update({"param." + k: v for k, v in m.state_dict().items()})
+    arrays.update({"grad." + k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+    save(name, **arrays)
+
+
+def make_encoder_goldens():
+    mod = import_reference_encoder_ops()
+    # geometry of the adapter at reduced width: H = 16 heads, P = 4, ratio 0.5 -> D = d_model/32
+    inj = dict(d_model=128, n_levels=3, n_heads=16, n_points=4, ratio=0.5, shapes=[(8, 8), (4, 4), (2, 2)])
+    ext = dict(d_model=128, n_levels=1, n_heads=16, n_points=4, ratio=0.5, shapes=[(4, 4)])
+    encoder_case(mod, "enc_injector", **inj, B=2, Lq=16, seed=50)
+    encoder_case(mod, "enc_extractor", **ext, B=2, Lq=84, seed=51)
+    encoder_case(mod, "enc_injector_f32", **inj, B=2, Lq=16, seed=50, dtype=torch.float32)
+    encoder_case(mod, "enc_extractor_f32", **ext, B=2, Lq=84, seed=51, dtype=torch.float32)
+    # the two branches no caller of the reference takes, kept for API fidelity: box reference points, padding mask
+    encoder_case(mod, "enc_boxes_padded", d_model=64, n_levels=2, n_heads=4, n_points=2, ratio=1.0,
+                 shapes=[(5, 3), (2, 4)], B=2, Lq=7, seed=52, ref_dim=4, padding=True)
+
+
 # ----------------------------------------------------------------------------- G6: bank builders
 def make_bank_goldens():
     fns = load_reference_methods(os.path.join(REF, "mm_interleaved/models/mm_interleaved.py"),
@@ -392,3 +484,4 @@ if __name__ == "__main__":
     make_mmfs_goldens(mods)
     make_bank_goldens()
     make_block_goldens()
+    make_encoder_goldens()

@@ -109,9 +109,11 @@ def test_backward_workspace_query_is_host_only():
     pts = 8 * 4096 * 8 * 4 * 4
     # bf16, canonical levels: re-packed loc/attn + level cursors + plan + per-pixel / per-cell run
     # table + sorted records (pixel-stationary: 32 B per sample; block-stationary: 16 B) + the queue
-    # and fp32 partial sums for long lists (block-stationary)
+    # and fp32 partial sums for long lists (block-stationary) + the work-item queue and fp32 partial
+    # tiles of the matrix-core reduce (4x4 pixels x D channels each, bounded by twice the expected
+    # record visits / records per item: 105 MB here)
     base = 3 * pts * 2 + 8 * 8 * 4 * 4 + 8 * 8 * 5440 * 8 + pts * 4 * 8
-    assert base < f(2, *dims, 1) <= base + (64 << 20)
+    assert base < f(2, *dims, 1) <= base + (176 << 20)
     assert f(2, *dims, 0) == 8 * 5440 * 8 * 128 * 4          # unknown level table: fp32 image for atomics
     assert f(2, *dims, 3) == 8 * 5440 * 8 * 128 * 4          # forced atomic
     assert f(0, *dims, 0) == 0                               # fp32 atomics accumulate in grad_value itself

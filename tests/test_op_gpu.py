@@ -137,13 +137,17 @@ def test_hybrid_dense_levels_match_oracle(case, dtype, parts, monkeypatch):
     check(got, run_oracle(x), dtype, f"hybrid[{parts}] {case[:5]}")
 
 
-@pytest.mark.parametrize("algo", ["block", "pixel"])
+@pytest.mark.parametrize("algo", ["tile", "block", "pixel"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_grad_value_generations_agree_with_oracle(algo, dtype, monkeypatch):
-    """grad_value: block-stationary / cell-sorted (csrc/msda_bwd_block.hip, default) and
+    """grad_value: 4x4 blocks on the matrix cores (csrc/msda_bwd_tile.hip, default for 16-bit storage),
+    2x2 blocks on the vector ALUs (csrc/msda_bwd_block.hip, fp32 storage and MMFS_VALUE_ALGO=block) and
     pixel-stationary (csrc/msda_bwd_value.hip, MMFS_VALUE_ALGO=pixel and the fallback for L > 128)
     on a shape with odd extents, a 1-pixel-wide level, hot spots and many taps outside the map."""
-    monkeypatch.setenv("MMFS_VALUE_ALGO", algo)
+    if algo == "tile":
+        monkeypatch.delenv("MMFS_VALUE_ALGO", raising=False)
+    else:
+        monkeypatch.setenv("MMFS_VALUE_ALGO", algo)
     x = make_inputs(2, 4, 64, 150, 4, [(13, 9), (1, 7), (6, 1), (16, 16), (2, 2)], seed=21,
                     loc_range=(-0.3, 1.3), dtype=dtype)
     x["loc"][:, :40, :, 3] = x["loc"][:, :40, :, 3] * 0.05 + 0.5       # hot spot: long lists on a few blocks

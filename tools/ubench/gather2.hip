@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) gather_rows(const char *base, size_t regi
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned x = (unsigned)(it * U + u) * ngrp + grp;
-            row[u] = TABLE ? table[(size_t)(it * U + u) * (gridDim.x * 256) + tid] : hrow(x, log2rows);
+            row[u] = TABLE ? table[(size_t)(it * U + u) * ngrp + grp] : hrow(x, log2rows);     // one entry per row: the 16 lanes read the same word
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] = ld16<POL>(reg + (size_t)row[u] * (unsigned)stride);
@@ -258,6 +258,7 @@ static void report(const char *name, double bytes, Res r)
 int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool table_only = argc > 1 && !strcmp(argv[1], "table");     // only the hash-vs-table comparison
     const size_t bytes = 2ull << 30;
     char *buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 1, bytes));
     float *out; CK(hipMalloc(&out, 64));
@@ -267,7 +268,7 @@ int main(int argc, char **argv)
 
     // ---- 0. vector-ALU issue rates (also calibrates the clock: v_fma_f32 is 1 per 2 clk per SIMD... or not)
     printf("== VALU issue: wave-instructions per SIMD per clock @2.4 GHz nominal (256 CUs x 4 SIMDs)\n");
-    {
+    if (!table_only) {
         const char *kn[] = {"v_fma_f32", "v_pk_fma_f32", "v_dot2c_f32_bf16", "v_lshlrev+v_and (bf16 unpack pair, 2 instr)",
                             "v_mul_lo_u32", "v_cvt_pk_bf16_f32", "v_perm_b32"};
         for (int wps : {1, 2, 4, 8}) {
@@ -312,7 +313,9 @@ int main(int argc, char **argv)
         report(name, (double)blocks * 256 * iters * U * 16, r);                                                      \
     } while (0)
     unsigned *tab = nullptr;
+    if (table_only) { RUN_ROWS(16, 8, POL_PLAIN, false, wheres[1], 32); RUN_ROWS(16, 8, POL_PLAIN, false, wheres[2], 32); }
     for (auto &w : wheres) {
+        if (table_only) break;
         // loads in flight at 32 waves/CU
         RUN_ROWS(16, 1, POL_PLAIN, false, w, 32);
         RUN_ROWS(16, 2, POL_PLAIN, false, w, 32);
@@ -335,17 +338,16 @@ int main(int argc, char **argv)
     {   // precomputed table instead of the hash (same rows), L2 case
         const Where &w = wheres[1];
         const int blocks = 256 * 8, iters = (quick ? 64 : 256);
-        const size_t n = (size_t)iters * 8 * blocks * 256;
+        const size_t n = (size_t)iters * 8 * blocks * 256 / 16;      // one entry per gathered row
         std::vector<unsigned> h(n);
         std::mt19937 rng(1234);
-        for (size_t i = 0; i < n; i += 16) {        // the 16 lanes of a row share one row index
-            const unsigned r = rng() >> (32 - w.log2rows);
-            for (int j = 0; j < 16; ++j) h[i + j] = r;
-        }
+        for (size_t i = 0; i < n; ++i) h[i] = rng() >> (32 - w.log2rows);
         CK(hipMalloc(&tab, n * 4)); CK(hipMemcpy(tab, h.data(), n * 4, hipMemcpyHostToDevice));
         RUN_ROWS(16, 8, POL_PLAIN, true, w, 32);
+        RUN_ROWS(16, 8, POL_PLAIN, true, wheres[2], 32);
         CK(hipFree(tab)); tab = nullptr;
     }
+    if (table_only) { printf("done\n"); return 0; }
 
     // ---- 2. random rows -> LDS by DMA
     printf("== random 256-B rows, global_load_lds_dwordx4 (LDS-DMA)\n");
