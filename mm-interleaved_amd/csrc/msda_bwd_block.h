@@ -66,11 +66,22 @@ constexpr int kTileLanes = 8;             // queue lanes of the extra work items
 
 struct TileHeader {
     uint32_t n_extra[kTileLanes];         // queued extra items per lane
-    uint32_t n_partials, cap_extra, cap_partials, pad;
-    uint4 null_rec;                       // what a K-step reads past the end of a list: weight 0, far outside
-    uint4 zero_row[32];                   // 512 zero bytes: the grad_out row of such a record
+    uint32_t n_partials, cap_extra, cap_partials, n_multi;
+    uint4 null_rec;                       // (spare)
+    uint4 zero_row[32];                   // (spare)
 };
-struct TileInfo { uint32_t parts, pbase; };                 // per (b, h, block)
+// What a work item needs to know about its block, written by the plan kernel (one 64-byte scalar load):
+// the five record runs (one per cell row), the level's extent and first pixel, the block's position.
+struct TileDesc {
+    int first[5];                         // first record of each run (index into the record list)
+    int cnt[5];                           // records per run
+    uint32_t hw;                          // Hl << 16 | Wl
+    int lstart;
+    uint32_t byx;                         // block row << 16 | block column
+    uint32_t parts, pbase;                // work items of the block; first partial tile when parts > 1
+    uint32_t arrived;                     // items of a block of several that have left their partial tile (the last one adds them up)
+};
+static_assert(sizeof(TileDesc) == 64, "one 64-byte line per block");
 struct TileItem { uint32_t bh, blk, part, pidx; };          // one extra work item (part >= 1)
 
 struct TileReduceArgs {
@@ -79,11 +90,89 @@ struct TileReduceArgs {
     const CellHeader *hdr;                // level rows (device)
     int cell_stride;
     TileHeader *th;
-    TileInfo *tinfo;                      // [B, H, blocks_bound]
+    TileDesc *tdesc;                      // [B, H, blocks_bound]
     TileItem *titems;                     // [kTileLanes, cap_extra]
+    uint32_t *slice_done;                 // [B, H] sort workgroups of the slice that have finished (zeroed with the cursors)
     float *tpartials;                     // [cap_partials, kTB*kTB, D]
     int blocks_bound;
 };
+constexpr uint32_t kVoidPart = 0xffffffffu;
+
+#ifdef __HIPCC__
+// The blocks of one (b, h) slice: descriptor (record runs, position) and, from the length of the list,
+// the number of work items; the extra ones are queued (one queue lane per XCD, keyed by h like every
+// other kernel's head -> XCD affinity).  Run by the LAST sort workgroup of the slice (the cell table
+// it reads was written by the slice's sort workgroups, which share an XCD and so an L2): thread `tid`
+// of `nthreads` takes blocks tid, tid + nthreads, ...
+__device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d, int64_t bh, int tid, int nthreads)
+{
+    const LevelRow *lv = level_rows(a.hdr);
+    const int nblk = a.hdr->n_blocks4;
+    for (int blk = tid; blk < nblk; blk += nthreads) {
+        int level = 0;
+        while (level + 1 < d.L && blk >= lv[level + 1].bbase4) ++level;
+        while (level < d.L && lv[level].nbx4 * lv[level].nby4 == 0) ++level;        // (empty levels own no block)
+        TileDesc td;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { td.first[r] = 0; td.cnt[r] = 0; }
+        td.hw = 0; td.lstart = 0; td.byx = 0; td.parts = 1; td.pbase = 0; td.arrived = 0;
+        if (level < d.L) {
+            const LevelRow lr = lv[level];
+            const int rel = blk - lr.bbase4, by = rel / lr.nbx4, bx = rel - by * lr.nbx4;
+            const uint2 *tab = a.celltab + bh * a.cell_stride + lr.cbase;
+            uint2 ent[kTB + 1][kTB + 1];
+#pragma unroll
+            for (int dy = 0; dy <= kTB; ++dy)
+#pragma unroll
+                for (int dx = 0; dx <= kTB; ++dx) {
+                    const int cy = kTB * by + dy, cx = kTB * bx + dx;
+                    ent[dy][dx] = make_uint2(0u, 0u);
+                    if (cy <= lr.Hl && cx <= lr.Wl) {
+                        const unsigned long long e = __hip_atomic_load(
+                            reinterpret_cast<const unsigned long long *>(&tab[cy * (lr.Wl + 1) + cx]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ent[dy][dx] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+                    }
+                }
+            int64_t n = 0;
+#pragma unroll
+            for (int dy = 0; dy <= kTB; ++dy) {
+                td.first[dy] = (int)ent[dy][0].x;               // (the cells of a row are one contiguous run)
+                int c = 0;
+#pragma unroll
+                for (int dx = 0; dx <= kTB; ++dx) c += (int)ent[dy][dx].y;
+                td.cnt[dy] = c;
+                n += c;
+            }
+            td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
+            td.lstart = lr.lstart;
+            td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
+            const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
+            if (parts > 1) {
+                const int ql = (int)(bh % d.H) % kTileLanes;
+                const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
+                const uint32_t eb = atomicAdd(&a.th->n_extra[ql], parts - 1);
+                if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
+                    td.parts = parts; td.pbase = pb;
+                    for (uint32_t p = 1; p < parts; ++p) {
+                        TileItem ti;
+                        ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = p; ti.pidx = pb + p;
+                        a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+                    }
+                } else if (eb < a.th->cap_extra) {
+                    // reserved queue entries that cannot be used must read as "nothing to do"
+                    for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
+                        TileItem ti;
+                        ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = kVoidPart; ti.pidx = 0;
+                        a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+                    }
+                }
+            }
+        }
+        a.tdesc[bh * a.blocks_bound + blk] = td;
+    }
+}
+#endif
+
 // 16-bit storage, D in {32, 64, 128}; MMFS_VALUE_ALGO=block keeps the vector-ALU reduce
 bool tile_reduce_supported(int dtype, const Dims &d);
 hipError_t tile_reduce(int dtype, const void *grad_out, void *grad_value, const TileReduceArgs &a, const Dims &d,

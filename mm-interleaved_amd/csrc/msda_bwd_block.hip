@@ -108,7 +108,7 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
     if (threadIdx.x != 0) return;
     if (th != nullptr) {
         for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
-        th->n_partials = 0u; th->cap_extra = tile_cap_extra; th->cap_partials = tile_cap_partials; th->pad = 0u;
+        th->n_partials = 0u; th->cap_extra = tile_cap_extra; th->cap_partials = tile_cap_partials; th->n_multi = 0u;
         th->null_rec = make_uint4(0u, __float_as_uint(-8.f), __float_as_uint(-8.f), 0u);
     }
     ovf_header[0] = 0u; ovf_header[1] = cap_slots; ovf_header[2] = cap_entries;                         // OvfHeader
@@ -267,7 +267,8 @@ template <typename T, int NV>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
-                   const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride)
+                   const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride,
+                   const TileReduceArgs ta)
 {
     __shared__ uint32_t off[kMaxTileCells + 1];
     __shared__ uint32_t cur[kMaxTileCells];
@@ -300,7 +301,25 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
     uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + tl.cbase;
     for (int p = tid; p < ncell; p += kThreads) {
         const int cg = (tl.ya + p / tw) * (tl.Wl + 1) + tl.xa + p % tw;
-        tab[cg] = make_uint2((uint32_t)(base + off[p]), off[p + 1] - off[p]);
+        // (written through, agent scope: the slice's last workgroup reads the table within this launch)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&tab[cg]),
+                           ((unsigned long long)(off[p + 1] - off[p]) << 32) | (unsigned long long)(uint32_t)(base + off[p]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Matrix-core reduce: the LAST workgroup of the (b, h) slice turns the slice's cell table into block
+    // descriptors and work items.  Hand-off inside the launch without the L2 write-back of a release
+    // fence (with the record scatter in flight that write-back costs more than the sort): the table is
+    // stored and read with 8-byte agent-scope accesses, the stores are drained before the arrival
+    // counter moves (cdna_hip_programming.md guideline 16, "8-B agent atomics both sides").
+    if (ta.th != nullptr) {
+        __shared__ uint32_t arrived;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            arrived = __hip_atomic_fetch_add(&ta.slice_done[(int64_t)b * d.H + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (arrived == (uint32_t)hdr->n_tiles - 1u)
+            plan_slice_blocks(ta, d, (int64_t)b * d.H + h, tid, kThreads);
     }
 }
 
@@ -753,8 +772,9 @@ struct Scratch {
     uint32_t cap_slots, cap_entries, cap_partials;
     // matrix-core reduce (msda_bwd_tile.hip): header, per-block info, queued extra items, fp32 partial tiles
     TileHeader *th;
-    TileInfo *tinfo;
+    TileDesc *tdesc;
     TileItem *titems;
+    uint32_t *slice_done;
     float *tpartials;
     uint32_t tile_cap_extra, tile_cap_partials;
     int tile_blocks_bound;     // >= 4x4 blocks of one (b, h)
@@ -770,7 +790,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     char *p = (char *)workspace;
     s.loc_t = p;                 p += up(pts * 2 * es);
     s.attn_t = p;                p += up(pts * es);
-    s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.cursor = (uint32_t *)p;    s.cursor_bytes = up(((int64_t)d.B * d.H * d.L + (int64_t)d.B * d.H) * 4);  p += s.cursor_bytes;   // + one arrival counter per slice
     s.hdr = (CellHeader *)p;
     p += up((int64_t)sizeof(CellHeader) + (int64_t)d.L * sizeof(LevelRow) + (int64_t)make_params(d).tiles_bound * sizeof(CTile));
     s.celltab = (uint2 *)p;      p += up((int64_t)d.B * d.H * cell_stride_of(d) * 8);
@@ -793,7 +813,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     // ceil(n / kTileChunk) items, so items and partial tiles are bounded by twice the visits / kTileChunk.  (The
     // bounds assume the AVERAGE 25/16 visits per sample; a block whose items or tiles do not fit is walked by one
     // wave alone -- slow, still correct.)
-    s.th = nullptr; s.tinfo = nullptr; s.titems = nullptr; s.tpartials = nullptr;
+    s.th = nullptr; s.tdesc = nullptr; s.titems = nullptr; s.slice_done = nullptr; s.tpartials = nullptr;
     s.tile_cap_extra = s.tile_cap_partials = 0; s.tile_blocks_bound = 0;
     if (tile_reduce_supported(dtype, d)) {
         const int64_t tvisits = pts * (kTB + 1) * (kTB + 1) / (kTB * kTB);
@@ -801,12 +821,22 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
         s.tile_cap_partials = (uint32_t)std::min<int64_t>(2 * (tvisits / kTileChunk) + 64, 0x3fffffff);
         s.tile_cap_extra = (uint32_t)std::min<int64_t>((tvisits / kTileChunk) / kTileLanes * 2 + 64, 0x3fffffff);   // per lane
         s.th = (TileHeader *)p;      p += up(sizeof(TileHeader));
-        s.tinfo = (TileInfo *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TileInfo));
+        s.tdesc = (TileDesc *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TileDesc));
         s.titems = (TileItem *)p;    p += up((int64_t)kTileLanes * s.tile_cap_extra * sizeof(TileItem));
+        s.slice_done = s.cursor + (int64_t)d.B * d.H * d.L;      // (zeroed with the cursors by backward_value_prepare)
         s.tpartials = (float *)p;    p += up((int64_t)s.tile_cap_partials * kTB * kTB * d.D * 4);
     }
     s.total = p - (char *)workspace;
     return s;
+}
+
+TileReduceArgs tile_args(const Scratch &sc, const Dims &d)
+{
+    TileReduceArgs a;
+    a.records = sc.records; a.celltab = sc.celltab; a.hdr = sc.hdr; a.cell_stride = cell_stride_of(d);
+    a.th = sc.th; a.tdesc = sc.tdesc; a.titems = sc.titems; a.slice_done = sc.slice_done; a.tpartials = sc.tpartials;
+    a.blocks_bound = sc.tile_blocks_bound;
+    return a;
 }
 
 template <typename T, int NV>
@@ -821,7 +851,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
                        sc.cap_partials, sc.th, sc.tile_cap_extra, sc.tile_cap_partials);
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                       cell_stride_of(d));
+                       cell_stride_of(d), tile_args(sc, d));
     return hipGetLastError();
 }
 
@@ -924,10 +954,7 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
     if (sc.th != nullptr) {
-        TileReduceArgs a;
-        a.records = sc.records; a.celltab = sc.celltab; a.hdr = sc.hdr; a.cell_stride = cell_stride_of(d);
-        a.th = sc.th; a.tinfo = sc.tinfo; a.titems = sc.titems; a.tpartials = sc.tpartials;
-        a.blocks_bound = sc.tile_blocks_bound;
+        const TileReduceArgs a = tile_args(sc, d);
         return tile_reduce(dtype, grad_out, grad_value, a, d, st);
     }
     switch (dtype) {

@@ -29,7 +29,8 @@
 //     exchange one value so that every lane stores whole dwords.
 //   * A list longer than kTileChunk records (small levels, hot spots -- every text token of the LLM
 //     path samples around the same reference point) is cut into work items planned on the device; a
-//     block of several items leaves fp32 partial tiles that a last small kernel adds up and rounds.
+//     block of several items leaves fp32 partial tiles; the item that finishes last adds them up and rounds.
+//     The planning itself rides on the tail of the sort kernel (plan_slice_blocks, msda_bwd_block.h).
 //
 // Semantics that differ from the gather kernels, by construction of a matrix product: a non-finite
 // grad_out element reaches all 16 pixels of the blocks its sample touches (0 * Inf = NaN), not only
@@ -37,6 +38,7 @@
 #include "msda_bwd_block.h"
 #include "msda_launch.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mmfs {
 namespace blk {
@@ -50,24 +52,22 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kKS = 16;                 // records per MFMA step (K of 32x32x16)
-constexpr int kStages = 3;              // row slots: one being multiplied, two in flight
-constexpr int kRecSlots = 5;            // record slots: fetched four steps ahead of their weights
+constexpr int kStages = 2;              // row slots: one being multiplied, one in flight (more waves per CU beat a deeper pipe)
+constexpr int kRecBatch = 4 * kKS;      // records fetched at a time (one DMA, 64 lanes): four steps' worth
+constexpr int kRecSlots = 2;            // record batches in LDS
 constexpr int kQueueWgs = 256 * kTileLanes;   // workgroups that walk the queue of extra items
-constexpr uint32_t kVoidPart = 0xffffffffu;
 
 template <typename T> struct TileMma;
 template <> struct TileMma<bf16_t> {
     static __device__ __forceinline__ f32x16 run(const s16x8 &a, const s16x8 &b, const f32x16 &c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
-    // fp32 weight -> leading 16 bits, rounded remainder (weights are finite: products of fractions
-    // and a finite attention weight... an infinite attention weight stays infinite in hi, lo = 0)
+    // fp32 weight -> leading 16 bits, rounded remainder.  (A non-finite weight -- a non-finite attention
+    // weight -- ends as NaN in the sums either way: Inf - Inf in the remainder.)
     static __device__ __forceinline__ void split(float w, uint16_t &hi, uint16_t &lo) {
         const uint32_t h = __float_as_uint(w) & 0xffff0000u;
-        const bool special = (__float_as_uint(w) & 0x7f800000u) == 0x7f800000u;      // Inf / NaN
-        const float r = special ? 0.f : w - __uint_as_float(h);                       // exact
-        hi = (uint16_t)((w != w ? 0x7fc00000u : h) >> 16);
-        lo = __builtin_bit_cast(uint16_t, (__bf16)r);
+        hi = (uint16_t)(h >> 16);
+        lo = __builtin_bit_cast(uint16_t, (__bf16)(w - __uint_as_float(h)));           // the difference is exact
     }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) { return Vec16<bf16_t>::pk(a, b); }
 };
@@ -93,13 +93,35 @@ template <int D> struct TileGeom {
     static constexpr int NB = D / 32;              // 32-channel column blocks = MFMAs per step
     static constexpr int RP = 256 / RB;            // rows per 256 bytes (one pass over the 64 banks)
     static constexpr int SLOT = kKS * RB;          // bytes of a row slot
-    static constexpr int LDS_BYTES = kStages * SLOT + kRecSlots * 256 + 1024;
+    static constexpr int ROWS_BYTES = kStages * SLOT > 16 * (RB + 16) ? kStages * SLOT : 16 * (RB + 16);   // (the epilogue stages the block's rows here, pitch RB + 16)
+    static constexpr int REC_BYTES = kRecSlots * kRecBatch * 16;
+    static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES + 1024;
     // chunk swizzle of row r (row index inside its slot): the 4 rows a 16-lane group of a transposing
     // read touches together must land in different banks
     static __device__ __forceinline__ int swz(int r) { return 4 * ((r / RP) % (4 / RP)); }
 };
 
 #define MMFS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+
+// Development aid (tools/exp_build.sh tprof "-DMMFS_PROFILE_TILE"): shader clocks per phase of a work
+// item, summed over items, read back with mmfs_debug_tile_profile().
+#ifdef MMFS_PROFILE_TILE
+}  // namespace
+constexpr int kProfSlots = 32768;
+__device__ unsigned long long g_tile_prof[kProfSlots * 12];     // one row per workgroup (mod kProfSlots): no contended atomics
+namespace {
+// (the deltas are kept in registers and flushed once, at the end of the item: an atomic per phase would sit
+// in the very vmcnt queue the phases wait on)
+#define TPROF_DECL unsigned long long tprof_c = __builtin_readcyclecounter(), tprof_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TPROF(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tprof_t[i] += tn - tprof_c; tprof_c = tn; } while (0)
+#define TPROF_COUNT(i, v) do { tprof_t[i] += (unsigned long long)(v); } while (0)
+#define TPROF_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_tile_prof[(blockIdx.x % kProfSlots) * 12 + i_], tprof_t[i_]); } while (0)
+#else
+#define TPROF_FLUSH() do {} while (0)
+#define TPROF_DECL do {} while (0)
+#define TPROF(i) do {} while (0)
+#define TPROF_COUNT(i, v) do {} while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -108,76 +130,57 @@ __device__ __forceinline__ void dma16(const void *src, void *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 16, 0, 0);
 }
+// 16 bytes per lane from rsrc + voffset to lds_dst + lane * 16; an offset past the descriptor's
+// extent moves nothing (or zeros): what a record past the end of a list asks for
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, void *lds_dst)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_dst, 16, (int)voffset, 0, 0, 0);
+}
 
 __device__ __forceinline__ int mfma_row32(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// level of a 4x4 block (uniform over the wave)
-__device__ __forceinline__ int level_of_block4(const LevelRow *__restrict__ lv, int L, int blk, int lane)
-{
-    for (int l0 = 0; l0 < L; l0 += 64) {
-        const int l = l0 + lane;
-        bool hit = false;
-        if (l < L) {
-            const int bb = lv[l].bbase4, cnt = lv[l].nbx4 * lv[l].nby4;
-            hit = blk >= bb && blk < bb + cnt;
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-        if (m) return l0 + (int)__builtin_ctzll(m);
-    }
-    return -1;
-}
+struct ItemArgs { int b, h, part; bool whole, partial_out; uint32_t pidx; };
 
-// the five record runs of a block (one per cell row) as one list: run r holds [pre[r], pre[r+1])
-struct Runs5 { int first[5]; int pre[6]; };
-
-__device__ __forceinline__ Runs5 block_runs(const uint2 *__restrict__ tab, const LevelRow &lr, int by, int bx, int lane)
-{
-    uint2 ent = make_uint2(0u, 0u);
-    if (lane < 25) {
-        const int cy = kTB * by + lane / 5, cx = kTB * bx + lane % 5;
-        if (cy <= lr.Hl && cx <= lr.Wl) ent = tab[cy * (lr.Wl + 1) + cx];
-    }
-    Runs5 r;
-    r.pre[0] = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        r.first[j] = __builtin_amdgcn_readlane((int)ent.x, 5 * j);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) c += __builtin_amdgcn_readlane((int)ent.y, 5 * j + i);
-        r.pre[j + 1] = r.pre[j] + c;
-    }
-    return r;
-}
-
-struct ItemArgs { int b, h, blk, part; bool whole, partial_out; uint32_t pidx; };
-
+// One work item = up to kTileChunk records of one block's list (all of it when `whole`).
+//
+// Software pipeline, four steps per round so that every LDS address is an immediate (two row slots,
+// a batch of 64 records per round):
+//   step k (slot k % 2):   wait for rows(k) -> request rows(k + 1) -> multiply step k
+//   first step of round j: also request record batch j + 1 (its slot was last read in round j - 1)
+// Every request is issued whether or not the list reaches that far (a request past the end moves no
+// data), so the number of requests in flight at each wait is a compile-time constant:
+//   ... | rows(4j+1) recs(j+1) | rows(4j+2) | rows(4j+3) | rows(4j+4) | rows(4j+5) recs(j+2) | ...
+//   step 4j+1 needs rows(4j+1): issued after it: recs(j+1) -> vmcnt(1);  step 4j+3 needs rows(4j+3) and
+//   recs(j+1) (for rows(4j+4)) -> vmcnt(0);  the others: vmcnt(0).
 template <typename T, int D>
 __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__restrict__ grad_value,
-                                          const TileReduceArgs &a, const Dims &d, const ItemArgs &it,
-                                          unsigned char *__restrict__ rows, unsigned char *__restrict__ recs,
-                                          unsigned char *__restrict__ atile)
+                                          const TileReduceArgs &a, const Dims &d, const TileDesc &td, const ItemArgs &it,
+                                          uint32_t *arrived_ctr, unsigned char *__restrict__ lds)
 {
     typedef TileGeom<D> G;
     typedef TileMma<T> M;
+    unsigned char *rows = lds, *recs = lds + G::ROWS_BYTES, *atile = recs + G::REC_BYTES;
     const int lane = threadIdx.x;
-    const LevelRow *lv = level_rows(a.hdr);
-    const int level = level_of_block4(lv, d.L, it.blk, lane);
-    if (level < 0) return;
-    const LevelRow lr = lv[level];
-    const int rel = it.blk - lr.bbase4;
-    const int by = rel / lr.nbx4, bx = rel - by * lr.nbx4;
-    const int64_t bh = (int64_t)it.b * d.H + it.h;
-    const Runs5 ru = block_runs(a.celltab + bh * a.cell_stride + lr.cbase, lr, by, bx, lane);
-    const int n = ru.pre[5];
+    TPROF_DECL;
+    const int Hl = (int)(td.hw >> 16), Wl = (int)(td.hw & 0xffffu);
+    const int by = (int)(td.byx >> 16), bx = (int)(td.byx & 0xffffu);
+    int pre[6];
+    pre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) pre[r + 1] = pre[r] + td.cnt[r];
+    const int n = pre[5];
     const int e0 = it.part * kTileChunk;
     const int e1 = it.whole ? n : min(n, e0 + kTileChunk);
-    const int nks = e1 > e0 ? (e1 - e0 + kKS - 1) / kKS : 0;
+    const int cnt = e1 > e0 ? e1 - e0 : 0;                        // records of this item
+    const int nks = (cnt + kKS - 1) / kKS;
+    const int rounds = (nks + 3) / 4;
+    if (__builtin_amdgcn_readfirstlane(n) >= 0) TPROF(0);          // descriptor arrived
+    TPROF_COUNT(8, 1); TPROF_COUNT(9, rounds); TPROF_COUNT(10, nks);
 
-    const int64_t HDB = (int64_t)d.H * d.D * (int64_t)sizeof(T);                  // bytes between consecutive queries
-    const char *gslice = (const char *)(grad_out + ((int64_t)it.b * d.Nq * d.H + it.h) * d.D);
-    const int64_t zero_off = (const char *)a.th->zero_row - gslice;
-    const uint4 *null_rec = &a.th->null_rec;
+    const uint32_t HDB = (uint32_t)(d.H * d.D) * (uint32_t)sizeof(T);            // bytes between consecutive queries
+    const T *gslice = grad_out + ((int64_t)it.b * d.Nq * d.H + it.h) * d.D;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        make_slab_rsrc(gslice, ((int64_t)d.Nq * d.H * d.D - (int64_t)it.h * d.D) * (int64_t)sizeof(T));
 
     f32x16 acc[G::NB];
 #pragma unroll
@@ -185,102 +188,129 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-    // records of step s -> record slot s % kRecSlots (16 lanes, one record each)
-    auto issue_records = [&](int s) {
-        if (lane < kKS) {
-            const int e = e0 + kKS * s + lane;
-            const uint4 *src = null_rec;
-            if (e < e1) {
-                int j = 0, del = ru.first[0] - ru.pre[0];
-#pragma unroll
-                for (int k = 1; k < 5; ++k)
-                    if (e >= ru.pre[k]) { j = k; del = ru.first[k] - ru.pre[k]; }
-                (void)j;
-                src = a.records + (uint32_t)(e + del);
-            }
-            dma16(src, recs + (s % kRecSlots) * 256);
-        }
-    };
-    // grad_out rows of step s -> row slot s % kStages (needs the step's records in LDS)
-    auto issue_rows = [&](int s) {
-        const uint32_t *rq = reinterpret_cast<const uint32_t *>(recs + (s % kRecSlots) * 256);
-        unsigned char *slot = rows + (s % kStages) * G::SLOT;
-        uint32_t q[G::NR];
-#pragma unroll
-        for (int u = 0; u < G::NR; ++u) q[u] = rq[(u * G::RPI + lane / G::LPR) * 4];      // (a void record reads q = 0)
-#pragma unroll
-        for (int u = 0; u < G::NR; ++u) {
-            const int rr = u * G::RPI + lane / G::LPR;
-            const int chunk = (lane % G::LPR) ^ G::swz(rr);
-            const bool valid = e0 + kKS * s + rr < e1;
-            // branch-free: a row past the end of the list is the zero row of the header
-            const int64_t off = valid ? (int64_t)q[u] * HDB : zero_off;
-            dma16(gslice + off + chunk * 16, slot + u * 1024);
-        }
-    };
+    if (rounds > 0) {
+        // rows past the end of the list are never written: they must not hold stale non-finite bits
+        for (int i = lane; i < kStages * G::SLOT / 16; i += 64) reinterpret_cast<uint4 *>(rows)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    if (nks > 0) issue_records(0);
-    if (nks > 1) issue_records(1);
-    for (int i = -2; i < nks; ++i) {
-        // wait for records(i+2) and rows(i): everything issued before them, i.e. all but
-        // rows(i+1) [NR ops, issued in the previous round] and records(i+3) [1 op, likewise]
-        const bool rows_next = i >= -1 && i + 1 < nks, rec_next = i + 3 < nks;
-        if (rows_next && rec_next) MMFS_WAIT_VM(G::NR + 1);
-        else if (rows_next) MMFS_WAIT_VM(G::NR);
-        else if (rec_next) MMFS_WAIT_VM(1);
-        else MMFS_WAIT_VM(0);
-        if (i + 2 < nks) issue_rows(i + 2);
-        if (i + 4 < nks) issue_records(i + 4);
-        if (i < 0) continue;
-
-        // ---- weight tile of step i: 16 records x 4 corners, one weight per lane
-        reinterpret_cast<uint4 *>(atile)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        {
-            const int r = lane >> 2, c = lane & 3;
-            const uint4 rec = reinterpret_cast<const uint4 *>(recs + (i % kRecSlots) * 256)[r];
-            const float y = __uint_as_float(rec.y), x = __uint_as_float(rec.z), av = __uint_as_float(rec.w);
-            const float yf = floorf(y), xf = floorf(x);
-            const float fy = y - yf, fx = x - xf;
-            const int iy = (int)yf + (c >> 1) - kTB * by, ix = (int)xf + (c & 1) - kTB * bx;
-            const float wy = (c >> 1) ? fy : 1.f - fy, wx = (c & 1) ? fx : 1.f - fx;
-            const float wgt = wy * wx * av;
-            if ((unsigned)iy < (unsigned)kTB && (unsigned)ix < (unsigned)kTB) {
-                uint16_t hi, lo;
-                M::split(wgt, hi, lo);
-                const int m = iy * kTB + ix;
-                reinterpret_cast<uint16_t *>(atile)[m * kKS + r] = hi;
-                reinterpret_cast<uint16_t *>(atile)[(16 + m) * kKS + r] = lo;
-            }
-        }
-        const s16x8 A = *reinterpret_cast<const s16x8 *>(atile + (lane & 31) * 32 + (lane >> 5) * 16);
-
-        // ---- rows of step i as B operands, one MFMA per 32 channels
-        const unsigned char *slot = rows + (i % kStages) * G::SLOT;
+        // lane constants
+        const int rsel = lane / G::LPR;                                     // row of a DMA instruction this lane serves
         const int g4 = lane >> 4, j16 = lane & 15;
+        int troff[G::NB];                                                   // transposing-read offsets inside a slot
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb) {
-            s16x8 B;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int krow = 8 * (g4 >> 1) + 4 * t + (j16 >> 2);
-                const int cb = nb * 64 + (g4 & 1) * 32 + (j16 & 3) * 8;             // byte offset inside the row
-                const int off = krow * G::RB + (((cb >> 4) ^ G::swz(krow)) << 4) + (cb & 15);
-                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4 *)(slot + off));
-                B[4 * t] = v[0]; B[4 * t + 1] = v[1]; B[4 * t + 2] = v[2]; B[4 * t + 3] = v[3];
-            }
-            acc[nb] = M::run(A, B, acc[nb]);
+            const int krow = 8 * (g4 >> 1) + (j16 >> 2);                    // (+ 4 for the second read: same swizzle)
+            const int cb = nb * 64 + (g4 & 1) * 32 + (j16 & 3) * 8;
+            troff[nb] = krow * G::RB + (((cb >> 4) ^ G::swz(krow)) << 4) + (cb & 15);
         }
+        const int a_rd = (lane & 31) * 32 + (lane >> 5) * 16;               // this lane's 16 bytes of the A operand
+        const int wr = lane >> 2, wc = lane & 3;                            // weight tile: record, corner
+        const int iy0 = (wc >> 1) - kTB * by, ix0 = (wc & 1) - kTB * bx;
+
+        // record batch j -> slot j % 2 (48 lanes, one record each)
+        auto issue_records = [&](int j) {
+            if (lane < kRecBatch) {
+                const int e = e0 + kRecBatch * j + lane;
+                uint32_t idx = 0u;                                           // (any valid address: never looked at)
+                if (e < e1) {
+                    int del = td.first[0] - pre[0];
+#pragma unroll
+                    for (int k = 1; k < 5; ++k)
+                        if (e >= pre[k]) del = td.first[k] - pre[k];
+                    idx = (uint32_t)(e + del);
+                }
+                dma16(a.records + idx, recs + (j & 1) * (kRecBatch * 16));
+            }
+        };
+        // grad_out rows of step k = 4j + S -> row slot S % 2
+        auto issue_rows = [&](int j, auto stage) {
+            constexpr int S = decltype(stage)::value;
+            const uint32_t *rq = reinterpret_cast<const uint32_t *>(recs + (j & 1) * (kRecBatch * 16) + S * (kKS * 16));
+            const int rel0 = kKS * (4 * j + S);
+            uint32_t q[G::NR];
+#pragma unroll
+            for (int u = 0; u < G::NR; ++u) q[u] = rq[(u * G::RPI + rsel) * 4];
+#pragma unroll
+            for (int u = 0; u < G::NR; ++u) {
+                const int rr = u * G::RPI + rsel;
+                const uint32_t chunk = (uint32_t)((lane % G::LPR) ^ G::swz(rr));
+                const uint32_t off = rel0 + rr < cnt ? __umul24(q[u], HDB) + chunk * 16u : kOobOffset;     // (Nq, H*D*e < 2^24: checked on the host)
+                dma16_buf(rsrc, off, rows + (S % 2) * G::SLOT + u * 1024);
+            }
+        };
+        auto multiply = [&](int j, auto stage) {
+            constexpr int S = decltype(stage)::value;
+            // ---- weight tile: 16 records x 4 corners, one weight per lane
+            reinterpret_cast<uint4 *>(atile)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            {
+                const uint4 rec = reinterpret_cast<const uint4 *>(recs + (j & 1) * (kRecBatch * 16) + S * (kKS * 16))[wr];
+                const float y = __uint_as_float(rec.y), x = __uint_as_float(rec.z), av = __uint_as_float(rec.w);
+                const float yf = floorf(y), xf = floorf(x);
+                const float fy = y - yf, fx = x - xf;
+                const int iy = (int)yf + iy0, ix = (int)xf + ix0;
+                const float wy = (wc >> 1) ? fy : 1.f - fy, wx = (wc & 1) ? fx : 1.f - fx;
+                const float wgt = wy * wx * av;
+                if (kKS * (4 * j + S) + wr < cnt && (unsigned)iy < (unsigned)kTB && (unsigned)ix < (unsigned)kTB) {
+                    uint16_t hi, lo;
+                    M::split(wgt, hi, lo);
+                    const int m = iy * kTB + ix;
+                    reinterpret_cast<uint16_t *>(atile)[m * kKS + wr] = hi;
+                    reinterpret_cast<uint16_t *>(atile)[(16 + m) * kKS + wr] = lo;
+                }
+            }
+            const s16x8 A = *reinterpret_cast<const s16x8 *>(atile + a_rd);
+            // ---- the step's rows as B operands, one MFMA per 32 channels
+            const unsigned char *slot = rows + (S % 2) * G::SLOT;
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) {
+                s16x8 B;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(slot + troff[nb] + t * 4 * G::RB));
+                    B[4 * t] = v[0]; B[4 * t + 1] = v[1]; B[4 * t + 2] = v[2]; B[4 * t + 3] = v[3];
+                }
+                acc[nb] = M::run(A, B, acc[nb]);
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        using S3 = std::integral_constant<int, 3>;
+
+        // prologue: recs(0) | rows(0)
+        issue_records(0);
+        MMFS_WAIT_VM(0);
+        TPROF(1);                                                 // LDS cleared, first records landed
+        issue_rows(0, S0{});
+        for (int j = 0; j < rounds; ++j) {
+            MMFS_WAIT_VM(0);
+            if (j == 0) TPROF(2);                                 // first rows landed
+            issue_rows(j, S1{});                                  // rows(4j + 1)
+            issue_records(j + 1);
+            if (4 * j < nks) multiply(j, S0{});
+            MMFS_WAIT_VM(1);
+            issue_rows(j, S2{});
+            if (4 * j + 1 < nks) multiply(j, S1{});
+            MMFS_WAIT_VM(0);
+            issue_rows(j, S3{});
+            if (4 * j + 2 < nks) multiply(j, S2{});
+            MMFS_WAIT_VM(0);
+            issue_rows(j + 1, S0{});                              // rows(4j + 4): first step of batch j + 1
+            if (4 * j + 3 < nks) multiply(j, S3{});
+        }
+        TPROF(3);                                                 // rounds
+        MMFS_WAIT_VM(0);                                          // (requests past the end of the list)
+        TPROF(4);
     }
 
-    // ---- epilogue: hi + lo rows, lane pairs exchange so that every lane stores whole dwords
+    // ---- epilogue: hi + lo rows; lane pairs exchange one value so that every lane holds whole dwords
     const bool odd = lane & 1;
     const int ch0 = (lane & 31) & ~1;
+    constexpr int PITCH = G::RB + 16;                             // staging pitch: rows 8 apart in different banks
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int pa = mfma_row32(r, lane), pb = mfma_row32(r + 4, lane);      // pixels 0..15 of the block
         const int p = odd ? pb : pa;
-        const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb) {
             const float va = acc[nb][r] + acc[nb][r + 8], vb = acc[nb][r + 4] + acc[nb][r + 12];
@@ -288,26 +318,85 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             const float lo_ch = odd ? recv : va, hi_ch = odd ? vb : recv;       // channels ch0, ch0 + 1 of pixel p
             const int ch = nb * 32 + ch0;
             if (it.partial_out) {
-                float2 *o = reinterpret_cast<float2 *>(a.tpartials + ((int64_t)it.pidx * (kTB * kTB) + p) * D + ch);
-                *o = make_float2(lo_ch, hi_ch);
-            } else if (y < lr.Hl && x < lr.Wl) {
-                T *o = grad_value + (((int64_t)it.b * d.S + lr.lstart + y * lr.Wl + x) * d.H + it.h) * d.D + ch;
-                *reinterpret_cast<uint32_t *>(o) = M::pack2(lo_ch, hi_ch);
+                // (written through, agent scope: another item of the block adds the tiles up within this launch)
+                float *o = a.tpartials + ((int64_t)it.pidx * (kTB * kTB) + p) * D + ch;
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(o),
+                                   ((unsigned long long)__float_as_uint(hi_ch) << 32) | (unsigned long long)__float_as_uint(lo_ch),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *reinterpret_cast<uint32_t *>(rows + p * PITCH + ch * 2) = M::pack2(lo_ch, hi_ch);
             }
         }
     }
+    if (it.partial_out) {
+        // A block of several items: the item that arrives last adds the partial tiles up (in tile order,
+        // whoever is last) and rounds.  The tiles are stored and read with agent-scope accesses and the
+        // stores are drained before the counter moves: no L2 write-back (a release fence here writes
+        // back every dirty grad_value line of the XCD, measured: the kernel twice as slow).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t prev = 0u;
+        if (lane == 0) prev = __hip_atomic_fetch_add(arrived_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+        if (prev == td.parts - 1u) {
+            constexpr int CPL = D >= 128 ? 2 : 1;                  // channels per lane
+            const int ch = lane * CPL;
+            float s[kTB * kTB][CPL];
+#pragma unroll
+            for (int p = 0; p < kTB * kTB; ++p)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) s[p][k] = 0.f;
+            if (ch < D) {
+                for (uint32_t c = 0; c < td.parts; ++c) {
+                    const float *src = a.tpartials + (int64_t)(td.pbase + c) * (kTB * kTB) * D + ch;
+#pragma unroll
+                    for (int p = 0; p < kTB * kTB; ++p) {
+                        if (CPL == 2) {
+                            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + p * D),
+                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s[p][0] += __uint_as_float((uint32_t)v); s[p][CPL - 1] += __uint_as_float((uint32_t)(v >> 32));
+                        } else {
+                            s[p][0] += __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(src + p * D),
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < kTB * kTB; ++p) {
+                    const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
+                    if (y < Hl && x < Wl) {
+                        T *o = grad_value + (((int64_t)it.b * d.S + td.lstart + y * Wl + x) * d.H + it.h) * d.D + ch;
+                        if (CPL == 2) *reinterpret_cast<uint32_t *>(o) = M::pack2(s[p][0], s[p][CPL - 1]);
+                        else o[0] = (T)s[p][0];
+                    }
+                }
+            }
+        }
+    } else {
+        // the block's 16 rows leave as whole 16-byte chunks, LPR consecutive lanes per row
+#pragma unroll
+        for (int i = 0; i < kTB * kTB * G::LPR / 64; ++i) {
+            const int c = i * 64 + lane, p = c / G::LPR, chunk = c % G::LPR;
+            const uint4 v = *reinterpret_cast<const uint4 *>(rows + p * PITCH + chunk * 16);
+            const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
+            if (y < Hl && x < Wl) {
+                T *o = grad_value + (((int64_t)it.b * d.S + td.lstart + y * Wl + x) * d.H + it.h) * d.D + chunk * 8;
+                *reinterpret_cast<uint4 *>(o) = v;
+            }
+        }
+    }
+    TPROF(5);                                                     // epilogue issued
+    TPROF_FLUSH();
 }
 
 // One wave per work item.  The first kQueueWgs workgroups walk the queue of extra items (the later
 // parts of long lists: started first, they are the long poles); every other workgroup is one block.
 template <typename T, int D>
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, 4)
 msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value, const TileReduceArgs a,
                      const Dims d, const int blocks_grid)
 {
     typedef TileGeom<D> G;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
-    unsigned char *rows = lds, *recs = lds + kStages * G::SLOT, *atile = recs + kRecSlots * 256;
     int w = blockIdx.x;
     if (w < kQueueWgs) {
         const int ql = w % kTileLanes;
@@ -317,8 +406,10 @@ msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
             if (ti.part == kVoidPart) continue;            // a reservation its block could not use
             ItemArgs it;
             it.b = (int)(ti.bh / (uint32_t)d.H); it.h = (int)(ti.bh % (uint32_t)d.H);
-            it.blk = (int)ti.blk; it.part = (int)ti.part; it.whole = false; it.partial_out = true; it.pidx = ti.pidx;
-            tile_item<T, D>(grad_out, grad_value, a, d, it, rows, recs, atile);
+            it.part = (int)ti.part; it.whole = false; it.partial_out = true; it.pidx = ti.pidx;
+            TileDesc *tdp = a.tdesc + ((int64_t)ti.bh * a.blocks_bound + ti.blk);
+            const TileDesc td = *tdp;
+            tile_item<T, D>(grad_out, grad_value, a, d, td, it, &tdp->arrived, lds);
         }
         return;
     }
@@ -330,94 +421,11 @@ msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
     const int j = t % blocks_grid;
     it.b = t / blocks_grid;
     if (j >= nblk) return;
-    it.blk = nblk - 1 - j;                      // coarse levels (long lists) first
-    const TileInfo info = a.tinfo[((int64_t)it.b * d.H + it.h) * a.blocks_bound + it.blk];
-    it.part = 0; it.whole = info.parts <= 1; it.partial_out = info.parts > 1; it.pidx = info.pbase;
-    tile_item<T, D>(grad_out, grad_value, a, d, it, rows, recs, atile);
-}
-
-// One thread per (b, h, block): length of the block's list -> number of work items; the extra ones
-// are queued (one queue lane per XCD, keyed by h like every other kernel's head -> XCD affinity).
-__global__ void __launch_bounds__(256)
-msda_bwd_tile_plan(const TileReduceArgs a, const Dims d, const int blocks_grid)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int nblk = a.hdr->n_blocks4;
-    const int blk = (int)(idx % blocks_grid);
-    const int64_t bh = idx / blocks_grid;
-    if (bh >= (int64_t)d.B * d.H || blk >= nblk) return;
-    const LevelRow *lv = level_rows(a.hdr);
-    int level = 0;
-    while (level + 1 < d.L && blk >= lv[level + 1].bbase4) ++level;
-    while (level < d.L && lv[level].nbx4 * lv[level].nby4 == 0) ++level;         // (empty levels own no block)
-    TileInfo info;
-    info.parts = 1; info.pbase = 0;
-    if (level < d.L) {
-        const LevelRow lr = lv[level];
-        const int rel = blk - lr.bbase4, by = rel / lr.nbx4, bx = rel - by * lr.nbx4;
-        const uint2 *tab = a.celltab + bh * a.cell_stride + lr.cbase;
-        int64_t n = 0;
-        for (int dy = 0; dy <= kTB; ++dy)
-            for (int dx = 0; dx <= kTB; ++dx) {
-                const int cy = kTB * by + dy, cx = kTB * bx + dx;
-                if (cy <= lr.Hl && cx <= lr.Wl) n += tab[cy * (lr.Wl + 1) + cx].y;
-            }
-        const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
-        if (parts > 1) {
-            const int ql = (int)(bh % d.H) % kTileLanes;
-            const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
-            const uint32_t eb = atomicAdd(&a.th->n_extra[ql], parts - 1);
-            if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
-                info.parts = parts; info.pbase = pb;
-                for (uint32_t p = 1; p < parts; ++p) {
-                    TileItem ti;
-                    ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = p; ti.pidx = pb + p;
-                    a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
-                }
-            } else if (eb < a.th->cap_extra) {
-                // reserved queue entries that cannot be used must read as "nothing to do"
-                for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
-                    TileItem ti;
-                    ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = kVoidPart; ti.pidx = 0;
-                    a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
-                }
-            }
-        }
-    }
-    a.tinfo[bh * a.blocks_bound + blk] = info;
-}
-
-// Blocks of several items: partial tiles -> grad_value rows.
-template <typename T, int D>
-__global__ void __launch_bounds__(64)
-msda_bwd_tile_finalize(T *__restrict__ grad_value, const TileReduceArgs a, const Dims d, const int blocks_grid)
-{
-    typedef TileMma<T> M;
-    const int lane = threadIdx.x;
-    const int w = blockIdx.x;
-    const int h = w % d.H, t = w / d.H, blk = t % blocks_grid, b = t / blocks_grid;
-    if (blk >= a.hdr->n_blocks4) return;
-    const TileInfo info = a.tinfo[((int64_t)b * d.H + h) * a.blocks_bound + blk];
-    if (info.parts <= 1) return;
-    const LevelRow *lv = level_rows(a.hdr);
-    const int level = level_of_block4(lv, d.L, blk, lane);
-    if (level < 0) return;
-    const LevelRow lr = lv[level];
-    const int rel = blk - lr.bbase4, by = rel / lr.nbx4, bx = rel - by * lr.nbx4;
-    for (int p = 0; p < kTB * kTB; ++p) {
-        const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
-        if (y >= lr.Hl || x >= lr.Wl) continue;
-        for (int ch = lane * 2; ch < D; ch += 128) {
-            float s0 = 0.f, s1 = 0.f;
-            for (uint32_t c = 0; c < info.parts; ++c) {
-                const float2 v = *reinterpret_cast<const float2 *>(
-                    a.tpartials + ((int64_t)(info.pbase + c) * (kTB * kTB) + p) * D + ch);
-                s0 += v.x; s1 += v.y;
-            }
-            T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + ch;
-            *reinterpret_cast<uint32_t *>(o) = M::pack2(s0, s1);
-        }
-    }
+    const int blk = nblk - 1 - j;                          // coarse levels (long lists) first
+    TileDesc *tdp = a.tdesc + (((int64_t)it.b * d.H + it.h) * a.blocks_bound + blk);
+    const TileDesc td = *tdp;
+    it.part = 0; it.whole = td.parts <= 1; it.partial_out = td.parts > 1; it.pidx = td.pbase;
+    tile_item<T, D>(grad_out, grad_value, a, d, td, it, &tdp->arrived, lds);
 }
 
 template <typename T, int D>
@@ -428,13 +436,10 @@ hipError_t launch_tile(const void *go, void *gv, const TileReduceArgs &a, const 
     const int blocks_grid = d.blocks4 > 0 ? std::min(d.blocks4, a.blocks_bound) : a.blocks_bound;
     const int64_t items = (int64_t)d.B * d.H * blocks_grid;
     if (items + kQueueWgs > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(msda_bwd_tile_plan, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a, d, blocks_grid);
     hipLaunchKernelGGL((msda_bwd_tile_reduce<T, D>), dim3((unsigned)(items + kQueueWgs)), dim3(64), 0, st,
                        (const T *)go, (T *)gv, a, d, blocks_grid);
-    hipLaunchKernelGGL((msda_bwd_tile_finalize<T, D>), dim3((unsigned)items), dim3(64), 0, st, (T *)gv, a, d, blocks_grid);
     return hipGetLastError();
 }
-
 template <typename T>
 hipError_t dispatch_tile(const void *go, void *gv, const TileReduceArgs &a, const Dims &d, hipStream_t st)
 {
@@ -448,6 +453,22 @@ hipError_t dispatch_tile(const void *go, void *gv, const TileReduceArgs &a, cons
 
 }  // namespace
 
+#ifdef MMFS_PROFILE_TILE
+extern "C" int mmfs_debug_tile_profile(unsigned long long *out, int reset)
+{
+    static unsigned long long host[mmfs::blk::kProfSlots * 12];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(mmfs::blk::g_tile_prof), sizeof(host));
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int s = 0; s < mmfs::blk::kProfSlots; ++s)
+        for (int i = 0; i < 12; ++i) out[i] += host[s * 12 + i];
+    if (e == hipSuccess && reset) {
+        for (auto &v : host) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::blk::g_tile_prof), host, sizeof(host));
+    }
+    return (int)e;
+}
+#endif
+
 bool tile_reduce_supported(int dtype, const Dims &d)
 {
     if (dtype != 1 && dtype != 2) return false;
@@ -456,6 +477,10 @@ bool tile_reduce_supported(int dtype, const Dims &d)
     if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'b' || e[0] == 'p') return false;     // "block", "pixel"
     // queue entries carry (b, h) and the block in 32 bits each; grid = B*H*blocks (+ queue) workgroups
     if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1) + kQueueWgs > 0x7fffffffLL) return false;
+    // the rows are fetched through a buffer descriptor over one (b, h) slice: 31-bit byte offsets
+    const int64_t es = 2;
+    if ((int64_t)d.Nq * d.H * d.D * es > kMaxSlabBytes) return false;
+    if (d.Nq >= (1 << 24) || (int64_t)d.H * d.D * es >= (1 << 24)) return false;       // 24-bit multiply for the row offset
     return true;
 }
 

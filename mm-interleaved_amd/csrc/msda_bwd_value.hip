@@ -508,7 +508,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     char *p = (char *)workspace;
     s.loc_t = p;                 p += up(pts * 2 * es);
     s.attn_t = p;                p += up(pts * es);
-    s.cursor = (uint32_t *)p;    s.cursor_bytes = up((int64_t)d.B * d.H * d.L * 4);  p += s.cursor_bytes;
+    s.cursor = (uint32_t *)p;    s.cursor_bytes = up(((int64_t)d.B * d.H * d.L + (int64_t)d.B * d.H) * 4);  p += s.cursor_bytes;   // (+ the block path's arrival counters: same layout)
     s.table = (TileTable *)p;    s.table_bytes = up((int64_t)sizeof(TileTable) + (int64_t)make_params(d).tiles_bound * sizeof(Tile));
     p += s.table_bytes;
     s.pixtab = (uint2 *)p;       p += up((int64_t)d.B * d.H * d.S * 8);
