@@ -19,11 +19,22 @@ Multi-GPU: the path shards on the batch axis with no data-path collective
 (SURVEY.md 8e); every rank processes its own B samples -> "scaling": "weak";
 value = N * B * K / t_max.
 
+The K timed steps run clean (one C call per pass, no events).  Per-kernel times come from a
+SEPARATE pass of --event-steps steps right after the timed region (HIP events recorded on the launch
+stream around every C-ABI launch), so ms_per_step does not depend on the sampling.
+
 Extra objects on the JSON line:
-  roofline     dominant kernel's algorithmic bytes per launch / its mean duration (HIP
-               events recorded on the launch stream inside the timed region) vs 8 TB/s
+  roofline     dominant kernel's algorithmic bytes per launch / its mean duration (the event
+               pass) vs 8 TB/s; "traffic" = HBM bytes of that kernel from profiles/pmc_traffic.json
+               when that file has an entry for this workload and kernel ("traffic_from" names the
+               rocprofv3 --pmc run it was taken from), else null
+  exchange     N > 1 only: the path's one exchange step, timed after the main region:
+               every rank all-gathers the multiscale features of its block of context images (LLM
+               geometry, 4 images per sequence: BASELINE config 5) and builds its sequences' bank
+               from the gathered tensor -- us per all-gather, GB/s per xGMI link, us per bank build
   cpu_baseline the oracle's restatement of the reference's only CPU path
-               (ms_deform_attn_core_pytorch) timed on this host, rank 0, N=1 only
+               (ms_deform_attn_core_pytorch) timed on this host at BASELINE config 1
+               (B=2, Nq=1024, L=4, H=8, P=4, C=256, fp32), all cores and 1 thread, rank 0, N=1 only
 """
 import argparse
 import json
@@ -112,34 +123,93 @@ def make_inputs(w, device, seed, loc_dist="uniform", visible="all"):
     return value, shapes, start, loc, attn, grad
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """Times oracle/msda_torch.py (restatement of the reference's CPU path) on a bounded
-    sample of the same workload: ONE batch element, fp32 on storage-rounded inputs."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=12.0):
+    """Times oracle/msda_torch.py (restatement of the reference's CPU path, checked against the imported
+    reference's goldens in tests/) at BASELINE config 1, fp32, forward + backward, the discipline of the
+    reference's ops/tests/speed_test.py:30-55 scaled to a CPU (5 warm-up iterations, then timed
+    iterations until ``budget_s`` or 20 of them): once with every host core, once with one thread."""
     from oracle import msda_torch
+    w = WORKLOADS["cfg1"]
     g = torch.Generator().manual_seed(0)
-    dt = DTYPES[w["dtype"]]
     shapes = w["shapes"] * w["n"]
-    B, Nq, H, D, P = 1, w["Nq"], w["H"], w["D"], w["P"]
+    B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
     S, L = sum(h * ww for h, ww in shapes), len(shapes)
-    rt = lambda t: t.to(dt).float()
-    value = rt(torch.rand(B, S, H, D, generator=g))
-    loc = rt(torch.rand(B, Nq, H, L, P, 2, generator=g))
+    value = torch.rand(B, S, H, D, generator=g)
+    loc = torch.rand(B, Nq, H, L, P, 2, generator=g)
     attn = torch.rand(B, Nq, H, L, P, generator=g) + 1e-5
-    attn = rt(attn / attn.sum((-1, -2), keepdim=True))
-    grad = rt(torch.randn(B, Nq, H * D, generator=g))
-    msda_torch.fwd_bwd(value, shapes, loc, attn, grad)            # warm-up
-    iters, t0 = 0, time.perf_counter()
-    while True:
-        msda_torch.fwd_bwd(value, shapes, loc, attn, grad)
-        iters += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or iters >= 10:
-            break
-    return {"value": round(B * iters / el, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle/msda_torch.py (ms_deform_attn_core_pytorch restated), fp32, B=1 slice of the "
-                      f"workload (Nq={Nq}), {iters} fwd+bwd iterations in {el:.1f}s on "
-                      f"{os.cpu_count()} host cpus"}
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    grad = torch.ones(B, Nq, H * D)
+    all_threads = torch.get_num_threads()
+    runs = {}
+    for threads in (all_threads, 1):
+        torch.set_num_threads(threads)
+        for _ in range(5 if threads > 1 else 1):
+            msda_torch.fwd_bwd(value, shapes, loc, attn, grad)
+        iters, t0 = 0, time.perf_counter()
+        while True:
+            msda_torch.fwd_bwd(value, shapes, loc, attn, grad)
+            iters += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or iters >= 20:
+                break
+        runs[threads] = (B * iters / el, el / iters * 1e3, iters)
+    torch.set_num_threads(all_threads)
+    ab = algorithmic_bytes(dict(w), 4)["fwdbwd"]
+    best = runs[all_threads]
+    return {"value": round(best[0], 3), "unit": "samples/s", "cores": all_threads, "kind": "port",
+            "ms_per_iter": round(best[1], 2), "effective_GBs": round(ab / (best[1] * 1e-3) / 1e9, 3),
+            "one_thread": {"value": round(runs[1][0], 3), "ms_per_iter": round(runs[1][1], 2)},
+            "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": f"oracle/msda_torch.py (ms_deform_attn_core_pytorch restated), BASELINE config 1 "
+                      f"(B={B} Nq={Nq} L={L} H={H} P={P} C={H * D}, fp32, fwd+bwd), {best[2]} timed iterations with "
+                      f"{all_threads} threads and {runs[1][2]} with 1 thread after warm-up"}
+
+
+def exchange_step(device, rank, world, dist, steps=20):
+    """The path's one exchange step at BASELINE config 5's geometry: 4 context images per sequence, LLM
+    pyramid (32^2, 16^2, 8^2 -> 1344 tokens) x C = 1024 bf16 = 2.75 MB per image; every rank encodes a
+    contiguous block of the images of ALL sequences and needs the images of ITS sequences.  Timed: the
+    RCCL all-gather of the packed features, and the bank build (one index-gather) from its result."""
+    from mmfs_amd import bank
+    B_local, n, hw, C = 4, 4, 1344, 1024
+    n_img = world * B_local * n
+    per_rank = bank.images_per_rank(n_img, world)
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    mine = torch.randn(per_rank, hw, C, device=device, generator=g).to(torch.bfloat16)
+    num = torch.full((B_local,), n, device=device)
+    first = rank * B_local * n
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_gather = t_bank = 0.0
+    for i in range(steps + 3):
+        ev[0].record()
+        allf = bank.all_gather_image_features(mine, n_img)
+        ev[1].record()
+        bk = bank.llm_feature_bank(allf[first:first + B_local * n], num, n)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            t_gather += ev[0].elapsed_time(ev[1]); t_bank += ev[1].elapsed_time(ev[2])
+    assert bk.shape == (B_local, n, hw, C)
+    t = torch.tensor([t_gather / steps, t_bank / steps], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    shard = per_rank * hw * C * 2
+    us = float(t[0]) * 1e3
+    return {"what": f"all_gather_into_tensor of {per_rank} images x {hw} tokens x {C} ch bf16 per rank + bank build "
+                    f"for {B_local} sequences x {n} images (BASELINE config 5 geometry)",
+            "allgather_us": round(us, 1), "shard_bytes": shard,
+            "GBs_per_link": round(shard / (us * 1e-6) / 1e9, 1), "link_peak_GBs": 153.0,
+            "received_GBs_per_gpu": round((world - 1) * shard / (us * 1e-6) / 1e9, 1),
+            "bank_us": round(float(t[1]) * 1e3, 1)}
 
 
 def main():
@@ -152,7 +222,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=sorted(DTYPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="diagnostic: no per-kernel events (one C call per pass); prints ms/step only")
+                    help="diagnostic: no per-kernel event pass; prints ms/step only")
+    ap.add_argument("--event-steps", type=int, default=10, help="steps of the per-kernel event pass (after the timed region)")
     ap.add_argument("--visible", default="all", choices=["all", "causal"],
                     help="causal: image k of n is visible to the queries after k/n of the sequence, zero attention elsewhere")
     ap.add_argument("--loc-dist", default="uniform", choices=["uniform", "centre"],
@@ -197,22 +268,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Per-kernel HIP events (recorded on the launch stream, inside the timed region) cost ~45 us of
-    # host work per step when every launch is bracketed: they are taken on every `sample`-th step
-    # only (>= 5 steps), the other steps issue each pass as ONE C call, like production.
-    log = None if args.no_kernel_events else []
-    sample = max(1, min(10, args.steps // 5))
+    # ---- the timed region: K clean steps (every pass ONE C call, like production)
+    MSDA._event_log = None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        MSDA._event_log = log if (log is not None and i % sample == 0) else None
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    MSDA._event_log = None
-    if log is None:
+    if args.no_kernel_events:
         if rank == 0:
             print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4), "note": "no kernel events"}))
         return
+    # ---- per-kernel HIP events, recorded on the launch stream around every C-ABI launch: a separate pass
+    log = []
+    MSDA._event_log = log
+    for i in range(max(1, args.event_steps)):
+        step()
+    fence()
+    MSDA._event_log = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist is not None:
@@ -230,11 +303,13 @@ def main():
             ab["msda_bwd_taps"] = ab["msda_bwd_taps_fine"]
         dom = max((k for k in mean_ms if k in ab), key=lambda k: mean_ms[k])
         achieved = ab[dom] / (mean_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")          # from a separate --pmc run
+        traffic = traffic_from = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")          # from a separate rocprofv3 --pmc run
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                j = json.load(open(pmc))
+                traffic = j.get(args.workload, {}).get(dom)
+                traffic_from = j.get("_source") if traffic is not None else None
             except Exception:
                 traffic = None
         Leff = len(w["shapes"]) * w["n"]
@@ -251,12 +326,19 @@ def main():
                        "global_batch": world * w["B"], "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_from": traffic_from,
                          "algorithmic_bytes": ab[dom], "mean_us": round(mean_ms[dom] * 1e3, 2)},
             "kernels_mean_us": {k: round(v * 1e3, 2) for k, v in mean_ms.items()},
-            "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # whole step against the roofline: algorithmic bytes of forward + backward / the clean step time
+            "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(w)
+            res["cpu_baseline"] = cpu_baseline()
+    ex = exchange_step(device, rank, world, dist) if dist is not None else None
+    if rank == 0:
+        if ex is not None:
+            res["exchange"] = ex
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -96,6 +96,14 @@ int mmfs_msda_forward(int dtype,
  * incoming gradient by the weight itself, and images a token cannot see have weight exactly 0.
  * Honoured by mmfs_msda_backward and mmfs_msda_backward_hybrid (row-gather kernel); a hint. */
 #define MMFS_BWD_LAZY_ZERO_ATTN 16u
+/* The caller has NOT looked at the level table (it lives in device memory, and the reference's callers
+ * rebuild it on every call: modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41) and does not want to pay a
+ * device->host copy per backward to find out whether MMFS_BWD_CANONICAL_LEVELS holds.  The sorted
+ * backward is taken and the table is checked ON THE DEVICE: any table whose levels do not overlap is
+ * served (rows that belong to no level are zero-filled, like the reference's zero-initialised output);
+ * overlapping, out-of-range or >= 65536-wide levels make the launch fail loudly (device-side trap) --
+ * a caller that builds such tables registers them on the host and gets the float-atomic path. */
+#define MMFS_BWD_DEVICE_CHECKED_LEVELS 32u
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.

@@ -190,7 +190,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         # come from mmfs_amd.levels.make_level_tables / register_level_tables (like the backward)
         info = None
         if _hybrid and "fwd" in _hybrid_parts and code in (1, 2) and D in (32, 64, 128) and L <= 64 and Nq >= 32:
-            info = _level_info(spatial_shapes, level_start_index, S)
+            info = _level_info(spatial_shapes, level_start_index, S, sync=False)
         if info is not None:
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             ws_bytes = _lib.mmfs_msda_forward_hybrid_workspace_bytes(code, hs, hst, *dims)
@@ -222,6 +222,7 @@ _BWD_FORCE_ATOMIC = 2
 _BWD_DENSE_TAPS = 4
 _BWD_DENSE_VALUE = 8
 _BWD_LAZY_ZERO_ATTN = 16
+_BWD_DEVICE_CHECKED_LEVELS = 32
 _E_UNSUPPORTED = -5
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
@@ -286,11 +287,11 @@ def levels_are_canonical(spatial_shapes, level_start_index, S):
     """True when start[l] == sum_{k<l} H_k*W_k and sum_l H_l*W_l == S (the packing every
     caller in the reference builds: modeling_llama_mmfs.py:303-305, sd_mmfs.py:35-37).
 
-    The tables live in device memory (reference API), so the first query for a given
-    pair of tensor objects costs one small device->host copy; the answer is cached on
-    the tensor object (keyed by the in-place version counters).  mmfs_amd's own callers
-    create their tables once with ``mmfs_amd.levels.make_level_tables`` which pre-seeds
-    the cache, so the training loop never syncs here."""
+    The tables live in device memory (reference API), so this query costs one small
+    device->host copy the first time a pair of tensor objects is asked about; the answer is
+    cached on the tensor object (keyed by the in-place version counters).  The op itself never
+    asks: it uses the answer when it is there (``mmfs_amd.levels.make_level_tables`` pre-seeds
+    it) and lets the library check the table on the device otherwise."""
     return _level_info(spatial_shapes, level_start_index, S)[0]
 
 
@@ -367,8 +368,14 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if _bwd_algo == "atomic":
         flags |= _BWD_FORCE_ATOMIC
     else:
-        info = _level_info(spatial_shapes, level_start_index, S)
-        if info[0]:
+        # What the level tables contain is only looked up, never fetched: tables that came from
+        # mmfs_amd.levels.make_level_tables / register_level_tables (or were seen by levels_are_canonical)
+        # carry their host copy; for any other pair -- the reference's own callers build fresh tensors on
+        # every call -- the library checks the table on the device (no device->host copy, no sync).
+        info = _level_info(spatial_shapes, level_start_index, S, sync=False)
+        if info is None:
+            flags |= _BWD_DEVICE_CHECKED_LEVELS
+        elif info[0]:
             flags |= _BWD_CANONICAL_LEVELS
     grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
     grad_loc = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
@@ -377,7 +384,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         stream = _stream(value.device)
         status = _E_UNSUPPORTED
         hyb_bytes = 0
-        if _hybrid and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
+        if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
             flags |= (_BWD_DENSE_TAPS if "taps" in _hybrid_parts else 0) | (_BWD_DENSE_VALUE if "value" in _hybrid_parts else 0)
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             hyb_bytes = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
@@ -412,7 +419,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         ws_bytes = 0 if hyb_bytes > 0 else _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
-        if hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS) and _event_log is None and not _bwd_overlap:
+        if hyb_bytes == 0 and (flags & (_BWD_CANONICAL_LEVELS | _BWD_DEVICE_CHECKED_LEVELS)) and _event_log is None and not _bwd_overlap:
             pass                                 # the library's own sequence below: one call (same kernels)
         elif hyb_bytes == 0 and (flags & _BWD_CANONICAL_LEVELS):
             # sorted backward, stage by stage (so each kernel can be timed / the halves can overlap)

@@ -45,7 +45,7 @@ static_assert(kNPX % 4 == 0, "block weights travel as 16-byte vectors");
 
 struct CellHeader {
     int n_tiles, n_blocks, n_cells, L;
-    int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce)
+    int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce); pad[0]: every row has exactly one owner level
 };
 
 // workspace table: CellHeader | LevelRow[L] | CTile[cap]

@@ -98,7 +98,7 @@ __device__ __host__ inline int cap_of(int64_t samples, int64_t blocks)
 }
 
 __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                  int L, int nt_min, int cap, int64_t samples_per_level,
+                                  int L, int S, int nt_min, int cap, int64_t samples_per_level,
                                   CellHeader *__restrict__ hdr, uint32_t *__restrict__ ovf_header,
                                   uint32_t cap_slots, uint32_t cap_entries, uint32_t cap_partials,
                                   TileHeader *__restrict__ th, uint32_t tile_cap_extra, uint32_t tile_cap_partials)
@@ -148,7 +148,33 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
         bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
     }
     hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
-    hdr->n_blocks4 = bbase4; hdr->pad[0] = hdr->pad[1] = hdr->pad[2] = 0;
+    hdr->n_blocks4 = bbase4; hdr->pad[1] = hdr->pad[2] = 0;
+    // The level table lives in device memory (reference API) and the caller may not have looked at it
+    // (MMFS_BWD_DEVICE_CHECKED_LEVELS: no device->host copy per call).  Owner-computes needs every
+    // grad_value row to belong to at most one level: checked here.  Rows that belong to NO level (a
+    // table with gaps; canonical tables have none) are zero-filled by zero_uncovered_rows.  Overlapping
+    // levels -- the reference would add both levels' gradients into the shared rows -- cannot be served
+    // by this path: loud, device-side failure (callers that know their table take the atomic path).
+    int64_t covered = 0;
+    bool bad = false;
+    for (int l = 0; l < L; ++l) {
+        const int64_t Hl = shapes[2 * l], Wl = shapes[2 * l + 1], a0 = start[l];
+        if (Hl < 0 || Wl < 0 || Hl >= 65536 || Wl >= 65536) { bad = true; continue; }
+        if (Hl == 0 || Wl == 0) continue;
+        const int64_t a1 = a0 + Hl * Wl;
+        if (a0 < 0 || a1 > S) bad = true;
+        covered += Hl * Wl;
+        for (int k = 0; k < l; ++k) {
+            const int64_t b0 = start[k], b1 = b0 + shapes[2 * k] * shapes[2 * k + 1];
+            if (shapes[2 * k] > 0 && shapes[2 * k + 1] > 0 && a0 < b1 && b0 < a1) bad = true;
+        }
+    }
+    hdr->pad[0] = (!bad && covered == S) ? 1 : 0;          // canonical in the sense that matters: every row has exactly one owner
+    if (bad) {
+        printf("mmfs_msda backward: level table has overlapping / out-of-range / oversized levels; "
+               "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
+        __builtin_trap();
+    }
 }
 
 // Exclusive prefix sum over a[0..n) (n <= kMaxTileCells), total left in a[n].
@@ -830,6 +856,30 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     return s;
 }
 
+// Rows of grad_value no level owns (a level table with gaps): zero, as the reference's zero-filled
+// output leaves them (ms_deform_attn_cuda.cu:127).  Canonical tables have none: the kernel returns at once.
+template <typename T>
+__global__ void __launch_bounds__(256)
+zero_uncovered_rows(T *__restrict__ grad_value, const CellHeader *__restrict__ hdr, const Dims d)
+{
+    if (hdr->pad[0]) return;
+    const LevelRow *lv = level_rows(hdr);
+    const int64_t row_elems = (int64_t)d.H * d.D;
+    for (int64_t r = blockIdx.x; r < (int64_t)d.B * d.S; r += gridDim.x) {
+        const int pix = (int)(r % d.S);
+        bool owned = false;
+        for (int l = 0; l < d.L; ++l) owned |= lv[l].Hl > 0 && lv[l].Wl > 0 && pix >= lv[l].lstart && pix < lv[l].lstart + lv[l].Hl * lv[l].Wl;
+        if (owned) continue;
+        for (int64_t i = threadIdx.x; i < row_elems; i += 256) grad_value[r * row_elems + i] = (T)0.f;
+    }
+}
+
+template <typename T>
+void launch_zero_uncovered(void *gv, const Scratch &sc, const Dims &d, hipStream_t st)
+{
+    hipLaunchKernelGGL((zero_uncovered_rows<T>), dim3(1024), dim3(256), 0, st, (T *)gv, sc.hdr, d);
+}
+
 TileReduceArgs tile_args(const Scratch &sc, const Dims &d)
 {
     TileReduceArgs a;
@@ -846,7 +896,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
-    hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min, tp.tiles_bound,
+    hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, d.S, tp.nt_min, tp.tiles_bound,
                        (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries,
                        sc.cap_partials, sc.th, sc.tile_cap_extra, sc.tile_cap_partials);
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
@@ -953,6 +1003,12 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
 {
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
+    switch (dtype) {
+        case 0: launch_zero_uncovered<float>(grad_value, sc, d, st); break;
+        case 1: launch_zero_uncovered<half_t>(grad_value, sc, d, st); break;
+        case 2: launch_zero_uncovered<bf16_t>(grad_value, sc, d, st); break;
+        default: break;
+    }
     if (sc.th != nullptr) {
         const TileReduceArgs a = tile_args(sc, d);
         return tile_reduce(dtype, grad_out, grad_value, a, d, st);

@@ -92,8 +92,11 @@ int mmfs_msda_forward(int dtype, const void *value, const int64_t *shapes, const
 
 static bool use_tiled(int dtype, const mmfs::Dims &d, unsigned flags)
 {
-    return (flags & MMFS_BWD_CANONICAL_LEVELS) && !(flags & MMFS_BWD_FORCE_ATOMIC) &&
-           mmfs::bwd_has_vector_path(dtype, d) && mmfs::bwd_value_tiled_supported(dtype, d);
+    if (flags & MMFS_BWD_FORCE_ATOMIC) return false;
+    if (!mmfs::bwd_has_vector_path(dtype, d) || !mmfs::bwd_value_tiled_supported(dtype, d)) return false;
+    if (flags & MMFS_BWD_CANONICAL_LEVELS) return true;
+    // nobody has looked at the table: the block-stationary generation checks it on the device
+    return (flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) && mmfs::bwd_value_block_supported(dtype, d);
 }
 
 int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,

@@ -8,8 +8,9 @@ and adds the one exchange step of the multi-GPU path: when the im
 encoder is balanced per image rather than per sequence, a sequence's context images may
 have been encoded on other ranks; ``all_gather_image_features`` brings the per-image
 multiscale features together with ONE all_gather_into_tensor (RCCL over xGMI; the
-reference has no counterpart, its ranks never exchange features) and the builders then
-index into the gathered tensor exactly as they would on a single rank.
+reference has no counterpart, its ranks never exchange features; differentiable: the gradient of an
+image returns to its owner by reduce-scatter) and the builders then index into the gathered tensor
+exactly as they would on a single rank.
 
 On device tensors the bank itself -- gather over images, channel-major -> token-major transposition,
 concatenation over levels, zero slots -- is ONE kernel pass (``gather_bank``: csrc/mmfs_bank.hip,
@@ -124,28 +125,71 @@ def prepare_mmfs_features_for_image_decoder(multiscale_features, text_ids, neare
 
 
 # ------------------------------------------------------------------ multi-GPU exchange
-def image_owner_layout(n_images_total, world_size):
-    """Images are encoded round-robin: image g lives on rank g % world at local slot g // world."""
-    per_rank = (n_images_total + world_size - 1) // world_size
-    return per_rank
+def images_per_rank(n_images_total, world_size):
+    """Images are encoded in contiguous blocks: image g lives on rank g // per_rank at local slot
+    g % per_rank (per_rank = ceil(n / world)), so that the rank-major buffer an all-gather fills IS the
+    global image order -- nothing to permute afterwards."""
+    return (n_images_total + world_size - 1) // world_size
+
+
+class AllGatherImageFeatures(torch.autograd.Function):
+    """local [per_rank, hw, C] (this rank's block of images, zero padded to ``per_rank``) ->
+    [world * per_rank, hw, C] = every image in global order, identical on every rank; differentiable.
+
+    Forward: ONE ``all_gather_into_tensor`` (RCCL over xGMI: on the full mesh every peer's shard rides its
+    own link); with the block layout of ``images_per_rank`` its output needs no reordering pass.
+    Backward: the image encoder is trained in the reference (only the LLM is frozen, mm_interleaved.py:74),
+    so every rank's gradient w.r.t. an image has to reach the rank that encoded it:
+    ``reduce_scatter_tensor`` (sum); backends without it (gloo: the CPU tests) all-reduce and slice.
+    The reference itself never exchanges features (each rank encodes its own sequences' images,
+    mm_interleaved.py:185-252); this is the build's extension for image-balanced encoding."""
+
+    @staticmethod
+    def forward(ctx, local, group):
+        import torch.distributed as dist
+        ctx.group = group
+        local = local.contiguous()
+        world = dist.get_world_size(group)
+        gathered = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        return gathered
+
+    @staticmethod
+    def backward(ctx, grad):
+        import torch.distributed as dist
+        group = ctx.group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        per_rank = grad.shape[0] // world
+        grad = grad.contiguous()
+        if dist.get_backend(group) == "nccl":
+            out = grad.new_empty((per_rank,) + tuple(grad.shape[1:]))
+            dist.reduce_scatter_tensor(out, grad, op=dist.ReduceOp.SUM, group=group)
+        else:
+            total = grad.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            out = total[rank * per_rank:(rank + 1) * per_rank].clone()
+        return out, None
 
 
 def all_gather_image_features(local_packed, n_images_total, group=None):
-    """local_packed [n_local, hw, C]: this rank's images (global ids rank, rank+W, rank+2W, ...).
-    Returns [n_images_total, hw, C] in global image order, identical on every rank.
-    One collective; each peer's shard travels over its own xGMI link on a full mesh."""
+    """local_packed [n_local, hw, C]: this rank's block of images (global ids rank * per_rank ...).
+    Returns [n_images_total, hw, C] in global image order, identical on every rank.  Differentiable:
+    gradients w.r.t. the result flow back to the rank that holds each image (``AllGatherImageFeatures``)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_packed[:n_images_total]
-    per_rank = image_owner_layout(n_images_total, world)
-    shard = local_packed.new_zeros((per_rank,) + tuple(local_packed.shape[1:]))
-    shard[: local_packed.shape[0]] = local_packed
-    gathered = local_packed.new_empty((world * per_rank,) + tuple(local_packed.shape[1:]))
-    dist.all_gather_into_tensor(gathered, shard.contiguous(), group=group)
-    # gathered[r*per_rank + s] is global image s*world + r  ->  reorder to global ids
-    g = torch.arange(n_images_total, device=local_packed.device)
-    return gathered.index_select(0, (g % world) * per_rank + g // world)
+    per_rank = images_per_rank(n_images_total, world)
+    if local_packed.shape[0] != per_rank:                     # the last rank(s) may hold fewer images
+        pad = local_packed.new_zeros((per_rank - local_packed.shape[0],) + tuple(local_packed.shape[1:]))
+        local_packed = torch.cat((local_packed, pad), 0)
+    return AllGatherImageFeatures.apply(local_packed, group)[:n_images_total]
+
+
+def local_image_range(n_images_total, rank, world_size):
+    """[lo, hi) of the global image ids rank ``rank`` encodes under the block layout."""
+    per_rank = images_per_rank(n_images_total, world_size)
+    return min(rank * per_rank, n_images_total), min((rank + 1) * per_rank, n_images_total)
 
 
 def shard_batch(n_items, rank, world_size):

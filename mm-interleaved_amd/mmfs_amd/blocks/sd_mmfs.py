@@ -61,10 +61,12 @@ def pixel_reference_points(h, w, device):
     key = (h, w, str(device))
     hit = _ref_cache.get(key)
     if hit is None:
-        ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5) / h
-        xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5) / w
-        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
-        hit = torch.stack((xx.reshape(-1), yy.reshape(-1)), -1)[None, :, None, :]
+        # (cached across calls: never an inference tensor, see mmfs_amd.levels.make_level_tables)
+        with torch.inference_mode(False), torch.no_grad():
+            ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5) / h
+            xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5) / w
+            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+            hit = torch.stack((xx.reshape(-1), yy.reshape(-1)), -1)[None, :, None, :].contiguous()
         _ref_cache[key] = hit
     return hit
 
@@ -111,8 +113,11 @@ class MMFSBlock(nn.Module):
         key = (n_tokens, pe.data_ptr(), pe._version, pe.dtype, pe.device)
         hit = self.__dict__.get("_pos_cache")
         if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, resize_pos_embed(pe, n_tokens))
+            # (kept across calls: a table made during an inference_mode() pass must still be usable
+            # by a later training step, so it is computed outside the mode on a plain copy)
+            with torch.inference_mode(False), torch.no_grad():
+                src = pe.detach().clone() if pe.is_inference() else pe.detach()
+                hit = (key, resize_pos_embed(src, n_tokens).clone())
             self.__dict__["_pos_cache"] = hit
         return hit[1]
 
@@ -258,7 +263,12 @@ class MMFSNet(nn.Module):
         -> (sample', tuple of residuals')   (sd_mmfs.py:230-272)."""
         assert len(down_block_res_samples) == len(self.mmfs_down_blocks)
         proj = mmfs_features if isinstance(mmfs_features, ProjectedFeatures) else None
-        if proj is None and self.fused_schedule and self._can_fuse():
+        # Under gradient checkpointing the reference recomputes feat_norm + value_proj inside every block's
+        # checkpoint and keeps none of them; handing each block a projected bank as a checkpoint INPUT would
+        # keep all 13 bank-sized tensors alive through the whole step -- on exactly the path where
+        # checkpointing was meant to save memory.  Training with checkpointing takes the reference's schedule.
+        ckpt = self.training and torch.is_grad_enabled() and any(b.gradient_checkpointing for b in self._blocks())
+        if proj is None and self.fused_schedule and self._can_fuse() and not ckpt:
             keep = self.cache_projected_features and not torch.is_grad_enabled()
             proj = self.__dict__.get("_projected") if keep else None
             if proj is None or not proj.matches(mmfs_features, self._projection_weights()):

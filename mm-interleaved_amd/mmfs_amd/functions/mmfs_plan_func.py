@@ -4,7 +4,7 @@ reference's MMFS.forward does between its Linear layers and the op
 ``mmfs_plan_backward`` in include/mmfs_msda.h; kernels in csrc/mmfs_plan.hip.
 
 ``mmfs_plan_supported`` tells the module whether the fused path applies (device tensors, 2-D
-reference points shared by all levels, L*(P+1) <= 256); otherwise the module evaluates the same
+reference points shared by all levels, P in {4, 8, 16}, n_images * n_levels <= 64); otherwise the module evaluates the same
 mathematics with framework ops -- that is NOT a CPU fallback of the sampling op, only of this
 front-end, and it is what the CPU parity tests of the module exercise.
 """
@@ -44,6 +44,7 @@ class MMFSPlanFunction(Function):
         off_q, att_q = off_q.contiguous(), att_q.to(dt).contiguous()
         off_tab, att_tab = off_tab.to(dt).contiguous(), att_tab.to(dt).contiguous()
         relpos, ref, ratios = relpos.contiguous(), ref.float().contiguous(), ratios.float().contiguous()
+        assert shapes.dtype == torch.int64 and shapes.is_contiguous() and shapes.shape == (n * L, 2), "spatial_shapes must be a contiguous int64 [n*L, 2] tensor"
         dev = off_q.device
         loc = torch.empty((N, Lq, H, n * L, P, 2), dtype=dt, device=dev)
         attn = torch.empty((N, Lq, H, n * L, P), dtype=dt, device=dev)

@@ -21,12 +21,16 @@ def make_level_tables(shapes_per_image, n_images, device):
     hit = _cache.get(key)
     if hit is not None:
         return hit
-    host = torch.tensor(list(key[0]) * int(n_images), dtype=torch.long).reshape(-1, 2)
-    px = host[:, 0] * host[:, 1]
-    start_host = px.cumsum(0) - px
-    S = int(px.sum())
-    shapes = host.to(device)
-    start = start_host.to(device)
+    # The tensors outlive the call that made them.  Made under torch.inference_mode() (an evaluation pass
+    # before training) they would be inference tensors, and every later training step would fail at
+    # save_for_backward ("Inference tensors cannot be saved for backward"): build them outside any mode.
+    with torch.inference_mode(False), torch.no_grad():
+        host = torch.tensor(list(key[0]) * int(n_images), dtype=torch.long).reshape(-1, 2)
+        px = host[:, 0] * host[:, 1]
+        start_host = px.cumsum(0) - px
+        S = int(px.sum())
+        shapes = host.to(device)
+        start = start_host.to(device)
     # pre-seed the shim's cache: (versions, start ptr, S) -> (canonical, host shapes, host start)
     shapes._mmfs_canonical = ((shapes._version, start._version, start.data_ptr(), S), True,
                               np.ascontiguousarray(host.numpy(), dtype=np.int64),

@@ -1,6 +1,8 @@
 """world_size-2 gloo tests (CPU): the batch-sharded multi-GPU path and its one exchange
 step, the all-gather of per-image features.  Acceptance: the bank built
-after the all-gather is bit-identical to the single-rank bank."""
+after the all-gather is bit-identical to the single-rank bank, and the gradient that flows
+back through the gather (the image encoder is trained in the reference) equals the
+single-rank gradient of every image, on the rank that owns it."""
 import os
 import socket
 
@@ -30,15 +32,26 @@ def _worker(rank, world, port, tmp):
         packed = bank.pack_image_levels(levels)                  # [7, 84, 6] -- the single-rank truth
         want_bank = bank.llm_feature_bank(packed, num, 3)
 
-        # each rank "encodes" only its round-robin share of the images ...
-        mine = packed[rank::world].contiguous()
+        # each rank "encodes" only its block of the images ...
+        i0, i1 = bank.local_image_range(n_img, rank, world)
+        mine = packed[i0:i1].clone().requires_grad_(True)
         gathered = bank.all_gather_image_features(mine, n_img)
-        assert torch.equal(gathered, packed), "gathered features differ from the single-rank tensor"
+        assert gathered.requires_grad
+        assert torch.equal(gathered.detach(), packed), "gathered features differ from the single-rank tensor"
         # ... and builds the bank of its own batch shard from the gathered tensor
         lo, hi = bank.shard_batch(num.numel(), rank, world)
         first = int(num[:lo].sum())
         local = bank.llm_feature_bank(gathered[first:first + int(num[lo:hi].sum())], num[lo:hi], 3)
-        assert torch.equal(local, want_bank[lo:hi])
+        assert torch.equal(local.detach(), want_bank[lo:hi])
+        # backward: every rank's loss touches images of other ranks; the gradient of an image must come
+        # back to its owner, summed over the ranks that used it.  Truth: the single-rank bank with the
+        # per-sequence weights every rank can recompute.
+        wts = torch.randn(want_bank.shape, generator=g)
+        (local * wts[lo:hi]).sum().backward()
+        ref = packed.clone().requires_grad_(True)
+        (bank.llm_feature_bank(ref, num, 3) * wts).sum().backward()
+        assert torch.allclose(mine.grad, ref.grad[i0:i1], rtol=0, atol=1e-6), "gradient did not return to the owning rank"
+        assert float(ref.grad[i0:i1].abs().max()) > 0
         # every sequence is processed by exactly one rank
         counts = torch.zeros(num.numel())
         counts[lo:hi] = 1

@@ -43,7 +43,10 @@ def close(a, b, tol):
     assert err <= tol * max(1.0, np.abs(b).max()), f"max err {err:.3e}"
 
 
-MMFS_CASES = ["mmfs_llm_mask3d", "mmfs_llm_decode", "mmfs_llm_n1", "mmfs_sd_mask2d"]
+MMFS_CASES = ["mmfs_llm_mask3d", "mmfs_llm_decode", "mmfs_llm_n1", "mmfs_sd_mask2d",
+              # the point counts the decoders really use (P = 8) and the north star's (P = 4)
+              "mmfs_p8_llm_n3", "mmfs_p8_llm_n4", "mmfs_p8_llm_n1", "mmfs_p8_llm_decode", "mmfs_p4_llm_n3",
+              "mmfs_p8_sd_grid", "mmfs_p8_sd_n1"]
 
 
 def build_mmfs(z, dtype=torch.float64):
@@ -284,6 +287,30 @@ def test_ms_deform_attn_module(oracle_op):
     assert torch.allclose(out, want, atol=1e-12)
 
 
+ENC_CASES = ["enc_injector", "enc_extractor", "enc_boxes_padded"]
+
+
+@pytest.mark.parametrize("name", ENC_CASES)
+def test_encoder_ms_deform_attn_matches_reference(name, oracle_op):
+    """The ViT-Adapter's MSDeformAttn (encoders/vit_adapter/ops/modules/ms_deform_attn.py:28-131) at the
+    injector / extractor geometries (adapter_modules.py:108-154), plus the two branches no caller takes
+    (box reference points, padding mask): output, input gradients, every parameter gradient."""
+    from mmfs_amd.modules import MSDeformAttn
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    m = load_params(MSDeformAttn(**cfg).double(), z)
+    q = T(z["query"]).requires_grad_(True)
+    f = T(z["feat"]).requires_grad_(True)
+    pad = T(z["padding_mask"]) if "padding_mask" in z else None
+    out = m(q, T(z["reference_points"]), f, T(z["spatial_shapes"]), T(z["level_start_index"]), pad)
+    close(out, z["out"], 1e-10)
+    out.backward(T(z["grad_out"]))
+    close(q.grad, z["grad_query"], 1e-9)
+    close(f.grad, z["grad_feat"], 1e-9)
+    for k, p in m.named_parameters():
+        close(p.grad, z["grad." + k], 1e-9)
+
+
 # ------------------------------------------------------------------ bank builders
 def test_bank_builders_match_reference():
     from mmfs_amd import bank
@@ -299,6 +326,29 @@ def test_bank_builders_match_reference():
     assert torch.equal(mask, T(z["img_mask"]))
     for i, f in enumerate(feats):
         assert torch.equal(f, T(z[f"img_feat.{i}"], torch.float32))
+
+
+def test_cached_tables_survive_an_inference_mode_first_call(oracle_op):
+    """An evaluation pass under torch.inference_mode() before training must not poison the caches:
+    the level tables, the pixel reference grid and the resized position table are kept across calls."""
+    from mmfs_amd import levels
+    from mmfs_amd.blocks import MMFSBlock
+    from mmfs_amd.blocks import sd_mmfs
+    levels._cache.clear(); sd_mmfs._ref_cache.clear()
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = MMFSBlock(attn_dim=32, query_dim=16, feat_dim=32, num_heads=4, n_points=2, n_levels=2,
+                        gradient_checkpointing=False, grid_size=8, spatial_shapes=[4, 2],
+                        base_spatial_shape=4, max_num_image_per_seq=5).double()
+    with torch.no_grad():
+        blk.conv.weight.normal_(0, 0.1)
+    sample = torch.randn(1, 16, 4, 4, dtype=torch.float64)
+    feat = torch.randn(1, 1, 20, 32, dtype=torch.float64)
+    mask = torch.ones(1, 1, dtype=torch.long)
+    with torch.inference_mode():
+        blk(sample, feat, mask, [(4, 4), (2, 2)])
+    s2, f2 = sample.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    blk(s2, f2, mask, [(4, 4), (2, 2)]).sum().backward()         # used to raise: inference tensors saved for backward
+    assert s2.grad is not None and f2.grad is not None
 
 
 def test_level_tables_are_cached_and_marked_canonical():

@@ -32,7 +32,7 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("name", ["mmfs_llm_mask3d", "mmfs_llm_decode", "mmfs_llm_n1", "mmfs_sd_mask2d"])
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 5e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5)])
 def test_mmfs_on_gpu_matches_reference(name, dtype, tol):
     from mmfs_amd.modules import MMFS
     z = load_golden(name)
@@ -62,6 +62,122 @@ def test_mmfs_on_gpu_matches_reference(name, dtype, tol):
         for k, p in m.named_parameters():
             if "grad." + k in z:
                 assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
+
+
+# The fused sampling-plan kernel (csrc/mmfs_plan.hip) only takes P in {4, 8, 16}: these are the goldens that
+# reach it -- the decoders' real point count (P = 8: modeling_llama_mmfs.py:326-339, sd_mmfs.py:50-53) and the
+# north star's (P = 4), LLM flavour (centre reference point, 3-D mask with an all-masked row, decode slice)
+# and SD flavour (per-pixel reference grid, 2-D long mask with a fully masked sample).
+P48_CASES = ["mmfs_p8_llm_n3", "mmfs_p8_llm_n4", "mmfs_p8_llm_n1", "mmfs_p8_llm_decode", "mmfs_p4_llm_n3",
+             "mmfs_p8_sd_grid", "mmfs_p8_sd_n1"]
+
+
+def run_mmfs(z, dtype, fused=True):
+    from mmfs_amd.modules import MMFS
+    cfg = ast.literal_eval(str(z["cfg"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = load_params(MMFS(**cfg), z).to(DEV, dtype)
+    m.fused_plan = fused
+    q = T(z["query"], dtype).requires_grad_(True)
+    f = T(z["feat"], dtype).requires_grad_(True)
+    mask = T(z["attention_mask"], torch.float32)
+    out = m(q, T(z["reference_points"], dtype), f, T(z["spatial_shapes"], None), T(z["level_start_index"], None), None, mask)
+    out.backward(T(z["grad_out"], dtype))
+    return m, out, q, f
+
+
+@pytest.mark.parametrize("name", P48_CASES)
+def test_fused_plan_kernel_matches_reference_fp32(name):
+    """fp32 on the device against the reference's fp64 golden: output 2e-5, input gradients and EVERY
+    parameter gradient 1e-4 relative (incl. the two relative-position tables, whose gradients the plan
+    kernel accumulates with atomics) -- through the fused plan kernel, which the run must really take."""
+    import MultiScaleDeformableAttention as MSDA
+    z = load_golden(name)
+    log = []
+    MSDA._event_log = log
+    try:
+        m, out, q, f = run_mmfs(z, torch.float32)
+    finally:
+        MSDA._event_log = None
+    assert any(n == "mmfs_plan_fwd" for n, _, _ in log) and any(n == "mmfs_plan_bwd" for n, _, _ in log)
+    assert rel_err(out, z["out"]) <= 2e-5
+    assert rel_err(q.grad, z["grad_query"]) <= 1e-4 and rel_err(f.grad, z["grad_feat"]) <= 1e-4
+    checked = 0
+    for k, p in m.named_parameters():
+        if "grad." + k in z:
+            assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
+            checked += 1
+    assert checked >= 10            # weights + biases of the five Linear layers and the relative-position table
+
+
+@pytest.mark.parametrize("name", ["mmfs_p8_llm_n3_f32", "mmfs_p8_sd_grid_f32"])
+def test_fused_plan_kernel_against_the_references_own_fp32_run(name):
+    """The same two modules evaluated by the reference in fp32: its rounding and ours differ, the
+    results agree to 1e-5 of the output scale (BASELINE north_star's fp32 bar)."""
+    z = load_golden(name)
+    m, out, q, f = run_mmfs(z, torch.float32)
+    assert rel_err(out, z["out"]) <= 1e-5
+
+
+# 16-bit module runs.  Bars, argued: every tensor that enters the op is rounded to the storage type
+# (relative step 2^-11 fp16, 2^-8 bf16), outputs are sums of ~n*L*P products of O(1) terms with
+# independent roundings, so a relative output error of a few steps is the floor: 4 steps each = 2e-3 /
+# 1.6e-2.  Gradients: d(out)/d(loc) is piecewise constant in the pixel grid and the 16-bit rounding of a
+# location (mmfs.py:265) moves some samples across a pixel border, flipping single entries; norm-wise the
+# flipped fraction is what counts.  Measured on MI355X over all eleven goldens (profiles/r02_module_16bit.txt):
+# worst norm-wise gradient error 9e-3 fp16 / 7e-2 bf16; bars at ~2x.
+@pytest.mark.parametrize("name", P48_CASES + ["mmfs_llm_mask3d", "mmfs_sd_mask2d"])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float16, 2e-3, 2e-2), (torch.bfloat16, 1.6e-2, 1.5e-1)])
+def test_mmfs_16bit_on_gpu(name, dtype, tol, gtol):
+    z = load_golden(name)
+    m, out, q, f = run_mmfs(z, dtype)
+    assert out.dtype == dtype
+    nrm = lambda a, b: float(torch.linalg.norm(a.double().cpu() - torch.from_numpy(np.asarray(b, np.float64)).reshape(a.shape))
+                             / max(np.linalg.norm(b), 1e-30))
+    e_out, e_q, e_f = rel_err(out, z["out"]), nrm(q.grad, z["grad_query"]), nrm(f.grad, z["grad_feat"])
+    print(f"MODULE16 {name} {str(dtype)[6:]} out {e_out:.2e} grad_query {e_q:.2e} grad_feat {e_f:.2e}")
+    assert e_out <= tol and e_q <= gtol and e_f <= gtol
+
+
+@pytest.mark.parametrize("name", ["enc_injector", "enc_extractor", "enc_boxes_padded"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_encoder_ms_deform_attn_on_gpu(name, dtype, tol):
+    """The ViT-Adapter's MSDeformAttn (second user of the same extension) against the
+    reference's golden: D = 32 as in the adapter (injector L = 3, extractor L = 1) and D = 16 (boxes, padding)."""
+    from mmfs_amd.modules import MSDeformAttn
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    m = load_params(MSDeformAttn(**cfg), z).to(DEV, dtype)
+    q = T(z["query"], dtype).requires_grad_(True)
+    f = T(z["feat"], dtype).requires_grad_(True)
+    pad = T(z["padding_mask"], None) if "padding_mask" in z else None
+    out = m(q, T(z["reference_points"], dtype), f, T(z["spatial_shapes"], None), T(z["level_start_index"], None), pad)
+    assert out.dtype == dtype and rel_err(out, z["out"]) <= tol
+    out.backward(T(z["grad_out"], dtype))
+    if dtype == torch.float32:
+        assert rel_err(q.grad, z["grad_query"]) <= 1e-4 and rel_err(f.grad, z["grad_feat"]) <= 1e-4
+        for k, p in m.named_parameters():
+            assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
+
+
+def test_core_pytorch_name_runs_the_hip_op():
+    """``ms_deform_attn_core_pytorch`` of the product (the reference's CPU/debug statement of the op,
+    ops/functions/ms_deform_attn_func.py:47-67) on device tensors against the reference's goldens,
+    forward and autograd backward; CPU tensors raise (the CPU statement is the oracle's)."""
+    from mmfs_amd.functions import ms_deform_attn_core_pytorch
+    for name in ("op_g1_d64", "op_g2_bs4"):
+        z = load_golden(name)
+        v = T(z["value"], torch.float32).requires_grad_(True)
+        l = T(z["loc"], torch.float32).requires_grad_(True)
+        a = T(z["attn"], torch.float32).requires_grad_(True)
+        shapes = [tuple(int(x) for x in r) for r in z["spatial_shapes"]]         # an iterable of (H, W), like the reference's callers pass
+        out = ms_deform_attn_core_pytorch(v, shapes, l, a)
+        assert rel_err(out, z["out_f64"]) <= 1e-5
+        out.backward(T(z["grad_out"], torch.float32).reshape(out.shape))
+        assert rel_err(v.grad, z["grad_value_f64"]) <= 1e-5 and rel_err(a.grad, z["grad_attn_f64"]) <= 1e-5
+        assert rel_err(l.grad, z["grad_loc_f64"]) <= 1e-5
+    with pytest.raises(RuntimeError, match="CPU"):
+        ms_deform_attn_core_pytorch(v.detach().cpu(), shapes, l.detach().cpu(), a.detach().cpu())
 
 
 def test_blocks_on_gpu_match_reference():

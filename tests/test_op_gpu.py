@@ -222,6 +222,57 @@ def test_non_canonical_level_table_falls_back_and_is_right():
     assert not got[1][:, 9:12].any() and not got[1][:, 36:].any()      # untouched rows are zero
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fresh_level_tensors_cost_no_host_sync(dtype):
+    """The reference's callers rebuild spatial_shapes / level_start_index on every call
+    (modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41): tensors the shim has never seen.  Neither pass may
+    copy them back to the host to find out whether the packing is canonical -- the library checks the
+    table on the device (MMFS_BWD_DEVICE_CHECKED_LEVELS)."""
+    from mmfs_amd.functions import MSDeformAttnFunction
+    x = make_inputs(2, 4, 64, 50, 4, [(12, 9), (6, 5), (3, 3)], seed=31, loc_range=(-0.1, 1.1), dtype=dtype)
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
+    v, l, a, g = dev(x["value"]), dev(x["loc"]), dev(x["attn"]), dev(x["grad"])
+    host_sh, host_st = x["shapes"].tolist(), x["start"].tolist()
+    sh_dev, st_dev = x["shapes"].to(DEV), x["start"].to(DEV)
+    res = None
+    for it in range(3):
+        # fresh tensor OBJECTS every call, made without a host->device copy inside the checked region
+        sh, st = sh_dev.clone(), st_dev.clone()
+        vv, ll, aa = v.clone().requires_grad_(True), l.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        if it:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            out = MSDeformAttnFunction.apply(vv, sh, st, ll, aa, 1)
+            out.backward(g.reshape(out.shape))
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        res = [out.detach(), vv.grad, ll.grad, aa.grad]
+    torch.cuda.synchronize()
+    check([r.double().cpu().numpy() for r in res], run_oracle(x), dtype, "fresh level tensors")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_unverified_gapped_table_is_served_by_the_sorted_backward(dtype):
+    """A table nobody registered, with a gap, a tail and the levels in reverse order: the device-side
+    check passes (no two levels overlap), the rows no level owns come back zero."""
+    g = torch.Generator().manual_seed(5)
+    B, H, D, Nq, P = 2, 4, 64, 33, 4
+    shapes = torch.tensor([(5, 6), (3, 3), (9, 2)], dtype=torch.long)
+    start = torch.tensor([20, 2, 55], dtype=torch.long)          # level 1 at 2..10, level 0 at 20..49, level 2 at 55..72
+    S = 80
+    rt = lambda t: t.to(dtype).double()
+    x = dict(value=rt(torch.rand(B, S, H, D, generator=g)), shapes=shapes, start=start,
+             loc=rt(torch.rand(B, Nq, H, 3, P, 2, generator=g) * 1.2 - 0.1),
+             attn=rt(torch.rand(B, Nq, H, 3, P, generator=g)), grad=rt(torch.randn(B, Nq, H * D, generator=g)))
+    got, want = run_hip(x, dtype), run_oracle(x)
+    check(got, want, dtype, "gapped, unverified levels")
+    owned = np.zeros(S, bool)
+    for (h, w), s0 in zip(shapes.tolist(), start.tolist()):
+        owned[s0:s0 + h * w] = True
+    assert not got[1][:, ~owned].any()
+
+
 def test_skewed_locations_overflow_the_tile_lists():
     """All queries sample the same spot: one pixel receives Nq*P records, far more than a
     workgroup's LDS list holds -> exercises the per-pixel query-range rounds."""
