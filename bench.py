@@ -165,9 +165,13 @@ def cpu_baseline(budget_s=12.0):
         runs[threads] = (B * iters / el, el / iters * 1e3, iters)
     torch.set_num_threads(all_threads)
     ab = algorithmic_bytes(dict(w), 4)["fwdbwd"]
-    best = runs[all_threads]
-    return {"value": round(best[0], 3), "unit": "samples/s", "cores": all_threads, "kind": "port",
+    # "value" is the better of the two runs (on a 128-core host the all-cores run of this small problem
+    # is often the slower one); both are on the line
+    best_threads = all_threads if runs[all_threads][0] >= runs[1][0] else 1
+    best = runs[best_threads]
+    return {"value": round(best[0], 3), "unit": "samples/s", "cores": best_threads, "kind": "port",
             "ms_per_iter": round(best[1], 2), "effective_GBs": round(ab / (best[1] * 1e-3) / 1e9, 3),
+            "all_cores": {"threads": all_threads, "value": round(runs[all_threads][0], 3), "ms_per_iter": round(runs[all_threads][1], 2)},
             "one_thread": {"value": round(runs[1][0], 3), "ms_per_iter": round(runs[1][1], 2)},
             "cpu": cpu_model(), "host_cpus": os.cpu_count(),
             "sample": f"oracle/msda_torch.py (ms_deform_attn_core_pytorch restated), BASELINE config 1 "
@@ -253,6 +257,11 @@ def main():
     if args.dtype:
         w["dtype"] = args.dtype
     value, shapes, start, loc, attn, grad = make_inputs(w, device, seed=rank, loc_dist=args.loc_dist, visible=args.visible)
+    # the level tables through the product's own constructor (mmfs_amd.levels.make_level_tables, what the MMFS
+    # blocks use): built once, cached, and known to the shim without a device->host copy -- the reference's
+    # callers rebuild both tensors on every call (tables the shim has never seen are checked on the device)
+    from mmfs_amd.levels import make_level_tables
+    shapes, start, _ = make_level_tables(w["shapes"], w["n"], device)
     value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
 
     def step():
@@ -264,6 +273,18 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- parity guard: no number is printed for kernels that compute something else.  Size-independent
+    # properties of the op on this very workload (tests/test_op_gpu.py::test_full_size_properties): out is
+    # linear in value and in attn, so <value, dL/dvalue> = <attn, dL/dattn> = <out, grad> (Euler); finite outputs.
+    out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
+    gv, gl, ga = torch.autograd.grad(out, (value, loc, attn), grad)
+    og = (out.double() * grad.reshape(out.shape).double()).sum()
+    rel = {"f32": 1e-4, "f16": 4e-3, "bf16": 3e-2}[w["dtype"]]
+    e1 = abs(float((gv.double() * value.double()).sum() - og)); e2 = abs(float((ga.double() * attn.double()).sum() - og))
+    assert bool(torch.isfinite(out).all() and torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()), "non-finite output"
+    assert e1 <= rel * abs(float(og)) + rel and e2 <= rel * abs(float(og)) + rel, f"parity guard failed: {e1:.3e} {e2:.3e} vs {float(og):.3e}"
+    del out, gv, gl, ga
 
     for _ in range(args.warmup):
         step()

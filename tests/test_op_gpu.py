@@ -21,12 +21,14 @@ DEV = "cuda"
 TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}
 
 
-def run_hip(x, dtype, use_autograd=True):
+def run_hip(x, dtype, use_autograd=True, register=False):
     import MultiScaleDeformableAttention as MSDA
     from mmfs_amd.functions import MSDeformAttnFunction
     dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
     value, loc, attn, grad = dev(x["value"]), dev(x["loc"]), dev(x["attn"]), dev(x["grad"])
     sh, st = dev(x["shapes"]), dev(x["start"])
+    if register:         # the shim then knows the table on the host (what mmfs_amd.levels.make_level_tables does):
+        MSDA.register_level_tables(sh, st, value.shape[1], host_shapes=x["shapes"], host_start=x["start"])   # hybrid routing
     if use_autograd:
         value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
         out = MSDeformAttnFunction.apply(value, sh, st, loc, attn, 1)
@@ -129,7 +131,7 @@ def test_hybrid_dense_levels_match_oracle(case, dtype, parts, monkeypatch):
     x["loc"][0, 5, 1 % H, -1, 0, 1] = float("inf")
     log = []
     monkeypatch.setattr(MSDA, "_event_log", log)
-    got = run_hip(x, dtype, use_autograd=False)
+    got = run_hip(x, dtype, use_autograd=False, register=True)
     monkeypatch.setattr(MSDA, "_event_log", None)
     names = {n for n, _, _ in log}
     for part, kernel in (("taps", "msda_bwd_taps_coarse"), ("value", "msda_bwd_value_coarse"), ("fwd", "msda_fwd_coarse")):

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Module-level measurement lines for BASELINE configs 3 and 4 -- not the contract
+benchmark (that is bench.py, the op at config 2), but what surrounds the op on the two decoder paths:
+
+  cfg3  text forward, Vicuna-7B geometry: the 8 MMFS layers of the LLM (LlamaMMFSAttention: RMSNorm x2,
+        MMFS with d_query = 4096, H = 16, P = 8, L = 3 (32^2, 16^2, 8^2; S = 1344), tanh gate), B = 4, one
+        image, Lq in {1 (decode), 128, 512, 2048}; the dense LLM between them is out of scope
+  cfg4  image forward at 512 px: the 13-block MMFSNet schedule (sd_mmfs.py:230-272), B = 8, 4 levels of one
+        image, random residuals and features; one denoising step (no_grad, eager and HIP-graph replay) and
+        one training step
+
+One JSON line per case: ms per call, the time split by kernel family from the torch profiler (GEMM =
+hipBLASLt / rocBLAS kernels of the F.linear layers; op = this library's HIP kernels; other = framework
+elementwise / norm / copy kernels), and the two rooflines the north star asks for:
+  gemm_mfma_util   = analytic FLOPs of the Linear layers / GEMM kernel time / 2.5 PFLOP/s (dense bf16 MFMA peak)
+  op_hbm_frac      = algorithmic bytes of the sampling op (SURVEY 8d formula) / op kernel time / 8 TB/s
+Random weights (no checkpoints offline), bf16.   usage: python tools/module_bench.py [cfg3] [cfg4]
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd")]
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+dev, dt = "cuda", torch.bfloat16
+MFMA_PEAK, HBM_PEAK = 2.5e15, 8e12
+
+
+def family(name):
+    n = name.lower()
+    if "mmfs" in n or "msda" in n:
+        return "op"
+    if "cijk" in n or "gemm" in n or "hipblaslt" in n or "tensile" in n or "xdl" in n:
+        return "gemm"
+    return "other"
+
+
+def timed(fn, iters=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def split(fn, iters=5):
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+    fam = {"op": 0.0, "gemm": 0.0, "other": 0.0}
+    launches = 0
+    for e in prof.key_averages():
+        fam[family(e.key)] += e.device_time_total / iters
+        launches += e.count / iters
+    return {k: round(v, 1) for k, v in fam.items()}, int(launches)
+
+
+def mmfs_linear_flops(tokens, bank_tokens, d_query, d_value, d_inner, d_out, H, L, P, max_img):
+    """Forward FLOPs of the five Linear layers of MMFS.forward as this build evaluates them (one
+    dynamic_offset_mask GEMM on the un-repeated query; heads on the query + small table GEMMs)."""
+    f = 2 * bank_tokens * d_value * d_inner                      # value_proj
+    f += 2 * tokens * d_query * d_query                          # dynamic_offset_mask
+    f += 2 * tokens * d_query * (H * P * 2)                      # sampling_offsets
+    f += 2 * tokens * d_query * (H * L * P)                      # attention_weights (point columns)
+    f += 2 * tokens * d_inner * d_out                            # output_proj
+    f += 2 * max_img * d_query * (H * P * 2 + 2 * H * L * (P + 1))   # relative-position tables
+    return f
+
+
+def op_bytes(B, Nq, H, D, Leff, P, S, e=2, backward=False):
+    pts, C = B * Nq * H * Leff * P, H * D
+    fwd = e * (B * S * C + 3 * pts + B * Nq * C)
+    bwd = e * (2 * B * S * C + 6 * pts + B * Nq * C)
+    return fwd + (bwd if backward else 0)
+
+
+def cfg3():
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    cfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, rms_norm_eps=1e-6,
+                                max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt) for i in range(8)]
+    with torch.no_grad():
+        for l in layers:
+            l.gate.fill_(0.5)
+            l.attn.sampling_offsets.weight.normal_(0, 0.01)
+    B, n, S = 4, 1, 1344
+    feats = torch.randn(B, n, S, 1024, device=dev, dtype=dt)
+    for Lq in (1, 128, 512, 2048):
+        hidden = torch.randn(B, Lq, 4096, device=dev, dtype=dt)
+        mask = torch.ones(B, Lq, n, device=dev)
+
+        def fwd():
+            with torch.no_grad():
+                h = hidden
+                for l in layers:
+                    h = h + l(h, feats, mask)
+                return h
+
+        def train():
+            h = hidden.clone().requires_grad_(True)
+            x = h
+            for l in layers:
+                x = x + l(x, feats, mask)
+            x.backward(torch.ones_like(x))
+
+        for label, fn, bwd in (("forward", fwd, False), ("forward+backward", train, True)):
+            if bwd and Lq == 1:
+                continue
+            ms = timed(fn)
+            fam, launches = split(fn)
+            flops = 8 * mmfs_linear_flops(B * Lq, B * n * S, 4096, 1024, 1024, 4096, 16, 3, 8, 50) * (3 if bwd else 1)
+            ob = 8 * op_bytes(B, Lq, 16, 64, 3 * n, 8, S * n, backward=bwd)
+            print(json.dumps({
+                "config": "cfg3", "what": f"8 MMFS layers (Vicuna-7B geometry), B={B}, Lq={Lq}, n_images={n}, bf16, {label}",
+                "ms": round(ms, 3), "kernel_us": fam, "launches": launches,
+                "gemm_flops": flops, "gemm_mfma_util": round(flops / (fam["gemm"] * 1e-6) / MFMA_PEAK, 4) if fam["gemm"] else None,
+                "op_algorithmic_bytes": ob, "op_hbm_frac": round(ob / (fam["op"] * 1e-6) / HBM_PEAK, 4) if fam["op"] else None,
+            }), flush=True)
+
+
+def cfg4():
+    from mmfs_amd.blocks import MMFSNet
+    from mmfs_amd.graphs import GraphedMMFSNet
+    B, n = 8, 1
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MMFSNet(input_channel=1024, block_out_channels=[320, 640, 1280, 1280], layers_per_block=2,
+                      n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]).to(dev, dt)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.02)
+            blk.mmfs.sampling_offsets.weight.normal_(0, 0.01)
+    geom = list(zip([320] * 4 + [640] * 3 + [1280] * 5, [64] * 3 + [32] * 3 + [16] * 3 + [8] * 3))
+    res = [torch.randn(B, c, s, s, device=dev, dtype=dt) for c, s in geom]
+    mid = torch.randn(B, 1280, 8, 8, device=dev, dtype=dt)
+    feats = [torch.randn(B, n, 1024, s, s, device=dev, dtype=dt) for s in (64, 32, 16, 8)]
+    mask = torch.ones(B, n, device=dev, dtype=torch.long)
+    S = 5440
+    tokens = [(c, s * s) for c, s in geom] + [(1280, 64)]
+    flops = sum(mmfs_linear_flops(B * t, 0, c, 1024, 1024, c, 16, 4, 8, 10) + 2 * B * t * c * c for c, t in tokens)
+    flops_proj = 13 * 2 * B * n * S * 1024 * 1024
+    ob = sum(op_bytes(B, t, 16, 64, 4 * n, 8, S * n) for _, t in tokens)
+
+    net.eval()
+
+    def sample_step():
+        with torch.no_grad():
+            return net(mid, res, feats, mask)
+
+    sample_step()
+    graphed = GraphedMMFSNet(net, mid, res, feats, mask)
+    cases = [("one denoising step, eager (projected bank kept across steps)", sample_step, flops, False),
+             ("one denoising step, HIP-graph replay", lambda: graphed(mid, res), flops, False)]
+    net_t = net
+
+    def train_step():
+        net_t.train()
+        r = [x.clone().requires_grad_(True) for x in res]
+        m, rr = net_t(mid.clone().requires_grad_(True), r, feats, mask)
+        (m.float().sum() + sum(x.float().sum() for x in rr)).backward()
+        net_t.eval()
+
+    cases.append(("training step (forward + backward, gradient checkpointing as the reference builds it)", train_step,
+                  3 * (flops + flops_proj) + flops + flops_proj, True))
+    for label, fn, fl, bwd in cases:
+        ms = timed(fn, iters=10, warm=3)
+        fam, launches = split(fn, iters=3)
+        obb = sum(op_bytes(B, t, 16, 64, 4 * n, 8, S * n, backward=bwd) for _, t in tokens) + (ob if bwd else 0)
+        print(json.dumps({
+            "config": "cfg4", "what": f"MMFSNet, 13 blocks at 512 px, B={B}, n_images={n}, bf16, {label}",
+            "ms": round(ms, 3), "kernel_us": fam, "launches": launches,
+            "gemm_flops": fl, "gemm_mfma_util": round(fl / (fam["gemm"] * 1e-6) / MFMA_PEAK, 4) if fam["gemm"] else None,
+            "op_algorithmic_bytes": obb, "op_hbm_frac": round(obb / (fam["op"] * 1e-6) / HBM_PEAK, 4) if fam["op"] else None,
+        }), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg3", "cfg4"]
+    if "cfg3" in which:
+        cfg3()
+    if "cfg4" in which:
+        cfg4()
