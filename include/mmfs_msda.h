@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 4   /* 4: + mmfs_bank_gather / mmfs_bank_scatter, MMFS_BWD_LAZY_ZERO_ATTN */
+#define MMFS_MSDA_ABI_VERSION 5   /* 5: + MMFS_BWD_DEVICE_CHECKED_LEVELS; the dense forward / grad_value products
+                                   *    (mmfs_msda_forward_hybrid*, MMFS_BWD_DENSE_VALUE) are gone: measured slower than
+                                   *    the row-gather forward and the matrix-core tile reduce on every shipped geometry */
 
 enum mmfs_dtype {
     MMFS_F32  = 0,
@@ -89,7 +91,6 @@ int mmfs_msda_forward(int dtype,
  *   float-atomic accumulation, which is also correct for gapped or overlapping levels. */
 #define MMFS_BWD_FORCE_ATOMIC 2u      /* testing/measurement: always take the atomic path */
 #define MMFS_BWD_DENSE_TAPS   4u      /* mmfs_msda_backward_hybrid: small levels' grad_loc / grad_attn by MFMA */
-#define MMFS_BWD_DENSE_VALUE  8u      /* mmfs_msda_backward_hybrid: small levels' grad_value by MFMA */
 /* The caller does not read grad_attn (nor grad_loc, which is 0 anyway) of samples whose attention
  * weight is exactly 0: they may be written as 0 without reading the value rows.  True for MMFS: the
  * weights come out of its masked softmax (mmfs.py:203-231), whose backward multiplies every
@@ -196,50 +197,32 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
                                  int64_t L, int64_t Nq, int64_t P, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * Hybrid path (no counterpart in the reference; same results within the storage type's
+ * Hybrid backward (no counterpart in the reference; same results within the storage type's
  * rounding).  On MI355X the row gathers of this op are bound by the vector-memory path, not by
  * HBM, and every level receives the same number of taps whatever its size.  When the caller can
  * hand over a HOST copy of the level table (``host_shapes`` [L, 2], ``host_start`` [L]: int64 in
- * host memory, equal to the device tables), levels of at most min(256, 64*P) pixels are
- * evaluated as dense products on the matrix cores (csrc/msda_dense.hip):
- *     forward     out += A_l . V_l          grad_value_l = A_l^T . grad_out
- *     taps        dot = grad_out . V_l^T    (then 4 look-ups per sample)
- * with A_l the [queries x pixels] matrix of bilinear*attention weights, carried as hi + lo
- * 16-bit halves (>= 16 significant bits); the other levels run through the kernels of the
- * plain entry points, restricted to those levels.
- * Applies to MMFS_F16 / MMFS_BF16, D in {32, 64, 128}, L <= 64, Nq >= 32, at least one such level;
- * otherwise the *_workspace_bytes queries return 0 and the calls MMFS_E_UNSUPPORTED: use the
- * plain entry points.  The backward additionally needs MMFS_BWD_CANONICAL_LEVELS and at least one
- * of MMFS_BWD_DENSE_TAPS / MMFS_BWD_DENSE_VALUE in ``flags`` (which of its two halves go dense).
- * One behavioural difference, inherent to a dense product: a NON-FINITE value / grad_out element
- * inside a dense level propagates (0 * Inf = NaN) to every query of its (b, h), not only to the
- * queries that sample it.  Environment MMFS_HYBRID=0 disables the routing.
+ * host memory, equal to the device tables), grad_loc / grad_attn of levels of at most
+ * min(256, 64*P) pixels are evaluated as a dense product on the matrix cores
+ * (csrc/msda_dense.hip, kernel msda_taps_coarse):
+ *     dot = grad_out . V_l^T    [queries x pixels], then 4 look-ups per sample
+ * and the other levels run through the row-gather kernel of the plain entry point, restricted to
+ * those levels.  grad_value always takes the sorted path of mmfs_msda_backward.
+ * Applies to MMFS_F16 / MMFS_BF16, D in {32, 64, 128}, L <= 64, Nq >= 32, at least one such level,
+ * MMFS_BWD_CANONICAL_LEVELS and MMFS_BWD_DENSE_TAPS in ``flags``; otherwise the *_workspace_bytes
+ * query returns 0 and the call MMFS_E_UNSUPPORTED: use mmfs_msda_backward.
+ * One behavioural difference, inherent to a dense product: a NON-FINITE value element inside a
+ * dense level propagates (0 * Inf = NaN) to grad_loc / grad_attn of every query of its (b, h),
+ * not only to the queries that sample it.  Environment MMFS_HYBRID=0 disables the routing.
  *
  * ``stages`` selects which launches a call issues (OR of the bits; all of them = the whole
  * pass, in this order), so each kernel can be timed on its own.
  */
-#define MMFS_HYB_FWD_COARSE 1u          /* pack the dense levels' value, MFMA product -> fp32 partial output */
-#define MMFS_HYB_FWD_FINE   2u          /* row gathers of the other levels on top of it -> out */
-#define MMFS_HYB_FWD_ALL    3u
-int64_t mmfs_msda_forward_hybrid_workspace_bytes(int dtype,
-                                                 const int64_t *host_shapes, const int64_t *host_start,
-                                                 int64_t B, int64_t S, int64_t H, int64_t D,
-                                                 int64_t L, int64_t Nq, int64_t P);
-int mmfs_msda_forward_hybrid(int dtype,
-                             const void *value, const int64_t *shapes, const int64_t *start,
-                             const int64_t *host_shapes, const int64_t *host_start,
-                             const void *loc, const void *attn, void *out,
-                             void *workspace, int64_t workspace_bytes,
-                             int64_t B, int64_t S, int64_t H, int64_t D,
-                             int64_t L, int64_t Nq, int64_t P, unsigned stages, void *stream);
-
 #define MMFS_HYB_BWD_TAPS_FINE      1u
 #define MMFS_HYB_BWD_TAPS_COARSE    2u
 #define MMFS_HYB_BWD_VALUE_PREPARE  4u
 #define MMFS_HYB_BWD_VALUE_SORT     8u
 #define MMFS_HYB_BWD_VALUE_REDUCE  16u
-#define MMFS_HYB_BWD_VALUE_COARSE  32u  /* must follow _REDUCE: it overwrites the dense levels' rows */
-#define MMFS_HYB_BWD_ALL           63u
+#define MMFS_HYB_BWD_ALL           31u
 int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype,
                                                   const int64_t *host_shapes, const int64_t *host_start,
                                                   int64_t B, int64_t S, int64_t H, int64_t D,

@@ -40,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 4
+_ABI_VERSION = 5
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -67,10 +67,6 @@ _lib.mmfs_msda_backward_value_sort.restype = _int
 _lib.mmfs_msda_backward_value_sort.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
 _lib.mmfs_msda_backward_value_reduce.restype = _int
 _lib.mmfs_msda_backward_value_reduce.argtypes = [_int] + [_vp] * 3 + [_i64] * 8 + [_vp]
-_lib.mmfs_msda_forward_hybrid_workspace_bytes.restype = _i64
-_lib.mmfs_msda_forward_hybrid_workspace_bytes.argtypes = [_int, _vp, _vp] + [_i64] * 7
-_lib.mmfs_msda_forward_hybrid.restype = _int
-_lib.mmfs_msda_forward_hybrid.argtypes = [_int] + [_vp] * 9 + [_i64] * 8 + [ctypes.c_uint, _vp]
 _lib.mmfs_msda_backward_hybrid_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_hybrid_workspace_bytes.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_hybrid.restype = _int
@@ -184,34 +180,10 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     dims = (B, S, H, D, L, Nq, P)
     with torch.cuda.device(value.device):
         stream = _stream(value.device)
-        status = _E_UNSUPPORTED
-        # hybrid routing (small levels on the matrix cores) needs the level table on the host: one
-        # small device->host copy the first time a pair of table tensors is seen, none when they
-        # come from mmfs_amd.levels.make_level_tables / register_level_tables (like the backward)
-        info = None
-        if _hybrid and "fwd" in _hybrid_parts and code in (1, 2) and D in (32, 64, 128) and L <= 64 and Nq >= 32:
-            info = _level_info(spatial_shapes, level_start_index, S, sync=False)
-        if info is not None:
-            hs, hst = info[1].ctypes.data, info[2].ctypes.data
-            ws_bytes = _lib.mmfs_msda_forward_hybrid_workspace_bytes(code, hs, hst, *dims)
-            if ws_bytes > 0:
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
-                args = (code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs, hst,
-                        sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes,
-                        *dims)
-                if _event_log is None:
-                    status = _lib.mmfs_msda_forward_hybrid(*args, _HYB_FWD_ALL, stream)
-                else:
-                    status = _launch("msda_fwd_coarse", value.device, _lib.mmfs_msda_forward_hybrid,
-                                     *args, _HYB_FWD_COARSE, stream)
-                    if status == 0:
-                        status = _launch("msda_fwd", value.device, _lib.mmfs_msda_forward_hybrid,
-                                         *args, _HYB_FWD_FINE, stream)
-        if status == _E_UNSUPPORTED:
-            status = _launch(
-                "msda_fwd", value.device, _lib.mmfs_msda_forward, code, value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                out.data_ptr(), *dims, stream)
+        status = _launch(
+            "msda_fwd", value.device, _lib.mmfs_msda_forward, code, value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            out.data_ptr(), *dims, stream)
     _check(status, "ms_deform_attn_forward")
     return out
 
@@ -220,19 +192,15 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 _BWD_CANONICAL_LEVELS = 1
 _BWD_FORCE_ATOMIC = 2
 _BWD_DENSE_TAPS = 4
-_BWD_DENSE_VALUE = 8
 _BWD_LAZY_ZERO_ATTN = 16
 _BWD_DEVICE_CHECKED_LEVELS = 32
 _E_UNSUPPORTED = -5
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
-# tests / measurements: False keeps every level on the row-gather kernels
+# tests / measurements: False keeps grad_loc / grad_attn of every level on the row-gather kernel
+# (True: levels of at most min(256, 64*P) pixels take the matrix-core product, csrc/msda_dense.hip)
 _hybrid = os.environ.get("MMFS_HYBRID", "1") != "0"
-# which parts route their small levels to the matrix cores: comma list of fwd, taps, value.
-# Measured on MI355X: "taps" pays; the forward's dense part costs an fp32 round
-# trip of the output through HBM and the dense grad_value kernel is not yet faster than sort+reduce.
-_hybrid_parts = set(x for x in os.environ.get("MMFS_HYBRID_PARTS", "taps").split(",") if x)
 
 # The backward's two halves are independent (grad_loc / grad_attn read value; grad_value does not)
 # and can be launched on two streams (a side stream that forks from and joins the caller's stream
@@ -276,11 +244,10 @@ class _fork:
             self.main.wait_stream(self.side)
 
 
-# stage bits of the *_hybrid entry points (include/mmfs_msda.h)
-_HYB_FWD_COARSE, _HYB_FWD_FINE, _HYB_FWD_ALL = 1, 2, 3
+# stage bits of mmfs_msda_backward_hybrid (include/mmfs_msda.h)
 _HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
-                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16), ("msda_bwd_value_coarse", 32))
-_HYB_BWD_ALL = 63
+                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16))
+_HYB_BWD_ALL = 31
 
 
 def levels_are_canonical(spatial_shapes, level_start_index, S):
@@ -385,7 +352,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         status = _E_UNSUPPORTED
         hyb_bytes = 0
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
-            flags |= (_BWD_DENSE_TAPS if "taps" in _hybrid_parts else 0) | (_BWD_DENSE_VALUE if "value" in _hybrid_parts else 0)
+            flags |= _BWD_DENSE_TAPS
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             hyb_bytes = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
         if hyb_bytes > 0:
@@ -401,8 +368,6 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     bits = sum(bit for _, bit in stages)
                     return _lib.mmfs_msda_backward_hybrid(*args, bits, _stream(value.device))
                 for name, bit in stages:
-                    if (bit == 2 and not flags & _BWD_DENSE_TAPS) or (bit == 32 and not flags & _BWD_DENSE_VALUE):
-                        continue
                     st = _launch(name, value.device, _lib.mmfs_msda_backward_hybrid, *args, bit, _stream(value.device))
                     if st != 0:
                         break

@@ -76,13 +76,12 @@ struct TileTable {
 };
 
 __global__ void plan_tiles_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                  int L, int nt_min, int cap, uint64_t skip_levels,
+                                  int L, int nt_min, int cap,
                                   TileTable *__restrict__ table)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int n = 0;
     for (int l = 0; l < L && n < cap; ++l) {
-        if (l < 64 && ((skip_levels >> l) & 1ull)) continue;      // dense level: msda_value_coarse owns it
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
         const int px = Hl * Wl;
         if (px <= 0) continue;
@@ -519,19 +518,13 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
 
 template <typename T, int NV>
 hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d,
-                       uint64_t skip_levels, hipStream_t st)
+                       hipStream_t st)
 {
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (skip_levels) {
-        // the skipped levels' pixels get no run: the reduce stores zero rows there and the dense
-        // kernel's epilogue overwrites them afterwards (same stream)
-        const hipError_t e = hipMemsetAsync(sc.pixtab, 0, (size_t)d.B * d.H * d.S * sizeof(uint2), st);
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, tp.nt_min,
-                       tp.tiles_bound, skip_levels, sc.table);
+                       tp.tiles_bound, sc.table);
     hipLaunchKernelGGL((msda_bwd_value_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        shapes, start, (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor,
                        sc.pixtab, sc.table, d, tp);
@@ -556,16 +549,16 @@ hipError_t launch_reduce(const Scratch &sc, const void *go, void *gv, const Dims
 
 template <typename T>
 hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d,
-                         uint64_t skip_levels, hipStream_t st)
+                         hipStream_t st)
 {
     // vectorised scan when the P locations of a (b,h,level,q) are whole, aligned 16-byte vectors
     const int loc_bytes = d.P * 2 * (int)sizeof(T);
     int nv = 0;
     if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
     switch (nv) {
-        case 1: return launch_sort<T, 1>(shapes, start, sc, d, skip_levels, st);
-        case 2: return launch_sort<T, 2>(shapes, start, sc, d, skip_levels, st);
-        default: return launch_sort<T, 0>(shapes, start, sc, d, skip_levels, st);
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, st);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, st);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, st);
     }
 }
 
@@ -613,26 +606,26 @@ hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, 
 
 // Stage 2b: sort the tap contributions by pixel (prepared workspace -> records + run table).
 hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                               const Dims &d, hipStream_t st, uint64_t skip_levels)
+                               const Dims &d, hipStream_t st)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
-    if (skip_levels == 0 && bwd_value_block_supported(dtype, d))
+    if (bwd_value_block_supported(dtype, d))
         return backward_value_block_sort(dtype, shapes, start, workspace, d, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
-        case 0: return dispatch_sort<float>(shapes, start, sc, d, skip_levels, st);
-        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, skip_levels, st);
-        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, skip_levels, st);
+        case 0: return dispatch_sort<float>(shapes, start, sc, d, st);
+        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, st);
+        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, st);
         default: return hipErrorInvalidValue;
     }
 }
 
 // Stage 2c: reduce every pixel's run into its grad_value row.
 hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                 const Dims &d, hipStream_t st, uint64_t skip_levels)
+                                 const Dims &d, hipStream_t st)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
-    if (skip_levels == 0 && bwd_value_block_supported(dtype, d))      // must mirror backward_value_sort
+    if (bwd_value_block_supported(dtype, d))      // must mirror backward_value_sort
         return backward_value_block_reduce(dtype, grad_out, grad_value, workspace, d, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {

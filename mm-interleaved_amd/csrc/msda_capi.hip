@@ -305,47 +305,6 @@ static mmfs::HybridPlan hybrid_plan(int dtype, const mmfs::Dims &d, const int64_
     return mmfs::make_hybrid_plan(dtype, d, host_shapes, host_start);
 }
 
-int64_t mmfs_msda_forward_hybrid_workspace_bytes(int dtype, const int64_t *host_shapes, const int64_t *host_start,
-                                                 int64_t B, int64_t S, int64_t H, int64_t D,
-                                                 int64_t L, int64_t Nq, int64_t P)
-{
-    mmfs::Dims d;
-    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
-    if (B * Nq * H * D == 0 || d.K == 0 || S == 0) return 0;
-    return mmfs::hybrid_fwd_workspace_bytes(dtype, d, hybrid_plan(dtype, d, host_shapes, host_start));
-}
-
-int mmfs_msda_forward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
-                             const int64_t *host_shapes, const int64_t *host_start,
-                             const void *loc, const void *attn, void *out,
-                             void *workspace, int64_t workspace_bytes,
-                             int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
-                             unsigned stages, void *stream)
-{
-    const int es = elem_size(dtype);
-    if (!es) return MMFS_E_DTYPE;
-    mmfs::Dims d;
-    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
-    if (rc) return rc;
-    if (B * Nq * H * D == 0 || d.K == 0 || S == 0) return MMFS_E_UNSUPPORTED;     // use mmfs_msda_forward
-    const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    if (!plan.coarse_active) return MMFS_E_UNSUPPORTED;
-    if (!value || !shapes || !start || !loc || !attn || !out) return MMFS_E_NULLPTR;
-    if (misaligned(value, 16) || misaligned(out, 16) || misaligned(loc, es) || misaligned(attn, es))
-        return MMFS_E_ALIGN;
-    if (!workspace || workspace_bytes < mmfs::hybrid_fwd_workspace_bytes(dtype, d, plan)) return MMFS_E_NULLPTR;
-    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
-    hipStream_t st = (hipStream_t)stream;
-    if (stages & MMFS_HYB_FWD_COARSE) {
-        const hipError_t e = mmfs::forward_coarse(dtype, value, loc, attn, workspace, d, plan, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (stages & MMFS_HYB_FWD_FINE)
-        return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st, &plan.fine,
-                                  mmfs::hybrid_fwd_init(workspace, d, plan));
-    return MMFS_OK;
-}
-
 int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host_shapes, const int64_t *host_start,
                                                   int64_t B, int64_t S, int64_t H, int64_t D,
                                                   int64_t L, int64_t Nq, int64_t P, unsigned flags)
@@ -354,11 +313,8 @@ int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
-    const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;
-    if (!dense_taps && !dense_value) return 0;
-    const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    return base + (dense_value ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0);
+    if (!((flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active)) return 0;
+    return (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
 }
 
 int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
@@ -385,18 +341,15 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     }
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
-    const bool dense_value = (flags & MMFS_BWD_DENSE_VALUE) && plan.coarse_active;
-    if (!dense_taps && !dense_value) return MMFS_E_UNSUPPORTED;
+    if (!dense_taps) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
         return MMFS_E_NULLPTR;
     if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||
         misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es))
         return MMFS_E_ALIGN;
     const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    if (!workspace || workspace_bytes < base + (dense_value ? mmfs::hybrid_bwd_partial_bytes(d, plan) : 0))
-        return MMFS_E_NULLPTR;
+    if (!workspace || workspace_bytes < base) return MMFS_E_NULLPTR;
     if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
-    void *partial = (char *)workspace + base;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     // (every level dense -- e.g. the ViT-Adapter extractor's single 16x16 map -- leaves the row-gather
@@ -409,11 +362,9 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))
         e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
-        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, dense_value ? plan.coarse_mask : 0);
+        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
-        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, dense_value ? plan.coarse_mask : 0);
-    if (e == hipSuccess && dense_value && (stages & MMFS_HYB_BWD_VALUE_COARSE))
-        e = mmfs::backward_value_coarse(dtype, loc, attn, grad_out, grad_value, partial, d, plan, st);
+        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
     return (int)e;
 }
 

@@ -144,28 +144,16 @@ __device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, uint
 }
 
 // ---------------------------------------------------------------- level routing (hybrid path)
-// When the host knows the level table (a host copy handed to the *_hybrid entry points), levels
-// of at most kCoarseMaxPx pixels are taken out of the row-gather kernels and evaluated as dense
-// matrix products on the matrix cores (msda_dense.hip); the gather kernels then visit only the
-// levels listed in a LevelSel.
+// When the host knows the level table (a host copy handed to mmfs_msda_backward_hybrid), levels of at
+// most kCoarseMaxPx pixels are taken out of the row-gather taps kernel and their grad_loc / grad_attn
+// evaluated as dense dot products on the matrix cores (msda_dense.hip); the gather kernel then visits
+// only the levels listed in a LevelSel.
 constexpr int kMaxSelLevels = 64;      // hybrid routing only for L <= 64
-constexpr int kMaxCoarse = 32;
 constexpr int kCoarseMaxPx = 256;
 
 struct LevelSel {
     int n;                             // levels to visit; < 0: all L levels in order
     uint8_t idx[kMaxSelLevels];
-};
-
-struct CoarseLevel {
-    int level, Hl, Wl, start;          // index in the level table, extent, first pixel on the S axis
-    int coff, kpad;                    // offset / padded pixel count (multiple of 8) in the packed coarse axis
-};
-
-struct CoarsePlan {
-    int n;                             // dense levels
-    int ktot;                          // sum of kpad
-    CoarseLevel lv[kMaxCoarse];
 };
 
 // Dense dot products for grad_loc / grad_attn (msda_taps_coarse): a level is walked in chunks of

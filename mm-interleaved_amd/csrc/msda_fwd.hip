@@ -42,8 +42,7 @@ template <typename T, int LPI, bool BUF>
 __global__ void __launch_bounds__(kThreads)
 msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
-             const T *__restrict__ attn, T *__restrict__ out, const Dims d,
-             const LevelSel sel, const float *__restrict__ init)
+             const T *__restrict__ attn, T *__restrict__ out, const Dims d)
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
@@ -51,21 +50,13 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int KC = (kRecsPerBlock / QPB) > kUnroll ? (kRecsPerBlock / QPB) : kUnroll;  // samples per query per chunk (pow2)
     constexpr int STRIDE = 2 * KC + 1;            // uint4 units; +1 breaks the bank alignment
     __shared__ uint4 lds[QPB * STRIDE];
-    __shared__ uint8_t sel_idx[kMaxSelLevels];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
     const int qi = tid / LPI, lig = tid % LPI;
     const int q = bc.q0 + qi;
     const bool q_ok = q < d.Nq;
-    // hybrid routing: only the levels of sel are gathered here, on top of the dense levels'
-    // contribution (init, fp32 [B, Nq, H, D]) computed by msda_fwd_coarse
-    const bool all_levels = sel.n < 0;
-    const int Ksel = all_levels ? d.K : sel.n * d.P;
-    if (!all_levels) {
-        if (tid < kMaxSelLevels) sel_idx[tid] = sel.idx[tid];
-        __syncthreads();
-    }
+    const int Ksel = d.K;
 
     const int64_t HD = (int64_t)d.H * d.D;
     const T *slab = value + ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;   // this (b, h)
@@ -78,14 +69,6 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    if (init != nullptr && q_ok) {
-        const float *ip = init + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + lig * VEC;
-#pragma unroll
-        for (int i = 0; i < VEC; i += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(ip + i);
-            acc[i] = t.x; acc[i + 1] = t.y; acc[i + 2] = t.z; acc[i + 3] = t.w;
-        }
-    }
 
     for (int k0 = 0; k0 < Ksel; k0 += KC) {
         const int kc = min(KC, Ksel - k0);
@@ -100,9 +83,8 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             rec.w[0] = rec.w[1] = rec.w[2] = rec.w[3] = 0.f;
             const int sq = bc.q0 + rq;
             if (kk < kc && sq < d.Nq) {
-                const int ks = k0 + kk;
-                const int l = all_levels ? ks / d.P : (int)sel_idx[ks / d.P];
-                const int k = l * d.P + ks % d.P;
+                const int k = k0 + kk;
+                const int l = k / d.P;
                 const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
                 const float lx = to_f32(loc[2 * s]), ly = to_f32(loc[2 * s + 1]);
                 const float a = to_f32(attn[s]);
@@ -224,8 +206,7 @@ msda_fwd_scalar(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 // ---------------------------------------------------------------- launchers
 template <typename T, int LPI>
 static hipError_t launch_vec(const void *value, const int64_t *shapes, const int64_t *start,
-                             const void *loc, const void *attn, void *out, Dims d, hipStream_t st,
-                             const LevelSel &sel, const float *init)
+                             const void *loc, const void *attn, void *out, Dims d, hipStream_t st)
 {
     constexpr int QPB = kThreads / LPI;
     d.q_tiles = (d.Nq + QPB - 1) / QPB;
@@ -235,10 +216,10 @@ static hipError_t launch_vec(const void *value, const int64_t *shapes, const int
     const bool buf = (int64_t)d.S * d.H * d.D * (int64_t)sizeof(T) <= kMaxSlabBytes;
     if (buf)
         hipLaunchKernelGGL((msda_fwd_vec<T, LPI, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d, sel, init);
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d);
     else
         hipLaunchKernelGGL((msda_fwd_vec<T, LPI, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d, sel, init);
+                           (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d);
     return hipGetLastError();
 }
 
@@ -255,39 +236,28 @@ static hipError_t launch_scalar(const void *value, const int64_t *shapes, const 
 
 template <typename T>
 static hipError_t dispatch_fwd(const void *value, const int64_t *shapes, const int64_t *start,
-                               const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st,
-                               const LevelSel &sel, const float *init)
+                               const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (d.D % VEC == 0) {
         switch (d.D / VEC) {
-#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, out, d, st, sel, init);
+#define MMFS_CASE(n) case n: return launch_vec<T, n>(value, shapes, start, loc, attn, out, d, st);
             MMFS_CASE(1) MMFS_CASE(2) MMFS_CASE(4) MMFS_CASE(8) MMFS_CASE(16) MMFS_CASE(32) MMFS_CASE(64)
 #undef MMFS_CASE
             default: break;
         }
     }
-    if (sel.n >= 0 || init) return hipErrorInvalidValue;      // routing exists on the vector path only
     return launch_scalar<T>(value, shapes, start, loc, attn, out, d, st);
 }
 
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
-                   const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st,
-                   const LevelSel *sel, const float *init)
+                   const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st)
 {
-    LevelSel all;
-    all.n = -1;
-    const bool routed = sel != nullptr && sel->n >= 0;
-    int qpb = 0;
-    if (!routed && !init && forward_cached_applicable(dtype, d, &qpb))
-        return forward_cached(dtype, value, shapes, start, loc, attn, out, d, qpb, st);
-    const LevelSel &s = routed ? *sel : all;
     switch (dtype) {
-        case 0: return dispatch_fwd<float>(value, shapes, start, loc, attn, out, d, st, s, init);
-        case 1: return dispatch_fwd<half_t>(value, shapes, start, loc, attn, out, d, st, s, init);
-        case 2: return dispatch_fwd<bf16_t>(value, shapes, start, loc, attn, out, d, st, s, init);
-        case 3: if (routed || init) return hipErrorInvalidValue;
-                return launch_scalar<double>(value, shapes, start, loc, attn, out, d, st);
+        case 0: return dispatch_fwd<float>(value, shapes, start, loc, attn, out, d, st);
+        case 1: return dispatch_fwd<half_t>(value, shapes, start, loc, attn, out, d, st);
+        case 2: return dispatch_fwd<bf16_t>(value, shapes, start, loc, attn, out, d, st);
+        case 3: return launch_scalar<double>(value, shapes, start, loc, attn, out, d, st);
         default: return hipErrorInvalidValue;
     }
 }

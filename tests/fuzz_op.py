@@ -66,17 +66,22 @@ def one_case(rng, idx):
     rt = lambda t: t.to(dtype).to(torch.float64)
     value, loc, attn, grad = rt(value), rt(loc), rt(attn), rt(grad)
     hybrid = rng.random() < 0.7
-    parts = rng.choice(["taps", "taps", "taps,value", "fwd,taps,value", "fwd"])
-    algo = rng.choice(["block", "block", "pixel"])
-    os.environ["MMFS_VALUE_ALGO"] = algo
+    registered = rng.random() < 0.6          # else: fresh device tables, checked on the device by the backward
+    algo = rng.choice(["tile", "tile", "block", "pixel"])
+    if algo == "tile":                       # the default: 4x4 blocks on the matrix cores for 16-bit storage
+        os.environ.pop("MMFS_VALUE_ALGO", None)
+    else:
+        os.environ["MMFS_VALUE_ALGO"] = algo
     MSDA._hybrid = hybrid
-    MSDA._hybrid_parts = set(parts.split(","))
     MSDA._bwd_algo = "atomic" if rng.random() < 0.08 else "auto"
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
-    desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid}:{parts} "
+    desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
             f"value={algo} bwd={MSDA._bwd_algo}")
-    out = MSDA.ms_deform_attn_forward(dev(value), dev(sh), dev(st), dev(loc), dev(attn), 1)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(dev(value), dev(sh), dev(st), dev(loc), dev(attn), dev(grad), 1)
+    dsh, dst = dev(sh), dev(st)
+    if registered:
+        MSDA.register_level_tables(dsh, dst, S, sh.numpy(), st.numpy())
+    out = MSDA.ms_deform_attn_forward(dev(value), dsh, dst, dev(loc), dev(attn), 1)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(dev(value), dsh, dst, dev(loc), dev(attn), dev(grad), 1)
     torch.cuda.synchronize()
     want = msda_oracle.forward(value, sh, st, loc, attn)
     wgv, wgl, wga = msda_oracle.backward(value, sh, st, loc, attn, grad)

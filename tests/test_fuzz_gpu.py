@@ -21,13 +21,13 @@ def _fuzz():
 @pytest.fixture
 def restore_knobs():
     import MultiScaleDeformableAttention as MSDA
-    keep = (MSDA._hybrid, set(MSDA._hybrid_parts), MSDA._bwd_algo, os.environ.get("MMFS_VALUE_ALGO"))
+    keep = (MSDA._hybrid, MSDA._bwd_algo, os.environ.get("MMFS_VALUE_ALGO"))
     yield
-    MSDA._hybrid, MSDA._hybrid_parts, MSDA._bwd_algo = keep[0], keep[1], keep[2]
-    if keep[3] is None:
+    MSDA._hybrid, MSDA._bwd_algo = keep[0], keep[1]
+    if keep[2] is None:
         os.environ.pop("MMFS_VALUE_ALGO", None)
     else:
-        os.environ["MMFS_VALUE_ALGO"] = keep[3]
+        os.environ["MMFS_VALUE_ALGO"] = keep[2]
 
 
 @pytest.mark.gpu
