@@ -154,6 +154,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr bool PRE = BUF && !SCATTER;           // records carry byte offsets, not pixel rows
     __shared__ uint4 lds[QPB * STRIDE];
     __shared__ uint8_t sel_idx[kMaxSelLevels];
+    __shared__ LevelLds levels;
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
@@ -163,10 +164,10 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     // hybrid routing: the levels not in sel get their grad_loc / grad_attn from msda_taps_coarse
     const bool all_levels = sel.n < 0;
     const int Ksel = all_levels ? d.K : sel.n * d.P;
-    if (!all_levels) {
-        if (tid < kMaxSelLevels) sel_idx[tid] = sel.idx[tid];
-        __syncthreads();
-    }
+    if (!all_levels && tid < kMaxSelLevels) sel_idx[tid] = sel.idx[tid];
+    levels.load(shapes, start, d.L, tid, kThreads);
+    const bool pair_ok = (((uintptr_t)loc | (uintptr_t)grad_loc) & (2 * sizeof(T) - 1)) == 0;
+    __syncthreads();
 
     const int64_t HD = (int64_t)d.H * d.D;
     const int64_t slice = ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;
@@ -196,9 +197,8 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         const int kc_pad = (kc + kUnroll - 1) / kUnroll * kUnroll;
         if (k0 > 0) __syncthreads();
         // ---- stage
-        for (int r = tid; r < QPB * KC; r += kThreads) {
-            const int rq = r / KC, kk = r % KC;
-            if (kk >= kc_pad) continue;
+        for (int r = tid; r < QPB * kc_pad; r += kThreads) {
+            const int rq = r / kc_pad, kk = r - rq * kc_pad;
             int row[4] = {-1, -1, -1, -1};
             float fx = 0.f, fy = 0.f, a = 0.f;
             uint32_t wh = 0;
@@ -208,9 +208,11 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 const int l = all_levels ? ks / d.P : (int)sel_idx[ks / d.P];
                 const int k = l * d.P + ks % d.P;
                 const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
-                const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-                const Tap<float> t = locate<float>(to_f32(loc[2 * s]), to_f32(loc[2 * s + 1]), Hl, Wl,
-                                                   (int)start[l]);
+                int Hl, Wl, lstart;
+                levels.get(shapes, start, l, Hl, Wl, lstart);
+                float lx, ly;
+                load_xy(loc, s, pair_ok, lx, ly);
+                const Tap<float> t = locate<float>(lx, ly, Hl, Wl, lstart);
                 fx = t.fx; fy = t.fy; a = to_f32(attn[s]);
                 // lazy_attn: nobody reads the gradients of a zero-weight sample -> no rows, zeros out
                 if (!(d.lazy_attn && !SCATTER && a == 0.f)) {
@@ -305,17 +307,16 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
         __syncthreads();
         // ---- coalesced store of this chunk's grad_attn / grad_loc
-        for (int r = tid; r < QPB * KC; r += kThreads) {
-            const int rq = r / KC, kk = r % KC;
+        for (int r = tid; r < QPB * kc; r += kThreads) {
+            const int rq = r / kc, kk = r - rq * kc;
             const int sq = bc.q0 + rq;
-            if (kk >= kc || sq >= d.Nq) continue;
+            if (sq >= d.Nq) continue;
             const uint4 res = lds[rq * STRIDE + 2 * kk];
             const int ks = k0 + kk;
             const int k = all_levels ? ks : (int)sel_idx[ks / d.P] * d.P + ks % d.P;
             const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
             grad_attn[s] = (T)__uint_as_float(res.x);
-            grad_loc[2 * s] = (T)__uint_as_float(res.y);
-            grad_loc[2 * s + 1] = (T)__uint_as_float(res.z);
+            store_xy(grad_loc, s, pair_ok, __uint_as_float(res.y), __uint_as_float(res.z));
         }
     }
 }

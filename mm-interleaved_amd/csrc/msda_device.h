@@ -114,6 +114,64 @@ __device__ __forceinline__ Tap<A> locate(A lx, A ly, int Hl, int Wl, int level_s
     return t;
 }
 
+// ---------------------------------------------------------------- staging helpers
+// The texture path spends the same 16 clocks on a wave-wide load whether a lane asks for 2 bytes or
+// for 16, and the row-gather kernels are bound by exactly that path: what a workgroup reads besides
+// its rows has to be FEW instructions.  So the level table is fetched once per workgroup into LDS
+// (instead of three 8-byte loads per sample), a sample's (x, y) pair is one load, and the staging
+// loops run over the live samples only (no lanes parked on padding).
+constexpr int kStageLevels = 128;
+
+struct LevelLds {
+    int tab[kStageLevels * 3];           // Hl, Wl, start of levels [0, min(L, kStageLevels))
+    // call from every thread of the workgroup, then __syncthreads() before the first get()
+    __device__ __forceinline__ void load(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                         int L, int tid, int nthreads) {
+        for (int l = tid; l < L && l < kStageLevels; l += nthreads) {
+            tab[3 * l] = (int)shapes[2 * l]; tab[3 * l + 1] = (int)shapes[2 * l + 1]; tab[3 * l + 2] = (int)start[l];
+        }
+    }
+    __device__ __forceinline__ void get(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                        int l, int &Hl, int &Wl, int &st) const {
+        if (l < kStageLevels) { Hl = tab[3 * l]; Wl = tab[3 * l + 1]; st = tab[3 * l + 2]; }
+        else { Hl = (int)shapes[2 * l]; Wl = (int)shapes[2 * l + 1]; st = (int)start[l]; }
+    }
+};
+
+// (x, y) of sample s as one load when the pair is naturally aligned (pair_ok: the tensor base is)
+template <typename T>
+__device__ __forceinline__ void load_xy(const T *__restrict__ loc, int64_t s, bool pair_ok, float &x, float &y)
+{
+    if (sizeof(T) == 2 && pair_ok) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(loc + 2 * s);
+        T p[2];
+        __builtin_memcpy(p, &w, 4);
+        x = to_f32(p[0]); y = to_f32(p[1]);
+    } else if (sizeof(T) == 4 && pair_ok) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(loc + 2 * s);
+        x = __uint_as_float(w.x); y = __uint_as_float(w.y);
+    } else {
+        x = to_f32(loc[2 * s]); y = to_f32(loc[2 * s + 1]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_xy(T *__restrict__ dst, int64_t s, bool pair_ok, float x, float y)
+{
+    T p[2] = {(T)x, (T)y};
+    if (sizeof(T) == 2 && pair_ok) {
+        uint32_t w;
+        __builtin_memcpy(&w, p, 4);
+        *reinterpret_cast<uint32_t *>(dst + 2 * s) = w;
+    } else if (sizeof(T) == 4 && pair_ok) {
+        uint2 w;
+        __builtin_memcpy(&w, p, 8);
+        *reinterpret_cast<uint2 *>(dst + 2 * s) = w;
+    } else {
+        dst[2 * s] = p[0]; dst[2 * s + 1] = p[1];
+    }
+}
+
 // ---------------------------------------------------------------- buffer addressing
 // Row gathers go through a buffer descriptor (SRD) whose base is the workgroup's
 // (batch, head) slab: the per-lane address is a 32-bit byte offset, and an offset at or

@@ -50,9 +50,13 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int KC = (kRecsPerBlock / QPB) > kUnroll ? (kRecsPerBlock / QPB) : kUnroll;  // samples per query per chunk (pow2)
     constexpr int STRIDE = 2 * KC + 1;            // uint4 units; +1 breaks the bank alignment
     __shared__ uint4 lds[QPB * STRIDE];
+    __shared__ LevelLds levels;
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
+    levels.load(shapes, start, d.L, tid, kThreads);
+    const bool pair_ok = ((uintptr_t)loc & (2 * sizeof(T) - 1)) == 0;
+    __syncthreads();
     const int qi = tid / LPI, lig = tid % LPI;
     const int q = bc.q0 + qi;
     const bool q_ok = q < d.Nq;
@@ -75,9 +79,8 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         const int kc_pad = (kc + kUnroll - 1) / kUnroll * kUnroll;
         if (k0 > 0) __syncthreads();              // previous chunk fully consumed
         // ---- stage: locations + weights -> tap records (coalesced over samples)
-        for (int r = tid; r < QPB * KC; r += kThreads) {
-            const int rq = r / KC, kk = r % KC;
-            if (kk >= kc_pad) continue;
+        for (int r = tid; r < QPB * kc_pad; r += kThreads) {
+            const int rq = r / kc_pad, kk = r - rq * kc_pad;
             FwdRec rec;
             rec.row[0] = rec.row[1] = rec.row[2] = rec.row[3] = -1;
             rec.w[0] = rec.w[1] = rec.w[2] = rec.w[3] = 0.f;
@@ -86,10 +89,12 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 const int k = k0 + kk;
                 const int l = k / d.P;
                 const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
-                const float lx = to_f32(loc[2 * s]), ly = to_f32(loc[2 * s + 1]);
+                float lx, ly;
+                load_xy(loc, s, pair_ok, lx, ly);
                 const float a = to_f32(attn[s]);
-                const Tap<float> t = locate<float>(lx, ly, (int)shapes[2 * l], (int)shapes[2 * l + 1],
-                                                   (int)start[l]);
+                int Hl, Wl, lstart;
+                levels.get(shapes, start, l, Hl, Wl, lstart);
+                const Tap<float> t = locate<float>(lx, ly, Hl, Wl, lstart);
                 const float gy = 1.f - t.fy, gx = 1.f - t.fx;
                 // a zero attention weight (an image the token cannot see: the masked softmax gives
                 // exactly 0, mmfs.py:203-231) reads no rows at all -- it is marked "outside"
