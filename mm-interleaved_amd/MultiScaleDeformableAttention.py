@@ -101,28 +101,38 @@ def _require(cond, msg):
 
 
 def _validate(named, value):
+    # (messages are only built when a check fails: this runs on every call of a ~100 us step)
+    dev = value.device
     for name, t in named:
-        _require(isinstance(t, torch.Tensor), f"{name} must be a tensor")
-        _require(t.is_contiguous(), f"{name} tensor has to be contiguous")
+        if not isinstance(t, torch.Tensor):
+            raise RuntimeError(f"{name} must be a tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
         # PyTorch-ROCm exposes HIP devices under the "cuda" device type
-        _require(t.is_cuda, f"{name} must be a CUDA tensor")   # reference wording, .cu:35-39
-        _require(t.device == value.device, f"{name} must be on the same device as value")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")   # reference wording, .cu:35-39
+        if t.device != dev:
+            raise RuntimeError(f"{name} must be on the same device as value")
 
 
 def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
-    _require(value.dim() == 4, "value must be [B, S, H, D]")
+    if value.dim() != 4:
+        raise RuntimeError("value must be [B, S, H, D]")
     B, S, H, D = value.shape
-    _require(spatial_shapes.dim() == 2 and spatial_shapes.shape[1] == 2, "spatial_shapes must be [L, 2]")
+    if spatial_shapes.dim() != 2 or spatial_shapes.shape[1] != 2:
+        raise RuntimeError("spatial_shapes must be [L, 2]")
     L = spatial_shapes.shape[0]
-    _require(sampling_loc.dim() == 6, "sampling_loc must be [B, Nq, H, L, P, 2]")
+    if sampling_loc.dim() != 6:
+        raise RuntimeError("sampling_loc must be [B, Nq, H, L, P, 2]")
     Nq, P = sampling_loc.shape[1], sampling_loc.shape[4]
-    _require(tuple(sampling_loc.shape) == (B, Nq, H, L, P, 2),
-             f"sampling_loc shape {tuple(sampling_loc.shape)} != {(B, Nq, H, L, P, 2)}")
-    _require(tuple(attn_weight.shape) == (B, Nq, H, L, P),
-             f"attn_weight shape {tuple(attn_weight.shape)} != {(B, Nq, H, L, P)}")
-    _require(level_start_index.numel() == L, "level_start_index must have one entry per level")
-    _require(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
-             "spatial_shapes and level_start_index must be int64 (reference reads data<int64_t>)")
+    if sampling_loc.shape != (B, Nq, H, L, P, 2):
+        raise RuntimeError(f"sampling_loc shape {tuple(sampling_loc.shape)} != {(B, Nq, H, L, P, 2)}")
+    if attn_weight.shape != (B, Nq, H, L, P):
+        raise RuntimeError(f"attn_weight shape {tuple(attn_weight.shape)} != {(B, Nq, H, L, P)}")
+    if level_start_index.numel() != L:
+        raise RuntimeError("level_start_index must have one entry per level")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 (reference reads data<int64_t>)")
     return B, S, H, D, L, Nq, P
 
 
@@ -143,7 +153,30 @@ def _aligned(t, nbytes=16):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
+class _on_device:
+    """torch.cuda.device(dev) without the context-manager cost when dev is already current."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+# host-only size queries of the library, memoised (they depend on the numbers only; the level table enters
+# through the identity + version of its host copy)
+_ws_cache = {}
 
 
 # bench.py sets this to a list to time individual kernels with HIP events recorded on
@@ -178,7 +211,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((B, Nq, H * D), dtype=value.dtype, device=value.device)
     code = _DTYPE_CODE[value.dtype]
     dims = (B, S, H, D, L, Nq, P)
-    with torch.cuda.device(value.device):
+    with _on_device(value.device):
         stream = _stream(value.device)
         status = _launch(
             "msda_fwd", value.device, _lib.mmfs_msda_forward, code, value.data_ptr(), spatial_shapes.data_ptr(),
@@ -347,14 +380,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.empty(value.shape, dtype=dt, device=value.device)
     grad_loc = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
     grad_attn = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
-    with torch.cuda.device(value.device):
+    with _on_device(value.device):
         stream = _stream(value.device)
         status = _E_UNSUPPORTED
         hyb_bytes = 0
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
             flags |= _BWD_DENSE_TAPS
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
-            hyb_bytes = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
+            key = (code, dims, flags, hs, hst)            # (the host copies live as long as their table tensor)
+            hyb_bytes = _ws_cache.get(key)
+            if hyb_bytes is None:
+                if len(_ws_cache) > 4096:
+                    _ws_cache.clear()
+                hyb_bytes = _ws_cache[key] = _lib.mmfs_msda_backward_hybrid_workspace_bytes(code, hs, hst, *dims, flags)
         if hyb_bytes > 0:
             # small levels on the matrix cores, the others through the gather / sort / reduce kernels
             ws = torch.empty(hyb_bytes, dtype=torch.uint8, device=value.device)
@@ -381,7 +419,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 if status == 0:
                     status = run_stages(_HYB_BWD_STAGES[2:])         # grad_value
                 fork.join()
-        ws_bytes = 0 if hyb_bytes > 0 else _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
+        ws_bytes = 0
+        if hyb_bytes == 0:
+            key = (code, dims, flags)
+            ws_bytes = _ws_cache.get(key)
+            if ws_bytes is None:
+                ws_bytes = _ws_cache[key] = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
         if hyb_bytes == 0 and (flags & (_BWD_CANONICAL_LEVELS | _BWD_DEVICE_CHECKED_LEVELS)) and _event_log is None and not _bwd_overlap:

@@ -97,13 +97,28 @@ __device__ __host__ inline int cap_of(int64_t samples, int64_t blocks)
     return (int)(c < kCapRecords ? kCapRecords : (c > 0x3fffffff ? 0x3fffffff : c));
 }
 
-__global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                  int L, int S, int nt_min, int cap, int64_t samples_per_level,
-                                  CellHeader *__restrict__ hdr, uint32_t *__restrict__ ovf_header,
-                                  uint32_t cap_slots, uint32_t cap_entries, uint32_t cap_partials,
-                                  TileHeader *__restrict__ th, uint32_t tile_cap_extra, uint32_t tile_cap_partials)
+struct PlanArgs {
+    const int64_t *shapes, *start;     // shapes == nullptr: no plan in this launch
+    int L, S, nt_min, cap;
+    int64_t samples_per_level;
+    CellHeader *hdr;
+    uint32_t *ovf_header;
+    uint32_t cap_slots, cap_entries, cap_partials;
+    TileHeader *th;
+    uint32_t tile_cap_extra, tile_cap_partials;
+};
+
+// The plan: one workgroup's job (its lanes 0-31 clear a row, lane 0 does the serial part).
+__device__ void plan_cells_body(const PlanArgs &pa)
 {
-    if (blockIdx.x != 0) return;
+    const int64_t *__restrict__ shapes = pa.shapes, *__restrict__ start = pa.start;
+    const int L = pa.L, S = pa.S, nt_min = pa.nt_min, cap = pa.cap;
+    const int64_t samples_per_level = pa.samples_per_level;
+    CellHeader *__restrict__ hdr = pa.hdr;
+    uint32_t *__restrict__ ovf_header = pa.ovf_header;
+    const uint32_t cap_slots = pa.cap_slots, cap_entries = pa.cap_entries, cap_partials = pa.cap_partials;
+    TileHeader *__restrict__ th = pa.th;
+    const uint32_t tile_cap_extra = pa.tile_cap_extra, tile_cap_partials = pa.tile_cap_partials;
     if (th != nullptr && threadIdx.x < 32) th->zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x != 0) return;
     if (th != nullptr) {
@@ -175,6 +190,49 @@ __global__ void plan_cells_kernel(const int64_t *__restrict__ shapes, const int6
                "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
         __builtin_trap();
     }
+}
+
+__global__ void plan_cells_kernel(const PlanArgs pa)
+{
+    if (blockIdx.x == 0) plan_cells_body(pa);
+}
+
+// Stage 2a and the plan in ONE launch (small shapes are bound by launches, not by bytes: the backward
+// used to open with a memset, two re-pack kernels and the plan kernel): every workgroup copies its
+// share of loc / attn into the [b, h, level, query, point] order the sort scans and clears its share
+// of the level cursors; the LAST workgroup also plans.  vb_*: bytes per copy (16 / 8 / 4 / 2).
+template <typename V>
+__device__ __forceinline__ void repack_part(const char *__restrict__ src, char *__restrict__ dst, int Nq, int HL,
+                                            int vpc, int64_t total)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // i enumerates the destination: (((b*HL + hl)*Nq + q)*vpc + v)
+        const int v = (int)(i % vpc);
+        int64_t r = i / vpc;
+        const int q = (int)(r % Nq); r /= Nq;
+        const int hl = (int)(r % HL);
+        const int64_t b = r / HL;
+        reinterpret_cast<V *>(dst)[i] = reinterpret_cast<const V *>(src)[((b * Nq + q) * HL + hl) * vpc + v];
+    }
+}
+
+__device__ __forceinline__ void repack_any(const char *src, char *dst, int Nq, int HL, int vb, int vpc, int64_t total)
+{
+    if (vb == 16) repack_part<uint4>(src, dst, Nq, HL, vpc, total);
+    else if (vb == 8) repack_part<uint2>(src, dst, Nq, HL, vpc, total);
+    else if (vb == 4) repack_part<uint32_t>(src, dst, Nq, HL, vpc, total);
+    else repack_part<uint16_t>(src, dst, Nq, HL, vpc, total);
+}
+
+__global__ void __launch_bounds__(256)
+msda_bwd_prepare(const char *__restrict__ loc, char *__restrict__ loc_t, int vb_l, int vpc_l, int64_t total_l,
+                 const char *__restrict__ attn, char *__restrict__ attn_t, int vb_a, int vpc_a, int64_t total_a,
+                 int Nq, int HL, uint32_t *__restrict__ cursor, int64_t cursor_words, const PlanArgs pa)
+{
+    if (pa.shapes != nullptr && blockIdx.x == gridDim.x - 1) plan_cells_body(pa);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cursor_words; i += (int64_t)gridDim.x * 256) cursor[i] = 0u;
+    repack_any(loc, loc_t, Nq, HL, vb_l, vpc_l, total_l);
+    repack_any(attn, attn_t, Nq, HL, vb_a, vpc_a, total_a);
 }
 
 // Exclusive prefix sum over a[0..n) (n <= kMaxTileCells), total left in a[n].
@@ -889,16 +947,26 @@ TileReduceArgs tile_args(const Scratch &sc, const Dims &d)
     return a;
 }
 
+static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, const TileParams &tp)
+{
+    PlanArgs pa;
+    pa.shapes = shapes; pa.start = start; pa.L = d.L; pa.S = d.S; pa.nt_min = tp.nt_min; pa.cap = tp.tiles_bound;
+    pa.samples_per_level = (int64_t)d.Nq * d.P; pa.hdr = sc.hdr; pa.ovf_header = reinterpret_cast<uint32_t *>(sc.ovf);
+    pa.cap_slots = sc.cap_slots; pa.cap_entries = sc.cap_entries; pa.cap_partials = sc.cap_partials;
+    pa.th = sc.th; pa.tile_cap_extra = sc.tile_cap_extra; pa.tile_cap_partials = sc.tile_cap_partials;
+    return pa;
+}
+
 template <typename T, int NV>
-hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, hipStream_t st)
+hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
+                       hipStream_t st)
 {
     const TileParams tp = make_params(d);
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
-    hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, shapes, start, d.L, d.S, tp.nt_min, tp.tiles_bound,
-                       (int64_t)d.Nq * d.P, sc.hdr, reinterpret_cast<uint32_t *>(sc.ovf), sc.cap_slots, sc.cap_entries,
-                       sc.cap_partials, sc.th, sc.tile_cap_extra, sc.tile_cap_partials);
+    if (!planned)
+        hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, plan_args(shapes, start, sc, d, tp));
     hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                        (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                        cell_stride_of(d), tile_args(sc, d));
@@ -906,15 +974,16 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
 }
 
 template <typename T>
-hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, hipStream_t st)
+hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
+                         hipStream_t st)
 {
     const int loc_bytes = d.P * 2 * (int)sizeof(T);
     int nv = 0;
     if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
     switch (nv) {
-        case 1: return launch_sort<T, 1>(shapes, start, sc, d, st);
-        case 2: return launch_sort<T, 2>(shapes, start, sc, d, st);
-        default: return launch_sort<T, 0>(shapes, start, sc, d, st);
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, planned, st);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, planned, st);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, planned, st);
     }
 }
 
@@ -985,25 +1054,57 @@ int64_t bwd_value_block_workspace_bytes(int dtype, const Dims &d)
 // (the workspace starts with the same three pieces as the pixel-stationary layout -- re-packed
 // loc, re-packed attn, level cursors -- so backward_value_prepare serves both)
 
+// Stage 2a for this generation: re-pack + cursors (+ the plan when the level table is at hand), one launch.
+hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *attn, const int64_t *shapes,
+                                        const int64_t *start, void *workspace, const Dims &d, hipStream_t st)
+{
+    if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
+    const int es = dtype == 0 ? 4 : 2;
+    const Scratch sc = carve(workspace, dtype, d);
+    auto gran = [](const void *a, const void *b, int chunk_bytes) {
+        const bool al = (((uintptr_t)a | (uintptr_t)b) % 16) == 0;
+        if (al && chunk_bytes % 16 == 0) return 16;
+        if (al && chunk_bytes % 8 == 0) return 8;
+        if (al && chunk_bytes % 4 == 0) return 4;
+        return 2;
+    };
+    const int cl = d.P * 2 * es, ca = d.P * es;
+    if (ca % 2) return hipErrorInvalidValue;
+    const int vb_l = gran(loc, sc.loc_t, cl), vb_a = gran(attn, sc.attn_t, ca);
+    const int vpc_l = cl / vb_l, vpc_a = ca / vb_a;
+    const int64_t groups = (int64_t)d.B * d.Nq * d.H * d.L;
+    const int64_t total_l = groups * vpc_l, total_a = groups * vpc_a;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total_l + 255) / 256, 256 * 64));
+    PlanArgs pa;
+    pa.shapes = nullptr;
+    if (shapes != nullptr && start != nullptr) pa = plan_args(shapes, start, sc, d, make_params(d));
+    hipLaunchKernelGGL(msda_bwd_prepare, dim3((unsigned)blocks), dim3(256), 0, st,
+                       (const char *)loc, (char *)sc.loc_t, vb_l, vpc_l, total_l,
+                       (const char *)attn, (char *)sc.attn_t, vb_a, vpc_a, total_a,
+                       d.Nq, d.H * d.L, sc.cursor, sc.cursor_bytes / 4, pa);
+    return hipGetLastError();
+}
+
 hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                                     const Dims &d, hipStream_t st)
+                                     const Dims &d, bool planned, hipStream_t st)
 {
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
-        case 0: return dispatch_sort<float>(shapes, start, sc, d, st);
-        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, st);
-        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, st);
+        case 0: return dispatch_sort<float>(shapes, start, sc, d, planned, st);
+        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, planned, st);
+        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, planned, st);
         default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                       const Dims &d, hipStream_t st)
+                                       const Dims &d, bool all_rows_owned, hipStream_t st)
 {
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
-    switch (dtype) {
+    // rows no level owns (only a table the HOST has not vouched for can have them)
+    if (!all_rows_owned) switch (dtype) {
         case 0: launch_zero_uncovered<float>(grad_value, sc, d, st); break;
         case 1: launch_zero_uncovered<half_t>(grad_value, sc, d, st); break;
         case 2: launch_zero_uncovered<bf16_t>(grad_value, sc, d, st); break;

@@ -592,9 +592,16 @@ int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d)
 
 // Stage 2a: re-pack loc/attn into the workspace and clear the per-level cursors.
 hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, void *workspace,
-                                  const Dims &d, hipStream_t st)
+                                  const Dims &d, hipStream_t st,
+                                  const int64_t *shapes, const int64_t *start, bool *planned)
 {
+    if (planned) *planned = false;
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
+    if (bwd_value_block_supported(dtype, d)) {       // one launch, plan included when the table is at hand
+        if (planned) *planned = shapes != nullptr && start != nullptr;
+        return backward_value_block_prepare(dtype, loc, attn, planned ? shapes : nullptr, planned ? start : nullptr,
+                                            workspace, d, st);
+    }
     const int es = dtype == 0 ? 4 : 2;
     const Scratch sc = carve(workspace, dtype, d);
     hipError_t e = hipMemsetAsync(sc.cursor, 0, (size_t)sc.cursor_bytes, st);
@@ -606,11 +613,11 @@ hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, 
 
 // Stage 2b: sort the tap contributions by pixel (prepared workspace -> records + run table).
 hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                               const Dims &d, hipStream_t st)
+                               const Dims &d, hipStream_t st, bool planned)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     if (bwd_value_block_supported(dtype, d))
-        return backward_value_block_sort(dtype, shapes, start, workspace, d, st);
+        return backward_value_block_sort(dtype, shapes, start, workspace, d, planned, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
         case 0: return dispatch_sort<float>(shapes, start, sc, d, st);
@@ -622,11 +629,11 @@ hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *
 
 // Stage 2c: reduce every pixel's run into its grad_value row.
 hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                 const Dims &d, hipStream_t st)
+                                 const Dims &d, hipStream_t st, bool all_rows_owned)
 {
     if (!bwd_value_tiled_supported(dtype, d)) return hipErrorInvalidValue;
     if (bwd_value_block_supported(dtype, d))      // must mirror backward_value_sort
-        return backward_value_block_reduce(dtype, grad_out, grad_value, workspace, d, st);
+        return backward_value_block_reduce(dtype, grad_out, grad_value, workspace, d, all_rows_owned, st);
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
         case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);
@@ -638,20 +645,22 @@ hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_val
 
 hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
                               const void *grad_out, void *grad_value, void *workspace, const Dims &d,
-                              hipStream_t st)
+                              hipStream_t st, bool planned, bool all_rows_owned)
 {
-    const hipError_t e = backward_value_sort(dtype, shapes, start, workspace, d, st);
+    const hipError_t e = backward_value_sort(dtype, shapes, start, workspace, d, st, planned);
     if (e != hipSuccess) return e;
-    return backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
+    return backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, all_rows_owned);
 }
 
 hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
                                 const void *loc, const void *attn, const void *grad_out,
-                                void *grad_value, void *workspace, const Dims &d, hipStream_t st)
+                                void *grad_value, void *workspace, const Dims &d, hipStream_t st,
+                                bool all_rows_owned)
 {
-    const hipError_t e = backward_value_prepare(dtype, loc, attn, workspace, d, st);
+    bool planned = false;
+    const hipError_t e = backward_value_prepare(dtype, loc, attn, workspace, d, st, shapes, start, &planned);
     if (e != hipSuccess) return e;
-    return backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st);
+    return backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st, planned, all_rows_owned);
 }
 
 }  // namespace mmfs

@@ -151,7 +151,7 @@ int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
         if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
         if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
         return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value,
-                                               workspace, d, st);
+                                               workspace, d, st, (flags & MMFS_BWD_CANONICAL_LEVELS) != 0);
     }
     // ---- float-atomic path
     const bool narrow = (dtype == MMFS_F16 || dtype == MMFS_BF16);
@@ -359,12 +359,17 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
                                 d, false, st, dense_taps ? &plan.fine_taps : nullptr);
     if (e == hipSuccess && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
         e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
+    // (the plan rides in the prepare launch only when this very call also sorts; the hybrid path needs
+    // MMFS_BWD_CANONICAL_LEVELS, so every grad_value row has an owner and no zero-fill pass is due)
+    bool planned = false;
+    const bool fuse_plan = (stages & MMFS_HYB_BWD_VALUE_SORT) != 0;
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))
-        e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st);
+        e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st, fuse_plan ? shapes : nullptr,
+                                         fuse_plan ? start : nullptr, &planned);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
-        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st);
+        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, planned);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
-        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st);
+        e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, true);
     return (int)e;
 }
 

@@ -25,28 +25,35 @@ bool bwd_has_vector_path(int dtype, const Dims &d);
 // grad_value (storage dtype) written exactly once.     [msda_bwd_value.hip]
 bool bwd_value_tiled_supported(int dtype, const Dims &d);
 int64_t bwd_value_tiled_workspace_bytes(int dtype, const Dims &d);   // re-packed loc/attn copies
+// shapes / start given to _prepare: the block generation plans in the same launch and *planned says so
+// (pass it on to _sort); all_rows_owned: the HOST vouches that every grad_value row has an owner level
+// (canonical table), so no zero-fill pass is launched.
 hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, void *workspace,
-                                  const Dims &d, hipStream_t st);
+                                  const Dims &d, hipStream_t st,
+                                  const int64_t *shapes = nullptr, const int64_t *start = nullptr, bool *planned = nullptr);
 hipError_t backward_value_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                               const Dims &d, hipStream_t st);
+                               const Dims &d, hipStream_t st, bool planned = false);
 hipError_t backward_value_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                 const Dims &d, hipStream_t st);
+                                 const Dims &d, hipStream_t st, bool all_rows_owned = false);
 
 // Second generation: samples sorted by the cell of their top-left corner, 2x2 pixel blocks as
 // owners (2.25 instead of 4 grad_out row reads per sample).   [msda_bwd_block.hip]
 // backward_value_sort / _reduce route here when it applies (and no level is skipped).
 bool bwd_value_block_supported(int dtype, const Dims &d);
 int64_t bwd_value_block_workspace_bytes(int dtype, const Dims &d);
+hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *attn, const int64_t *shapes,
+                                        const int64_t *start, void *workspace, const Dims &d, hipStream_t st);
 hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                                     const Dims &d, hipStream_t st);
+                                     const Dims &d, bool planned, hipStream_t st);
 hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
-                                       const Dims &d, hipStream_t st);
+                                       const Dims &d, bool all_rows_owned, hipStream_t st);
 hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
                               const void *grad_out, void *grad_value, void *workspace, const Dims &d,
-                              hipStream_t st);
+                              hipStream_t st, bool planned = false, bool all_rows_owned = false);
 hipError_t backward_value_tiled(int dtype, const int64_t *shapes, const int64_t *start,
                                 const void *loc, const void *attn, const void *grad_out,
-                                void *grad_value, void *workspace, const Dims &d, hipStream_t st);
+                                void *grad_value, void *workspace, const Dims &d, hipStream_t st,
+                                bool all_rows_owned = false);
 
 // Hybrid routing of grad_loc / grad_attn: levels of <= 256 pixels as dense MFMA dot products, the rest
 // through the gather kernel restricted to plan.fine_taps.                   [msda_dense.hip]
