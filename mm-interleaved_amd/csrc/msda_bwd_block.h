@@ -11,7 +11,7 @@ namespace blk {
 
 constexpr int kThreads = 1024;          // sort: 16 waves per workgroup
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxTileCells = 4096;     // cells per sort tile (two counter arrays of 16 KiB)
+constexpr int kMaxTileCells = 5120;     // cells per sort tile (two counter arrays of 20 KiB): a 64x64 level (65x65 cells) is ONE tile
 constexpr int kScanUnroll = 4;
 constexpr int kMaxLevels = 128;         // levels the block path takes
 constexpr int kLdsLevels = 32;          // level rows the reduce keeps in LDS (beyond: read from the table)

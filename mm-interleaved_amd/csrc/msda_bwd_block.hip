@@ -111,7 +111,6 @@ struct PlanArgs {
 // The plan: one workgroup's job (its lanes 0-31 clear a row, lane 0 does the serial part).
 __device__ void plan_cells_body(const PlanArgs &pa)
 {
-    const int64_t *__restrict__ shapes = pa.shapes, *__restrict__ start = pa.start;
     const int L = pa.L, S = pa.S, nt_min = pa.nt_min, cap = pa.cap;
     const int64_t samples_per_level = pa.samples_per_level;
     CellHeader *__restrict__ hdr = pa.hdr;
@@ -120,6 +119,13 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     TileHeader *__restrict__ th = pa.th;
     const uint32_t tile_cap_extra = pa.tile_cap_extra, tile_cap_partials = pa.tile_cap_partials;
     if (th != nullptr && threadIdx.x < 32) th->zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    // the level table once, in parallel, into LDS: the serial part below reads every row O(L) times, and a
+    // dependent global load costs microseconds while the rest of the launch streams loc / attn
+    __shared__ int64_t ltab[3 * kMaxLevels];
+    for (int l = threadIdx.x; l < L && l < kMaxLevels; l += blockDim.x) {
+        ltab[3 * l] = pa.shapes[2 * l]; ltab[3 * l + 1] = pa.shapes[2 * l + 1]; ltab[3 * l + 2] = pa.start[l];
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     if (th != nullptr) {
         for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
@@ -133,9 +139,9 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     CTile *tile = tiles_of(hdr, L);
     int n = 0, cbase = 0, bbase = 0, bbase4 = 0;
     for (int l = 0; l < L; ++l) {
-        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        const int Hl = (int)ltab[3 * l], Wl = (int)ltab[3 * l + 1];
         LevelRow r;
-        r.Hl = Hl; r.Wl = Wl; r.lstart = (int)start[l]; r.cbase = cbase; r.bbase = bbase;
+        r.Hl = Hl; r.Wl = Wl; r.lstart = (int)ltab[3 * l + 2]; r.cbase = cbase; r.bbase = bbase;
         r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
         r.bbase4 = bbase4; r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
         if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = r.nbx4 = r.nby4 = 0; lv[l] = r; continue; }
@@ -173,15 +179,15 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     int64_t covered = 0;
     bool bad = false;
     for (int l = 0; l < L; ++l) {
-        const int64_t Hl = shapes[2 * l], Wl = shapes[2 * l + 1], a0 = start[l];
+        const int64_t Hl = ltab[3 * l], Wl = ltab[3 * l + 1], a0 = ltab[3 * l + 2];
         if (Hl < 0 || Wl < 0 || Hl >= 65536 || Wl >= 65536) { bad = true; continue; }
         if (Hl == 0 || Wl == 0) continue;
         const int64_t a1 = a0 + Hl * Wl;
         if (a0 < 0 || a1 > S) bad = true;
         covered += Hl * Wl;
         for (int k = 0; k < l; ++k) {
-            const int64_t b0 = start[k], b1 = b0 + shapes[2 * k] * shapes[2 * k + 1];
-            if (shapes[2 * k] > 0 && shapes[2 * k + 1] > 0 && a0 < b1 && b0 < a1) bad = true;
+            const int64_t b0 = ltab[3 * k + 2], b1 = b0 + ltab[3 * k] * ltab[3 * k + 1];
+            if (ltab[3 * k] > 0 && ltab[3 * k + 1] > 0 && a0 < b1 && b0 < a1) bad = true;
         }
     }
     hdr->pad[0] = (!bad && covered == S) ? 1 : 0;          // canonical in the sense that matters: every row has exactly one owner
@@ -825,7 +831,10 @@ TileParams make_params(const Dims &d)
 {
     TileParams tp;
     const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
-    int64_t nt = std::max<int64_t>(1, (512 + slices - 1) / slices);
+    // every tile of a level scans all of the level's samples (twice), so tiles are only added when there
+    // are too few (b, h, level) slices to give half the CUs a workgroup (measured at the north-star shape,
+    // 256 slices: 1 tile per level 65 us, 2: 71, 3: 77, 4: 91, 6: 140)
+    int64_t nt = std::max<int64_t>(1, (128 + slices - 1) / slices);
     if (const char *e = getenv("MMFS_NT_MIN")) nt = std::max(1, atoi(e));
     tp.nt_min = (int)std::min<int64_t>(nt, 256);
     // cells per level <= 2 * pixels + 2; tiles per level <= 2 * nt_l + 1
