@@ -31,6 +31,8 @@ names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_reduce": "msda_bwd_value_re
          "msda_bwd_vec_atomic": "msda_bwd_atomic",
          # second-generation grad_value kernels answer to the same stage names in bench.py
          "msda_bwd_block_reduce": "msda_bwd_value_reduce", "msda_bwd_cell_sort": "msda_bwd_value_sort",
+         # third generation: matrix-core tile reduce; the fused re-pack + plan launch
+         "msda_bwd_tile_reduce": "msda_bwd_value_reduce", "msda_bwd_prepare": "msda_bwd_value_prepare",
          "msda_taps_coarse": "msda_bwd_taps_coarse"}
 traffic = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
@@ -46,6 +48,11 @@ for line in open(os.path.join(src, "pmc_summary.txt")):
 path = os.path.join(dst, "pmc_traffic.json")
 allw = json.load(open(path)) if os.path.exists(path) else {}
 allw[workload] = traffic
-allw["_source"] = f"profiles/{prefix}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)"
+src_note = f"profiles/{prefix}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)"
+prov = allw.get("_source")
+if not isinstance(prov, dict):          # (older files: one string for every workload)
+    prov = {w: prov for w in allw if w != "_source"} if prov else {}
+prov[workload] = src_note
+allw["_source"] = prov
 json.dump(allw, open(path, "w"), indent=1)
 print(json.dumps(allw, indent=1))

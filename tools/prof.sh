@@ -17,7 +17,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $out/pmc$i -- python $root/bench.py $args > $out/pmc$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $grp --output-format csv -d $out/pmc$i -- python $root/bench.py $args > $out/pmc$i.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os
