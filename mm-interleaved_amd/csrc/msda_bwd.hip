@@ -201,7 +201,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const int rq = r / kc_pad, kk = r - rq * kc_pad;
             int row[4] = {-1, -1, -1, -1};
             float fx = 0.f, fy = 0.f, a = 0.f;
-            uint32_t wh = 0;
+            uint32_t lv = 0;                              // the sample's level: its extents are looked up when the sample is finished
             const int sq = bc.q0 + rq;
             if (kk < kc && sq < d.Nq) {
                 const int ks = k0 + kk;
@@ -218,7 +218,12 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 if (!(d.lazy_attn && !SCATTER && a == 0.f)) {
                     row[0] = t.row[0]; row[1] = t.row[1]; row[2] = t.row[2]; row[3] = t.row[3];
                 }
-                wh = ((uint32_t)Hl << 16) | (uint32_t)Wl;
+                lv = (uint32_t)l;
+            }
+            if (!BUF) {
+                // flat addresses have no descriptor to stop a row that a malformed level table puts past S
+#pragma unroll
+                for (int c = 0; c < 4; ++c) row[c] = row[c] < d.S ? row[c] : -1;
             }
             if (PRE) {
 #pragma unroll
@@ -227,7 +232,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             }
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
             dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
-            dst[1] = make_uint4(__float_as_uint(fx), __float_as_uint(fy), __float_as_uint(a), wh);
+            dst[1] = make_uint4(__float_as_uint(fx), __float_as_uint(fy), __float_as_uint(a), lv);
         }
         __syncthreads();
         // ---- gather + reduce + scatter
@@ -283,7 +288,9 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     }
                     const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
                     const float a = __uint_as_float(meta[u].z);
-                    const float Wl = (float)(meta[u].w & 0xffffu), Hl = (float)(meta[u].w >> 16);
+                    int Hli, Wli, lst;                  // (exact for any extent: nothing is packed into 16 bits here)
+                    levels.get(shapes, start, (int)meta[u].w, Hli, Wli, lst);
+                    const float Wl = (float)Wli, Hl = (float)Hli;
                     const float gy = 1.f - fy, gx = 1.f - fx;
                     const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
                     if (lig == 0) {

@@ -105,6 +105,11 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 rec.w[2] = t.fy * gx * a; rec.w[3] = t.fy * t.fx * a;
             }
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
+            if (!BUF) {
+                // flat addresses have no descriptor to stop a row that a malformed level table puts past S
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rec.row[c] = rec.row[c] < d.S ? rec.row[c] : -1;
+            }
             if (BUF) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)      // pixel row -> byte offset in the slab, or "outside"

@@ -272,6 +272,21 @@ def test_unverified_gapped_table_is_served_by_the_sorted_backward(dtype):
     assert not got[1][:, ~owned].any()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_levels_wider_than_65535_take_the_atomic_path_with_exact_extents(dtype):
+    """The sorted backward packs level extents into 16 bits; a registered table with a wider level is
+    routed to the float-atomic path, whose records carry the level index and look the extents up
+    (round 1 packed (Hl << 16) | Wl there too: silently wrong grad_loc for such a level)."""
+    x = make_inputs(1, 2, 32, 40, 4, [(1, 70000), (3, 3)], seed=9, dtype=dtype)
+    got, want = run_hip(x, dtype, register=True), run_oracle(x)
+    # x = loc * 70000 - 0.5 in fp32 (the reference's arithmetic too) is good to 2^-7 of a pixel, and whether the
+    # compiler contracts it into one FMA moves it by that much: the bilinear weights carry ~1 % noise against
+    # the fp64 oracle.  A truncated extent would be off by 70000 / 4464 = 15.7x in grad_loc.
+    for n, g, w in zip(("out", "grad_value", "grad_loc", "grad_attn"), got, want):
+        scale = max(1.0, float(np.abs(w).max()))
+        assert max_abs(g, w) <= 3e-2 * scale, f"70000-wide level {n}: {max_abs(g, w):.3e} vs scale {scale:.3g}"
+
+
 def test_skewed_locations_overflow_the_tile_lists():
     """All queries sample the same spot: one pixel receives Nq*P records, far more than a
     workgroup's LDS list holds -> exercises the per-pixel query-range rounds."""
