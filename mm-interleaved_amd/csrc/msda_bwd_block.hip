@@ -277,9 +277,12 @@ enum ScanMode { kCount = 0, kScatter = 1 };
 // One sample against the tile: if its top-left cell is in the tile
 //   kCount  : off[cell] += 1
 //   kScatter: list[off[cell] + cur[cell]++] = {q, y, x, attention}
-template <int MODE>
-__device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q, const CTile &tl, int tw,
-                                             uint32_t *off, uint32_t *cur, uint4 *__restrict__ list)
+// COMPACT (16-bit storage feeding the matrix-core reduce, Nq <= 65536): the record is the sample's INPUT
+// words, 8 bytes instead of 16 -- {query | weight bits << 16, x bits | y bits << 16} -- and the reduce
+// redoes y = ly * H - 0.5 itself: half the record traffic of a step (67 MB written + read at the north star).
+template <int MODE, bool COMPACT>
+__device__ __forceinline__ void visit_sample(float lx, float ly, float a, uint32_t xy_bits, uint32_t a_bits, int q,
+                                             const CTile &tl, int tw, uint32_t *off, uint32_t *cur, void *__restrict__ list)
 {
     const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
     const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
@@ -294,23 +297,33 @@ __device__ __forceinline__ void visit_sample(float lx, float ly, float a, int q,
         atomicAdd(&off[pl], 1u);
     } else {
         const uint32_t slot = off[pl] + atomicAdd(&cur[pl], 1u);
-        list[slot] = make_uint4((uint32_t)q, __float_as_uint(y), __float_as_uint(x), __float_as_uint(a));
+        if (COMPACT) reinterpret_cast<uint2 *>(list)[slot] = make_uint2((uint32_t)q | (a_bits << 16), xy_bits);
+        else reinterpret_cast<uint4 *>(list)[slot] = make_uint4((uint32_t)q, __float_as_uint(y), __float_as_uint(x), __float_as_uint(a));
     }
 }
 
-template <typename T, int MODE, int NV>
+template <typename T> __device__ __forceinline__ uint32_t raw_bits(T v)
+{
+    if (sizeof(T) == 2) return (uint32_t)__builtin_bit_cast(uint16_t, v);
+    return 0u;                                   // (fp32 storage never takes the compact format)
+}
+template <> __device__ __forceinline__ uint32_t raw_bits<float>(float) { return 0u; }
+
+template <typename T, int MODE, int NV, bool COMPACT>
 __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T *__restrict__ attn,
                                              const Dims &d, const CTile &tl, int b, int h,
-                                             uint32_t *off, uint32_t *cur, uint4 *__restrict__ list)
+                                             uint32_t *off, uint32_t *cur, void *__restrict__ list)
 {
     const int tw = tl.xb - tl.xa;
     const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
     if (NV == 0) {
         for (int q = (int)threadIdx.x; q < d.Nq; q += kThreads) {
             const int64_t s0 = s_first + (int64_t)q * d.P;
-            for (int p = 0; p < d.P; ++p)
-                visit_sample<MODE>(to_f32(loc[2 * (s0 + p)]), to_f32(loc[2 * (s0 + p) + 1]),
-                                   to_f32(attn[s0 + p]), q, tl, tw, off, cur, list);
+            for (int p = 0; p < d.P; ++p) {
+                const T lx = loc[2 * (s0 + p)], ly = loc[2 * (s0 + p) + 1], a = attn[s0 + p];
+                visit_sample<MODE, COMPACT>(to_f32(lx), to_f32(ly), to_f32(a), raw_bits(lx) | (raw_bits(ly) << 16), raw_bits(a),
+                                            q, tl, tw, off, cur, list);
+            }
         }
         return;
     }
@@ -339,9 +352,13 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
                 float l[VEC], a[VEC];
                 V::unpack(lraw[u][v], l);
                 V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
+                const uint32_t lw[4] = {lraw[u][v].x, lraw[u][v].y, lraw[u][v].z, lraw[u][v].w};
+                const uint32_t aw[2] = {araw[u][v].x, araw[u][v].y};
 #pragma unroll
                 for (int i = 0; i < VEC / 2; ++i)
-                    visit_sample<MODE>(l[2 * i], l[2 * i + 1], a[i], q, tl, tw, off, cur, list);
+                    // (16-bit storage: sample i's (x, y) pair is word i of the vector, its weight half-word i)
+                    visit_sample<MODE, COMPACT>(l[2 * i], l[2 * i + 1], a[i], lw[i & 3], (aw[(i >> 1) & 1] >> (16 * (i & 1))) & 0xffffu,
+                                                q, tl, tw, off, cur, list);
             }
         }
     }
@@ -353,7 +370,7 @@ struct TileParams {
 };
 
 // ---------------------------------------------------------------- kernel A: sort by cell
-template <typename T, int NV>
+template <typename T, int NV, bool COMPACT>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
@@ -378,7 +395,7 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
 
     for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
     __syncthreads();
-    scan_samples<T, kCount, NV>(loc, attn, d, tl, b, h, off, cur, nullptr);
+    scan_samples<T, kCount, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
     block_exclusive_scan(off, ncell, wave_tot);
     const uint32_t total = off[ncell];
@@ -387,7 +404,8 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
     if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
     __syncthreads();
     const int64_t base = slot * ((int64_t)d.Nq * d.P) + region;
-    if (total) scan_samples<T, kScatter, NV>(loc, attn, d, tl, b, h, off, cur, records + base);
+    if (total) scan_samples<T, kScatter, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur,
+                                                      COMPACT ? (void *)(reinterpret_cast<uint2 *>(records) + base) : (void *)(records + base));
     uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + tl.cbase;
     for (int p = tid; p < ncell; p += kThreads) {
         const int cg = (tl.ya + p / tw) * (tl.Wl + 1) + tl.xa + p % tw;
@@ -976,9 +994,15 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
     if (!planned)
         hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, plan_args(shapes, start, sc, d, tp));
-    hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
-                       (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                       cell_stride_of(d), tile_args(sc, d));
+    // the matrix-core reduce takes 8-byte records (its support test bounds Nq by 65536), the others 16-byte ones
+    if (sizeof(T) == 2 && sc.th != nullptr)
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, sizeof(T) == 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
+                           cell_stride_of(d), tile_args(sc, d));
+    else
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
+                           cell_stride_of(d), tile_args(sc, d));
     return hipGetLastError();
 }
 

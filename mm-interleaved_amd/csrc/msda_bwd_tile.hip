@@ -16,7 +16,9 @@
 //     2.25) and walks the cell-sorted records of the 5x5 cells whose footprints touch it: five
 //     contiguous runs of the record list (the sort's tiles are whole cell rows), seen as one list;
 //   * 16 records per step.  Their grad_out rows travel global -> LDS by DMA (global_load_lds, no
-//     registers, no vector instructions; 3 steps in flight), their records too (5 slots);
+//     registers, no vector instructions), their records too.  A record is 8 bytes: the sample's INPUT
+//     words {query | weight bits << 16, x bits | y bits << 16} as the sort found them (16-bit storage,
+//     Nq <= 65536); the pixel coordinates are recomputed here with the sort's own expression;
 //   * the rows are the B operand of v_mfma_f32_32x32x16_{bf16,f16} (K = record, N = channel), read
 //     out of LDS with the transposing ds_read_b64_tr_b16; the 16-byte chunks of a row are stored
 //     XOR-swizzled (the swizzle is applied to the DMA's SOURCE address, the LDS image of a DMA is
@@ -94,7 +96,7 @@ template <int D> struct TileGeom {
     static constexpr int RP = 256 / RB;            // rows per 256 bytes (one pass over the 64 banks)
     static constexpr int SLOT = kKS * RB;          // bytes of a row slot
     static constexpr int ROWS_BYTES = kStages * SLOT > 16 * (RB + 16) ? kStages * SLOT : 16 * (RB + 16);   // (the epilogue stages the block's rows here, pitch RB + 16)
-    static constexpr int REC_BYTES = kRecSlots * kRecBatch * 16;
+    static constexpr int REC_BYTES = kRecSlots * kRecBatch * 8;       // per batch: 64 first words, then 64 second words
     static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES + 1024;
     // chunk swizzle of row r (row index inside its slot): the 4 rows a 16-lane group of a transposing
     // read touches together must land in different banks
@@ -130,6 +132,10 @@ __device__ __forceinline__ void dma16(const void *src, void *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 16, 0, 0);
 }
+__device__ __forceinline__ void dma4(const void *src, void *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 4, 0, 0);
+}
 // 16 bytes per lane from rsrc + voffset to lds_dst + lane * 16; an offset past the descriptor's
 // extent moves nothing (or zeros): what a record past the end of a list asks for
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, void *lds_dst)
@@ -150,8 +156,8 @@ struct ItemArgs { int b, h, part; bool whole, partial_out; uint32_t pidx; };
 // Every request is issued whether or not the list reaches that far (a request past the end moves no
 // data), so the number of requests in flight at each wait is a compile-time constant:
 //   ... | rows(4j+1) recs(j+1) | rows(4j+2) | rows(4j+3) | rows(4j+4) | rows(4j+5) recs(j+2) | ...
-//   step 4j+1 needs rows(4j+1): issued after it: recs(j+1) -> vmcnt(1);  step 4j+3 needs rows(4j+3) and
-//   recs(j+1) (for rows(4j+4)) -> vmcnt(0);  the others: vmcnt(0).
+//   step 4j+1 needs rows(4j+1): issued after it: recs(j+1), two requests -> vmcnt(2);  step 4j+3 needs
+//   rows(4j+3) and recs(j+1) (for rows(4j+4)) -> vmcnt(0);  the others: vmcnt(0).
 template <typename T, int D>
 __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__restrict__ grad_value,
                                           const TileReduceArgs &a, const Dims &d, const TileDesc &td, const ItemArgs &it,
@@ -218,17 +224,20 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
                         if (e >= pre[k]) del = td.first[k] - pre[k];
                     idx = (uint32_t)(e + del);
                 }
-                dma16(a.records + idx, recs + (j & 1) * (kRecBatch * 16));
+                const uint32_t *rw = reinterpret_cast<const uint32_t *>(a.records) + 2 * (size_t)idx;
+                unsigned char *slot = recs + (j & 1) * (kRecBatch * 8);
+                dma4(rw, slot);                                              // {query | weight << 16} of the batch's 64 records
+                dma4(rw + 1, slot + kRecBatch * 4);                          // {x | y << 16}
             }
         };
         // grad_out rows of step k = 4j + S -> row slot S % 2
         auto issue_rows = [&](int j, auto stage) {
             constexpr int S = decltype(stage)::value;
-            const uint32_t *rq = reinterpret_cast<const uint32_t *>(recs + (j & 1) * (kRecBatch * 16) + S * (kKS * 16));
+            const uint32_t *rq = reinterpret_cast<const uint32_t *>(recs + (j & 1) * (kRecBatch * 8) + S * (kKS * 4));
             const int rel0 = kKS * (4 * j + S);
             uint32_t q[G::NR];
 #pragma unroll
-            for (int u = 0; u < G::NR; ++u) q[u] = rq[(u * G::RPI + rsel) * 4];
+            for (int u = 0; u < G::NR; ++u) q[u] = rq[u * G::RPI + rsel] & 0xffffu;
 #pragma unroll
             for (int u = 0; u < G::NR; ++u) {
                 const int rr = u * G::RPI + rsel;
@@ -242,8 +251,11 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             // ---- weight tile: 16 records x 4 corners, one weight per lane
             reinterpret_cast<uint4 *>(atile)[lane] = make_uint4(0u, 0u, 0u, 0u);
             {
-                const uint4 rec = reinterpret_cast<const uint4 *>(recs + (j & 1) * (kRecBatch * 16) + S * (kKS * 16))[wr];
-                const float y = __uint_as_float(rec.y), x = __uint_as_float(rec.z), av = __uint_as_float(rec.w);
+                const uint32_t *rb = reinterpret_cast<const uint32_t *>(recs + (j & 1) * (kRecBatch * 8)) + S * kKS + wr;
+                const uint32_t w0 = rb[0], w1 = rb[kRecBatch];
+                const float av = to_f32(__builtin_bit_cast(T, (uint16_t)(w0 >> 16)));
+                const float lx = to_f32(__builtin_bit_cast(T, (uint16_t)(w1 & 0xffffu))), ly = to_f32(__builtin_bit_cast(T, (uint16_t)(w1 >> 16)));
+                const float y = ly * (float)Hl - 0.5f, x = lx * (float)Wl - 0.5f;          // (the sort's expression, bit for bit)
                 const float yf = floorf(y), xf = floorf(x);
                 const float fy = y - yf, fx = x - xf;
                 const int iy = (int)yf + iy0, ix = (int)xf + ix0;
@@ -288,7 +300,7 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             issue_rows(j, S1{});                                  // rows(4j + 1)
             issue_records(j + 1);
             if (4 * j < nks) multiply(j, S0{});
-            MMFS_WAIT_VM(1);
+            MMFS_WAIT_VM(2);
             issue_rows(j, S2{});
             if (4 * j + 1 < nks) multiply(j, S1{});
             MMFS_WAIT_VM(0);
@@ -480,7 +492,7 @@ bool tile_reduce_supported(int dtype, const Dims &d)
     // the rows are fetched through a buffer descriptor over one (b, h) slice: 31-bit byte offsets
     const int64_t es = 2;
     if ((int64_t)d.Nq * d.H * d.D * es > kMaxSlabBytes) return false;
-    if (d.Nq >= (1 << 24) || (int64_t)d.H * d.D * es >= (1 << 24)) return false;       // 24-bit multiply for the row offset
+    if (d.Nq > 65536 || (int64_t)d.H * d.D * es >= (1 << 24)) return false;            // 16-bit query index in the records; 24-bit multiply for the row offset
     return true;
 }
 
