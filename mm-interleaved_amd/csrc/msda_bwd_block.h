@@ -61,7 +61,10 @@ __device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { r
 // CellHeader::n_blocks4.  A block's list of records is cut into work items of kTileChunk records;
 // a block of more than one item leaves fp32 partial tiles that a last small kernel adds up.
 constexpr int kTB = 4;
-constexpr int kTileChunk = 1024;
+#ifndef MMFS_TILE_CHUNK
+#define MMFS_TILE_CHUNK 1024
+#endif
+constexpr int kTileChunk = MMFS_TILE_CHUNK;
 constexpr int kTileLanes = 8;             // queue lanes of the extra work items (one per XCD, keyed by h % 8)
 
 struct TileHeader {

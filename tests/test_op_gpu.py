@@ -287,6 +287,13 @@ def test_levels_wider_than_65535_take_the_atomic_path_with_exact_extents(dtype):
         assert max_abs(g, w) <= 3e-2 * scale, f"70000-wide level {n}: {max_abs(g, w):.3e} vs scale {scale:.3g}"
 
 
+def test_more_than_65536_queries_leave_the_compact_records():
+    """The matrix-core reduce keeps the query index in 16 bits of its 8-byte records; with more queries the
+    2x2-block reduce (16-byte records) takes over for 16-bit storage too."""
+    x = make_inputs(1, 1, 32, 66000, 4, [(6, 5), (3, 4)], seed=12, dtype=torch.bfloat16)
+    check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "Nq = 66000")
+
+
 def test_skewed_locations_overflow_the_tile_lists():
     """All queries sample the same spot: one pixel receives Nq*P records, far more than a
     workgroup's LDS list holds -> exercises the per-pixel query-range rounds."""
