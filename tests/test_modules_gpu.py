@@ -325,3 +325,88 @@ def test_graphed_mmfs_net_replays_the_eager_schedule():
         assert torch.equal(got[0], want[0])
         assert all(torch.equal(a, b) for a, b in zip(got[1], want[1]))
         assert float((want[0] - mid2).abs().max()) > 1e-4       # the blocks did contribute
+
+
+# ---------------------------------------------------------------- real geometries (BASELINE configs 3 and 4)
+# The goldens above are reduced shapes (the reference itself has to run on the CPU to make them).  These two
+# run the REAL geometries -- Vicuna-7B's MMFS layer, the 13-block MMFSNet at 512 px -- on the GPU in fp32
+# against the very same module (same weights) evaluated on the CPU in fp64 with the oracle in the op's place.
+@pytest.fixture()
+def oracle_op_cpu(monkeypatch):
+    """CPU copies of the modules call the C oracle; CUDA tensors keep the HIP op."""
+    from oracle.msda_oracle import OracleMSDAFunction
+    import mmfs_amd.modules.mmfs as m1
+    real = m1.MSDeformAttnFunction
+
+    class Routed:
+        @staticmethod
+        def apply(value, *a):
+            return (real if value.is_cuda else OracleMSDAFunction).apply(value, *a)
+    monkeypatch.setattr(m1, "MSDeformAttnFunction", Routed)
+
+
+def test_llm_layer_at_vicuna_7b_geometry(oracle_op_cpu):
+    """BASELINE config 3: hidden 4096, 16 MMFS heads of 64, P = 8, levels 32^2 / 16^2 / 8^2 of one image
+    (modeling_llama_mmfs.py:311-367); 128 tokens, B = 2.  out and both input gradients, fp32 vs fp64."""
+    import copy
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    cfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, rms_norm_eps=1e-6,
+                                max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = LlamaMMFSAttention(cfg, 0).double()
+    with torch.no_grad():
+        ref.gate.fill_(0.7)
+        ref.attn.sampling_offsets.weight.normal_(0, 0.02)
+        ref.attn.attention_weights.weight.normal_(0, 0.02)
+    gpu = copy.deepcopy(ref).float().to(DEV)
+    B, Lq, n, S = 2, 128, 1, 32 * 32 + 16 * 16 + 8 * 8
+    g = torch.Generator().manual_seed(4)
+    hidden = torch.randn(B, Lq, 4096, generator=g, dtype=torch.float64)
+    feats = torch.randn(B, n, S, 1024, generator=g, dtype=torch.float64)
+    mask = torch.ones(B, Lq, n, dtype=torch.float64)
+    grad = torch.randn(B, Lq, 4096, generator=g, dtype=torch.float64)
+    res = []
+    for mod, dev, dt in ((ref, "cpu", torch.float64), (gpu, DEV, torch.float32)):
+        h = hidden.detach().clone().to(dev, dt).requires_grad_(True)
+        f = feats.detach().clone().to(dev, dt).requires_grad_(True)
+        out = mod(h, f, mask.to(dev, dt))
+        out.backward(grad.to(dev, dt))
+        res.append((out.detach().double().cpu(), h.grad.double().cpu(), f.grad.double().cpu()))
+    for name, a, b in zip(("out", "grad_hidden", "grad_feats"), res[1], res[0]):
+        err = float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+        assert err <= 1e-4, f"{name}: {err:.3e}"
+
+
+def test_mmfs_net_at_512px_geometry(oracle_op_cpu):
+    """BASELINE config 4: the 13-block MMFSNet of the 512-px UNet (sd_mmfs.py:230-272: 320 / 640 / 1280 / 1280
+    channels at 64^2 ... 8^2, 16 heads of 64, P = 8, four levels of one image), B = 1, one denoising step,
+    fp32 on the GPU vs fp64 on the CPU."""
+    import copy
+    from mmfs_amd.blocks import MMFSNet
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = MMFSNet(input_channel=1024, block_out_channels=[320, 640, 1280, 1280], layers_per_block=2,
+                      n_levels=4, n_points=8, gradient_checkpointing=False, spatial_shapes=[64, 32, 16, 8]).double()
+    with torch.no_grad():
+        for blk in ref._blocks():
+            blk.conv.weight.normal_(0, 0.02)
+            blk.mmfs.sampling_offsets.weight.normal_(0, 0.01)
+            blk.mmfs.attention_weights.weight.normal_(0, 0.02)
+    ref.eval()
+    gpu = copy.deepcopy(ref).float().to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    geom = list(zip([320] * 4 + [640] * 3 + [1280] * 5, [64] * 3 + [32] * 3 + [16] * 3 + [8] * 3))
+    res_in = [torch.randn(1, c, s, s, generator=g, dtype=torch.float64) for c, s in geom]
+    mid = torch.randn(1, 1280, 8, 8, generator=g, dtype=torch.float64)
+    feats = [torch.randn(1, 1, 1024, s, s, generator=g, dtype=torch.float64) for s in (64, 32, 16, 8)]
+    mask = torch.ones(1, 1, dtype=torch.long)
+    outs = []
+    for mod, dev, dt in ((ref, "cpu", torch.float64), (gpu, DEV, torch.float32)):
+        with torch.no_grad():
+            m, rr = mod(mid.to(dev, dt), [r.to(dev, dt) for r in res_in], [f.to(dev, dt) for f in feats], mask.to(dev))
+        outs.append([m.double().cpu()] + [r.double().cpu() for r in rr])
+    assert len(outs[0]) == 13
+    for i, (a, b) in enumerate(zip(outs[1], outs[0])):
+        err = float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+        assert err <= 1e-4, f"output {i}: {err:.3e}"
