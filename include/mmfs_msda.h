@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 5   /* 5: + MMFS_BWD_DEVICE_CHECKED_LEVELS; the dense forward / grad_value products
+#define MMFS_MSDA_ABI_VERSION 6   /* 6: + mmfs_sample_forward (plan -> sampler in one kernel)
+                                   * 5: + MMFS_BWD_DEVICE_CHECKED_LEVELS; the dense forward / grad_value products
                                    *    (mmfs_msda_forward_hybrid*, MMFS_BWD_DENSE_VALUE) are gone: measured slower than
                                    *    the row-gather forward and the matrix-core tile reduce on every shipped geometry */
 
@@ -276,6 +277,22 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
                        float *d_off_q, float *d_att_q, float *d_off_tab, float *d_att_tab,
                        int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
                        int64_t Lr, int64_t Nr, void *stream);
+
+/*
+ * The plan feeding the sampler (second half): mmfs_plan_forward followed by
+ * mmfs_msda_forward as ONE kernel -- the locations and weights [N, Lq, H, n*L, P(, 2)] never exist in
+ * memory.  Same inputs as mmfs_plan_forward plus the op's value / level tables (``shapes`` / ``start``
+ * have n*L rows), same arithmetic (the plan's numbers are rounded to the storage type before use), so
+ * ``out`` [N, Lq, H*D] is bit-identical to the two calls.  ``sink`` [N, Lq, H] fp32 may be NULL.
+ * Forward only -- the backward needs loc / attn as tensors (a training step keeps the two calls).
+ * MMFS_E_UNSUPPORTED (use the two calls) for P = 16, head rows that are not 16 bytes x 2^k (k <= 6), value
+ * slabs of 2 GiB or more.
+ */
+int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                        const void *off_q, const void *att_q, const void *off_tab, const void *att_tab,
+                        const int64_t *relpos, const float *ref, const float *ratios, void *out, float *sink,
+                        int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                        int64_t M, int64_t Lr, int64_t Nr, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-image feature bank: MMFS's ``input_flatten`` built in one pass.

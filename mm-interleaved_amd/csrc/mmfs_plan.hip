@@ -266,6 +266,210 @@ plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_
     }
 }
 
+
+// ---------------------------------------------------------------- plan -> sampler, one kernel (forward / inference)
+// SURVEY.md 8f N1, second half: the sampling plan feeds the sampler directly -- the locations and weights
+// [N, Lq, H, n*L, P(, 2)] never exist in HBM.  This is msda_fwd_vec (csrc/msda_fwd.hip) with its staging
+// replaced: instead of reading loc / attn it evaluates the plan for its 256 / LPI queries of one (sample,
+// head) from the heads' outputs and table rows, in the SAME arithmetic as plan_forward_kernel (same lane
+// groups, same reduction order, results rounded to the storage type before use), so the output is bit-
+// identical to plan_forward + ms_deform_attn_forward.  Forward only: the backward needs loc / attn as
+// tensors (the sort scans them, the plan backward reads the weights), so training keeps the two kernels.
+constexpr int kSampleRecs = 512;        // tap records staged per chunk (as msda_fwd_vec)
+constexpr int kSampleUnroll = 2;
+
+__device__ __forceinline__ float rgroup_max(float v, int G)
+{
+    for (int o = G / 2; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float rgroup_add(float v, int G)
+{
+    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int LPI, int P>
+__global__ void __launch_bounds__(kThreads)
+mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                const T *__restrict__ off_q, const T *__restrict__ att_q,
+                const T *__restrict__ off_tab, const T *__restrict__ att_tab,
+                const int64_t *__restrict__ relpos, const float *__restrict__ ref, const float *__restrict__ ratios,
+                T *__restrict__ out, float *__restrict__ sink, const Dims d, const PlanDims pd, const int G)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int QPB = kThreads / LPI;
+    constexpr int KC = (kSampleRecs / QPB) > P ? (kSampleRecs / QPB) : P;      // samples per query per chunk: whole rows of P
+    static_assert(KC % P == 0 && KC % kSampleUnroll == 0, "chunks hold whole rows of P points");
+    constexpr int STRIDE = 2 * KC + 1;
+    __shared__ uint4 lds[QPB * STRIDE];
+    __shared__ LevelLds levels;
+    __shared__ float2 stat[QPB];                          // softmax max and 1 / sum per query of the tile
+    __shared__ float4 plan[QPB * KC];                     // {x, y, weight} of the chunk's samples
+
+    const BlockCoord bc = block_coord(d, QPB);
+    const int tid = threadIdx.x;
+    const int qi = tid / LPI, lig = tid % LPI;
+    const int q = bc.q0 + qi;
+    const bool q_ok = q < d.Nq;
+    const int nL = d.L;                                   // = n * levels per image
+    const int64_t HD = (int64_t)d.H * d.D;
+    const T *slab = value + ((int64_t)bc.b * d.S) * HD + (int64_t)bc.h * d.D;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
+    levels.load(shapes, start, nL, tid, kThreads);
+    const float sink_logit = -logf((float)nL);
+
+    // logits of row gl (= image k, level l) of the item (bc.b, sq, bc.h), as plan_forward_kernel forms them
+    auto row_logits = [&](int sq, int gl, float (&lg)[P]) {
+        const int64_t it = ((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h;
+        const int k = gl / pd.L, l = gl % pd.L;
+        const int64_t r = relpos[((int64_t)bc.b * pd.Lr + (pd.Lr == 1 ? 0 : sq)) * pd.n + k];
+        float a[P], t[P];
+        load_row<T, P>(att_q + (it * pd.L + l) * P, a);
+        load_row<T, P>(att_tab + ((r * pd.H + bc.h) * pd.L + l) * P, t);
+        const float pen = r == 0 ? -10000.f : 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) lg[p] = a[p] + t[p] + pen;
+        return r;
+    };
+
+    // ---- softmax statistics of the tile's queries (lane group of G per query, like the plan kernel)
+    for (int base = 0; base < QPB * G; base += kThreads) {
+        if (base + (tid & ~63) >= QPB * G) continue;      // (whole waves only: the groups shuffle)
+        const int s = base + tid, rq = s / G, gl = s % G;
+        const int sq = bc.q0 + rq;
+        const bool item_ok = rq < QPB && sq < d.Nq;
+        const bool act = item_ok && gl < nL;
+        float lg[P];
+        float m = sink_logit;
+        if (act) {
+            row_logits(sq, gl, lg);
+#pragma unroll
+            for (int p = 0; p < P; ++p) m = fmaxf(m, lg[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; ++p) lg[p] = -INFINITY;
+        }
+        m = rgroup_max(m, G);
+        float z = act ? __expf(sink_logit - m) : 0.f;
+        const float my_sink = z;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { lg[p] = __expf(lg[p] - m); z += lg[p]; }
+        z = rgroup_add(z, G);
+        const float inv = 1.f / z;
+        const float sink_sum = rgroup_add(my_sink, G) * inv;
+        if (item_ok && gl == 0) {
+            stat[rq] = make_float2(m, inv);
+            if (sink != nullptr) sink[((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h] = sink_sum;
+        }
+    }
+    __syncthreads();
+
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+    for (int k0 = 0; k0 < d.K; k0 += KC) {
+        const int kc = min(KC, d.K - k0);                 // a multiple of P (and of the unroll)
+        const int rows = kc / P;
+        if (k0 > 0) __syncthreads();
+        // ---- stage, step 1: one lane per (query, row): the row's P weights and locations, rounded to the
+        // storage type like the tensors of the two-kernel path, parked in LDS
+        for (int s = tid; s < QPB * rows; s += kThreads) {
+            const int rq = s / rows, rr = s - rq * rows, gl = k0 / P + rr;
+            const int sq = bc.q0 + rq;
+            float4 *dst = &plan[rq * KC + rr * P];
+            if (sq >= d.Nq) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) dst[p] = make_float4(-8.f, -8.f, 0.f, 0.f);      // outside every map, weight 0
+                continue;
+            }
+            float lg[P];
+            const int64_t r = row_logits(sq, gl, lg);
+            const float2 st2 = stat[rq];
+            const int64_t it = ((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h;
+            const int l = gl % pd.L;
+            float oq[2 * P], ot[2 * P];
+            load_row<T, 2 * P>(off_q + it * 2 * P, oq);
+            load_row<T, 2 * P>(off_tab + (r * pd.H + bc.h) * 2 * P, ot);
+            const float rx = ref[((int64_t)(pd.Nr == 1 ? 0 : bc.b) * pd.Lq + sq) * 2];
+            const float ry = ref[((int64_t)(pd.Nr == 1 ? 0 : bc.b) * pd.Lq + sq) * 2 + 1];
+            int Hl, Wl, lstart;
+            levels.get(shapes, start, gl, Hl, Wl, lstart);
+            const float sx = ratios[l] / (float)Wl, sy = ratios[l] / (float)Hl;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float wgt = __expf(lg[p] - st2.x);
+                wgt *= st2.y;
+                dst[p] = make_float4(to_f32((T)(rx + (oq[2 * p] + ot[2 * p]) * sx)),
+                                     to_f32((T)(ry + (oq[2 * p + 1] + ot[2 * p + 1]) * sy)), to_f32((T)wgt), 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- stage, step 2: one lane per sample: location -> tap record (as msda_fwd_vec does from its tensors)
+        for (int r = tid; r < QPB * kc; r += kThreads) {
+            const int rq = r / kc, kk = r - rq * kc, gl = (k0 + kk) / P;
+            const float4 pl = plan[rq * KC + kk];
+            const float a = pl.z;
+            int Hl, Wl, lstart;
+            levels.get(shapes, start, gl, Hl, Wl, lstart);
+            const Tap<float> t = locate<float>(pl.x, pl.y, Hl, Wl, lstart);
+            const float gy = 1.f - t.fy, gx = 1.f - t.fx;
+            uint32_t off[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                off[c] = (a != 0.f && t.row[c] >= 0) ? (uint32_t)t.row[c] * row_bytes : kOobOffset;
+            uint4 *dst = &lds[rq * STRIDE + 2 * kk];
+            dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
+            dst[1] = make_uint4(__float_as_uint(gy * gx * a), __float_as_uint(gy * t.fx * a),
+                                __float_as_uint(t.fy * gx * a), __float_as_uint(t.fy * t.fx * a));
+        }
+        __syncthreads();
+        // ---- gather (as msda_fwd_vec: 2 taps = 8 row reads in flight per lane, whole-wave skip of zero weights)
+        if (q_ok) {
+            const uint4 *recs = &lds[qi * STRIDE];
+            for (int kk = 0; kk < kc; kk += kSampleUnroll) {
+                uint4 raw[kSampleUnroll][4];
+                float w[kSampleUnroll][4];
+                uint4 rrs[kSampleUnroll];
+                uint32_t any_w = 0u;
+#pragma unroll
+                for (int u = 0; u < kSampleUnroll; ++u) {
+                    rrs[u] = recs[2 * (kk + u)];
+                    const uint4 ww = recs[2 * (kk + u) + 1];
+                    any_w |= (ww.x | ww.y | ww.z | ww.w) << 1;
+                    w[u][0] = __uint_as_float(ww.x); w[u][1] = __uint_as_float(ww.y);
+                    w[u][2] = __uint_as_float(ww.z); w[u][3] = __uint_as_float(ww.w);
+                }
+                if (__builtin_amdgcn_ballot_w64(any_w != 0u) == 0ull) continue;
+#pragma unroll
+                for (int u = 0; u < kSampleUnroll; ++u) {
+                    raw[u][0] = buffer_load16(rsrc, rrs[u].x + lane_off);
+                    raw[u][1] = buffer_load16(rsrc, rrs[u].y + lane_off);
+                    raw[u][2] = buffer_load16(rsrc, rrs[u].z + lane_off);
+                    raw[u][3] = buffer_load16(rsrc, rrs[u].w + lane_off);
+                }
+#pragma unroll
+                for (int u = 0; u < kSampleUnroll; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v[VEC];
+                        V::unpack(raw[u][c], v);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w[u][c], v[i], acc[i]);
+                    }
+            }
+        }
+    }
+    if (q_ok) {
+        T *o = out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + lig * VEC;
+        *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+    }
+}
+
 int esize(int dtype) { return dtype == MMFS_F32 ? 4 : (dtype == MMFS_F16 || dtype == MMFS_BF16) ? 2 : 0; }
 
 int check_dims(int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M, int64_t Lr,
@@ -374,6 +578,68 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
     if (dtype == MMFS_F32) return by_p(float());
     if (dtype == MMFS_F16) return by_p(half_t());
     return by_p(bf16_t());
+}
+
+int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                        const void *off_q, const void *att_q, const void *off_tab, const void *att_tab,
+                        const int64_t *relpos, const float *ref, const float *ratios, void *out, float *sink,
+                        int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                        int64_t M, int64_t Lr, int64_t Nr, void *stream)
+{
+    using namespace mmfs;
+    const int es = esize(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    PlanDims pd;
+    const int rc = check_dims(N, Lq, H, L, P, n, M, Lr, Nr, &pd);
+    if (rc) return rc;
+    if (S < 0 || D <= 0 || S > 0x7ffffffdLL || H * D > 0x7fffffffLL) return MMFS_E_DIMS;
+    if (N * Lq * H == 0) return MMFS_OK;
+    if (P == 16 || S == 0) return MMFS_E_UNSUPPORTED;                       // (P = 16: the two-kernel path)
+    const int vec = 16 / es;
+    if (D % vec) return MMFS_E_UNSUPPORTED;
+    const int lpi = (int)(D / vec);
+    if (lpi < 1 || lpi > 64 || (lpi & (lpi - 1))) return MMFS_E_UNSUPPORTED;
+    if (S * H * D * (int64_t)es > kMaxSlabBytes) return MMFS_E_UNSUPPORTED;        // buffer-descriptor rows only
+    if (!value || !shapes || !start || !off_q || !att_q || !off_tab || !att_tab || !relpos || !ref || !ratios || !out)
+        return MMFS_E_NULLPTR;
+    if (((uintptr_t)value | (uintptr_t)out) % 16) return MMFS_E_ALIGN;
+    Dims d;
+    d.B = (int)N; d.S = (int)S; d.H = (int)H; d.D = (int)D; d.L = (int)(n * L); d.Nq = (int)Lq; d.P = (int)P;
+    d.K = d.L * d.P; d.lazy_attn = 0; d.blocks4 = 0;
+    int G = 4;
+    while (G < d.L) G *= 2;                                                 // the plan kernel's lane-group width
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto tag_t, auto tag_lpi, auto tag_p) {
+        typedef decltype(tag_t) T;
+        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value;
+        constexpr int QPB = kThreads / LPI;
+        Dims dd = d;
+        dd.q_tiles = (d.Nq + QPB - 1) / QPB;
+        const int64_t blocks = (int64_t)d.B * dd.q_tiles * d.H;
+        if (blocks > 0x7fffffffLL) return (int)MMFS_E_DIMS;
+        hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           (const T *)value, shapes, start, (const T *)off_q, (const T *)att_q,
+                           (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, dd, pd, G);
+        return (int)hipGetLastError();
+    };
+    auto by_p = [&](auto tag_t, auto tag_lpi) {
+        if (P == 4) return go(tag_t, tag_lpi, std::integral_constant<int, 4>());
+        return go(tag_t, tag_lpi, std::integral_constant<int, 8>());
+    };
+    auto by_lpi = [&](auto tag_t) {
+        switch (lpi) {
+            case 1: return by_p(tag_t, std::integral_constant<int, 1>());
+            case 2: return by_p(tag_t, std::integral_constant<int, 2>());
+            case 4: return by_p(tag_t, std::integral_constant<int, 4>());
+            case 8: return by_p(tag_t, std::integral_constant<int, 8>());
+            case 16: return by_p(tag_t, std::integral_constant<int, 16>());
+            case 32: return by_p(tag_t, std::integral_constant<int, 32>());
+            default: return by_p(tag_t, std::integral_constant<int, 64>());
+        }
+    };
+    if (dtype == MMFS_F32) return by_lpi(float());
+    if (dtype == MMFS_F16) return by_lpi(half_t());
+    return by_lpi(bf16_t());
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ _lib.mmfs_plan_forward.restype = _int
 _lib.mmfs_plan_forward.argtypes = [_int] + [_vp] * 11 + [_i64] * 9 + [_vp]
 _lib.mmfs_plan_backward.restype = _int
 _lib.mmfs_plan_backward.argtypes = [_int] + [_vp] * 12 + [_i64] * 9 + [_vp]
+_lib.mmfs_sample_forward.restype = _int
+_lib.mmfs_sample_forward.argtypes = [_int] + [_vp] * 12 + [_i64] * 11 + [_vp]
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -84,3 +86,36 @@ class MMFSPlanFunction(Function):
         s0, s1, s2, s3 = ctx.shapes_in
         return (d_off_q.to(dt).reshape(s0), d_att_q.to(dt).reshape(s1), d_off_tab.to(dt).reshape(s2),
                 d_att_tab.to(dt).reshape(s3), None, None, None, None, None, None, None)
+
+
+def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P):
+    """Plan -> sampler in ONE kernel (``mmfs_sample_forward`` in include/mmfs_msda.h):
+    the locations / weights [N, Lq, H, n*L, P(, 2)] are never written.  Inference only (no autograd graph);
+    bit-identical to ``MMFSPlanFunction`` + ``MSDeformAttnFunction``.  value [N, S, H, D]; the other
+    arguments as for ``MMFSPlanFunction``.  Returns (out [N, Lq, H*D], sink [N, Lq, H] fp32), or None when
+    the shape is outside the fused kernel's range (the caller then runs the two kernels)."""
+    dt = value.dtype
+    if dt not in _CODE or off_q.dtype != dt or not value.is_cuda:
+        return None
+    N, S, Hh, D = value.shape
+    Lq = off_q.shape[1]
+    n, Lr, Nr, M = relpos.shape[-1], relpos.shape[1], ref.shape[0], off_tab.shape[0]
+    value = value.contiguous()
+    off_q, att_q = off_q.contiguous(), att_q.to(dt).contiguous()
+    off_tab, att_tab = off_tab.to(dt).contiguous(), att_tab.to(dt).contiguous()
+    relpos, ref, ratios = relpos.contiguous(), ref.float().contiguous(), ratios.float().contiguous()
+    assert shapes.dtype == torch.int64 and shapes.is_contiguous() and shapes.shape == (n * L, 2)
+    assert start.dtype == torch.int64 and start.is_contiguous() and start.numel() == n * L
+    dev = value.device
+    out = torch.empty((N, Lq, Hh * D), dtype=dt, device=dev)
+    sink = torch.empty((N, Lq, Hh), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = MSDA._launch("mmfs_sample_fwd", dev, _lib.mmfs_sample_forward, _CODE[dt], value.data_ptr(),
+                          shapes.data_ptr(), start.data_ptr(), off_q.data_ptr(), att_q.data_ptr(),
+                          off_tab.data_ptr(), att_tab.data_ptr(), relpos.data_ptr(), ref.data_ptr(),
+                          ratios.data_ptr(), out.data_ptr(), sink.data_ptr(),
+                          N, S, Lq, Hh, D, L, P, n, M, Lr, Nr, MSDA._stream(dev))
+    if rc == MSDA._E_UNSUPPORTED:
+        return None
+    MSDA._check(rc, "mmfs_sample_forward")
+    return out, sink

@@ -20,13 +20,14 @@ What is organised differently from the reference forward, with identical mathema
 * the sink ("ignore") slot is handled as the constant logit it is (mmfs.py:225).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
-from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported
+from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
 from ..levels import host_shapes
 
 
@@ -65,6 +66,8 @@ class MMFS(nn.Module):
         self.offset_init_magnitude = offset_init_magnitude
         self.max_num_image_per_seq = max_num_image_per_seq
         self.fused_plan = True                    # use csrc/mmfs_plan.hip when it applies
+        # inference: plan -> sampler in one kernel, no loc / attn tensors (MMFS_FUSED_SAMPLER=0: measurements)
+        self.fused_sampler = os.environ.get("MMFS_FUSED_SAMPLER", "1") != "0"
         d_inner = int(d_model * ratio)
         self.d_inner = d_inner
 
@@ -108,7 +111,7 @@ class MMFS(nn.Module):
             relpos = relpos[:, -1:, :]
         return relpos
 
-    def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images):
+    def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images, sampler=None):
         """Everything between the query and the op: sampling locations [N,Lq,H,n*L,P,2],
         attention weights over the real points [N,Lq,H,n*L,P], and the summed sink weights
         [N,Lq,H] (mmfs.py:154-163, 174-265)."""
@@ -133,9 +136,16 @@ class MMFS(nn.Module):
             dq = self.attention_weights.in_features
             aw_w = self.attention_weights.weight.view(H, L, P + 1, dq)[:, :, :P].reshape(H * L * P, dq)
             aw_b = self.attention_weights.bias.view(H, L, P + 1)[:, :, :P].reshape(H * L * P)
-            loc, attn, sink_sum = MMFSPlanFunction.apply(
-                self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, F.linear(table, aw_w), relpos,
-                reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
+            heads = (self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, F.linear(table, aw_w), relpos,
+                     reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
+            if sampler is not None:
+                # inference: the plan feeds the sampler inside one kernel (``sampler`` = (value, level starts));
+                # returns the op's output and the sink weights instead of loc / attn
+                res = mmfs_sample_forward(sampler[0], input_spatial_shapes, sampler[1], *heads[:4], relpos,
+                                          heads[5], self.scale_ratios, H, L, P)
+                if res is not None:
+                    return None, res[0], res[1]
+            loc, attn, sink_sum = MMFSPlanFunction.apply(*heads)
             return loc, attn, sink_sum
 
         # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
@@ -194,12 +204,20 @@ class MMFS(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.reshape(N, n * hw, self.n_heads, self.d_inner // self.n_heads).contiguous()
 
-        loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes,
-                                               attention_mask, n)
-        # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
-        # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
-        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                         loc.to(value.dtype).contiguous(), attn, self.im2col_step, True)
+        # no autograd graph wanted (sampling / decoding): plan and sampler run as one kernel, the locations
+        # and weights never exist as tensors (csrc/mmfs_plan.hip, mmfs_sample_fwd); bit-identical output
+        fuse = (self.fused_sampler and self.fused_plan and value.is_cuda and query.dtype == value.dtype
+                and not (torch.is_grad_enabled() and (query.requires_grad or value.requires_grad
+                                                      or any(p.requires_grad for p in self.parameters()))))
+        loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes, attention_mask, n,
+                                               sampler=(value, input_level_start_index) if fuse else None)
+        if loc is None:
+            out = attn                            # (the fused kernel's result)
+        else:
+            # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
+            # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
+            out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                             loc.to(value.dtype).contiguous(), attn, self.im2col_step, True)
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)

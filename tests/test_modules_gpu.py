@@ -410,3 +410,48 @@ def test_mmfs_net_at_512px_geometry(oracle_op_cpu):
     for i, (a, b) in enumerate(zip(outs[1], outs[0])):
         err = float((a - b).abs().max() / max(1.0, float(b.abs().max())))
         assert err <= 1e-4, f"output {i}: {err:.3e}"
+
+
+# ---------------------------------------------------------------- plan -> sampler in one kernel (N1)
+@pytest.mark.parametrize("name", P48_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype):
+    """Inference (no autograd graph): ``mmfs_sample_forward`` evaluates the plan inside the sampler's staging,
+    loc / attn are never written.  Same arithmetic as the two kernels -> the module output must be EQUAL, bit
+    for bit; in fp32 it is also held to the reference's golden.  The run must really take the fused kernel."""
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.modules import MMFS
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = load_params(MMFS(**cfg), z).to(DEV, dtype).eval()
+    args = (T(z["query"], dtype), T(z["reference_points"], dtype), T(z["feat"], dtype), T(z["spatial_shapes"], None),
+            T(z["level_start_index"], None), None, T(z["attention_mask"], torch.float32))
+    outs = {}
+    for fused in (True, False):
+        m.fused_sampler = fused
+        log = []
+        MSDA._event_log = log
+        try:
+            with torch.no_grad():
+                outs[fused] = m(*args)
+        finally:
+            MSDA._event_log = None
+        names = {n for n, _, _ in log}
+        assert ("mmfs_sample_fwd" in names) == fused and ("mmfs_plan_fwd" in names) == (not fused), names
+    assert torch.equal(outs[True], outs[False])
+    if dtype == torch.float32:
+        assert rel_err(outs[True], z["out"]) <= 2e-5
+
+
+def test_fused_sampler_is_not_taken_when_a_gradient_is_wanted():
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.modules import MMFS
+    z = load_golden("mmfs_p8_llm_n3")
+    log = []
+    MSDA._event_log = log
+    try:
+        run_mmfs(z, torch.float32)                 # forward + backward
+    finally:
+        MSDA._event_log = None
+    assert not any(n == "mmfs_sample_fwd" for n, _, _ in log)
