@@ -157,3 +157,22 @@ def test_hybrid_workspace_queries_are_host_only():
     assert bw(0, hs, hst, *dims, CANON | TAPS) == 0        # fp32 storage
     big = np.array([[64, 64], [32, 32]], dtype=np.int64)   # no level small enough
     assert bw(2, big.ctypes.data, np.array([0, 4096], dtype=np.int64).ctypes.data, 8, 5120, 8, 128, 2, 4096, 4, CANON | TAPS) == 0
+
+
+def test_sample_forward_argument_errors_return_before_any_launch():
+    """mmfs_sample_forward (plan -> sampler in one kernel): dtype / dims / unsupported shapes / NULL pointers are
+    answered on the host."""
+    lib = ctypes.CDLL(LIB)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    f = lib.mmfs_sample_forward
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] + [vp] * 12 + [i64] * 11 + [vp]
+    null = [None] * 12
+    #            N  S     Lq  H  D   L  P  n  M  Lr Nr
+    dims = [2, 1344, 16, 16, 64, 3, 8, 1, 8, 1, 1]
+    assert f(9, *null, *dims, None) == -1                               # dtype
+    assert f(2, *null, *(dims[:6] + [5] + dims[7:]), None) == -5        # P = 5: unsupported by the plan
+    assert f(2, *null, *(dims[:6] + [16] + dims[7:]), None) == -5       # P = 16: two-kernel path
+    assert f(2, *null, *(dims[:4] + [24] + dims[5:]), None) == -5       # D = 24: no 16-byte vector rows
+    assert f(2, *null, *dims, None) == -3                               # NULL tensors
+    assert f(2, *null, *([0] + dims[1:]), None) == 0                    # empty batch
