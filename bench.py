@@ -366,7 +366,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-    ex = exchange_step(device, rank, world, dist) if dist is not None else None
+    ex = None
+    if dist is not None:
+        try:
+            ex = exchange_step(device, rank, world, dist)
+        except Exception as e:                      # the headline number does not depend on this step
+            ex = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if ex is not None:
             res["exchange"] = ex
