@@ -286,27 +286,24 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 #pragma unroll
                         for (int c = 0; c < 4; ++c) dot[c] = group_sum<LPI>(dot[c]);
                     }
-                    const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
-                    const float a = __uint_as_float(meta[u].z);
-                    int Hli, Wli, lst;                  // (exact for any extent: nothing is packed into 16 bits here)
-                    levels.get(shapes, start, (int)meta[u].w, Hli, Wli, lst);
-                    const float Wl = (float)Wli, Hl = (float)Hli;
-                    const float gy = 1.f - fy, gx = 1.f - fx;
-                    const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
-                    if (lig == 0) {
-                        const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
-                        const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
-                        const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
-                        recs[2 * (kk + u)] = make_uint4(__float_as_uint(ga), __float_as_uint(Wl * dw * a),
-                                                        __float_as_uint(Hl * dh * a), 0u);
-                    }
+                    // the four dots go back through the record; the per-sample algebra is done in the store
+                    // pass below, one lane per SAMPLE (here only one lane in LPI would do it, per instruction)
+                    if (lig == 0)
+                        recs[2 * (kk + u)] = make_uint4(__float_as_uint(dot[0]), __float_as_uint(dot[1]),
+                                                        __float_as_uint(dot[2]), __float_as_uint(dot[3]));
+                    if (SCATTER) {
+                        const float fx = __uint_as_float(meta[u].x), fy = __uint_as_float(meta[u].y);
+                        const float a = __uint_as_float(meta[u].z);
+                        const float gy = 1.f - fy, gx = 1.f - fx;
+                        const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (SCATTER && rows[u][c] >= 0) {
-                            const float coef = w[c] * a;
-                            float *p = gvbase + (int64_t)rows[u][c] * HD;
+                        for (int c = 0; c < 4; ++c) {
+                            if (rows[u][c] >= 0) {
+                                const float coef = w[c] * a;
+                                float *p = gvbase + (int64_t)rows[u][c] * HD;
 #pragma unroll
-                            for (int j = 0; j < VEC; ++j) atomic_add(p + j * LPI, coef * gat[j]);
+                                for (int j = 0; j < VEC; ++j) atomic_add(p + j * LPI, coef * gat[j]);
+                            }
                         }
                     }
                 }
@@ -318,12 +315,21 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const int rq = r / kc, kk = r - rq * kc;
             const int sq = bc.q0 + rq;
             if (sq >= d.Nq) continue;
-            const uint4 res = lds[rq * STRIDE + 2 * kk];
+            const uint4 res = lds[rq * STRIDE + 2 * kk], meta = lds[rq * STRIDE + 2 * kk + 1];
             const int ks = k0 + kk;
             const int k = all_levels ? ks : (int)sel_idx[ks / d.P] * d.P + ks % d.P;
             const int64_t s = (((int64_t)bc.b * d.Nq + sq) * d.H + bc.h) * d.K + k;
-            grad_attn[s] = (T)__uint_as_float(res.x);
-            store_xy(grad_loc, s, pair_ok, __uint_as_float(res.y), __uint_as_float(res.z));
+            // per-sample algebra of the reference (cuh:119-161) on the four corner dots
+            const float d0 = __uint_as_float(res.x), d1 = __uint_as_float(res.y), d2 = __uint_as_float(res.z), d3 = __uint_as_float(res.w);
+            const float fx = __uint_as_float(meta.x), fy = __uint_as_float(meta.y), a = __uint_as_float(meta.z);
+            int Hli, Wli, lst;                          // (exact for any extent: nothing is packed into 16 bits here)
+            levels.get(shapes, start, (int)meta.w, Hli, Wli, lst);
+            const float gy = 1.f - fy, gx = 1.f - fx;
+            const float ga = (gy * gx) * d0 + (gy * fx) * d1 + (fy * gx) * d2 + (fy * fx) * d3;
+            const float dw = gy * (d1 - d0) + fy * (d3 - d2);
+            const float dh = gx * (d2 - d0) + fx * (d3 - d1);
+            grad_attn[s] = (T)ga;
+            store_xy(grad_loc, s, pair_ok, (float)Wli * dw * a, (float)Hli * dh * a);
         }
     }
 }
