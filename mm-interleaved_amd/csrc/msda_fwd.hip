@@ -51,9 +51,16 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int STRIDE = 2 * KC + 1;            // uint4 units; +1 breaks the bank alignment
     __shared__ uint4 lds[QPB * STRIDE];
     __shared__ LevelLds levels;
+    // taps of the chunk that weigh something for at least one query of a wave: bit kk of the wave's word
+    // (set while staging; the gather walks the set bits, so a tap nobody needs is never issued and the walk
+    // has a counted trip -- the shape the compiler's wait-count pass pipelines cleanly)
+    constexpr bool kPipe = BUF && KC <= 64;
+    constexpr int QPW = 64 / LPI > 0 ? 64 / LPI : 1;       // queries per wave
+    __shared__ unsigned long long live[kThreads / 64];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
+    if (kPipe && tid < kThreads / 64) live[tid] = 0ull;
     levels.load(shapes, start, d.L, tid, kThreads);
     const bool pair_ok = ((uintptr_t)loc & (2 * sizeof(T) - 1)) == 0;
     __syncthreads();
@@ -118,8 +125,62 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             dst[0] = make_uint4(rec.row[0], rec.row[1], rec.row[2], rec.row[3]);
             dst[1] = make_uint4(__float_as_uint(rec.w[0]), __float_as_uint(rec.w[1]),
                                 __float_as_uint(rec.w[2]), __float_as_uint(rec.w[3]));
+            if (kPipe) {
+                const uint32_t any_w = (__float_as_uint(rec.w[0]) | __float_as_uint(rec.w[1]) |
+                                        __float_as_uint(rec.w[2]) | __float_as_uint(rec.w[3])) << 1;   // (-0 is zero too)
+                if (any_w != 0u) atomicOr(&live[rq / QPW], 1ull << kk);
+            }
         }
         __syncthreads();
+        if (kPipe) {
+            // ---- gather, software-pipelined: the 4 row reads of the next live tap are in flight while the
+            // current one is multiplied (4..8 reads in flight per lane)
+            const int wv = tid >> 6;
+            const unsigned long long mraw = live[wv];
+            unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mraw >> 32)) << 32) |
+                                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mraw);
+            if ((tid & 63) == 0) live[wv] = 0ull;                 // (mine; the next chunk's staging sets it after the barrier)
+            const uint4 *recs = &lds[qi * STRIDE];
+            uint4 rawA[4], rawB[4], wA, wB;
+            auto issue = [&](uint4 (&raw)[4], uint4 &ww) {
+                const int kk = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint4 rr = recs[2 * kk];
+                ww = recs[2 * kk + 1];
+                raw[0] = buffer_load16(rsrc, rr.x + lane_off);
+                raw[1] = buffer_load16(rsrc, rr.y + lane_off);
+                raw[2] = buffer_load16(rsrc, rr.z + lane_off);
+                raw[3] = buffer_load16(rsrc, rr.w + lane_off);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto consume = [&](const uint4 (&raw)[4], const uint4 &ww) {
+                const float w4[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v[VEC];
+                    V::unpack(raw[c], v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w4[c], v[i], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) asm volatile("" : "+v"(acc[i]));     // the sums are due HERE, not after the next reads
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int n_live = __builtin_popcountll(m);
+            if (n_live & 1) { issue(rawA, wA); consume(rawA, wA); }
+            if (n_live >= 2) {
+                issue(rawA, wA);
+                for (int i = 2; i < n_live - 1; i += 2) {
+                    issue(rawB, wB);
+                    consume(rawA, wA);
+                    issue(rawA, wA);
+                    consume(rawB, wB);
+                }
+                issue(rawB, wB);
+                consume(rawA, wA);
+                consume(rawB, wB);
+            }
+        } else
         // ---- gather: kUnroll taps (4*kUnroll row reads) in flight per lane
         if (q_ok) {
             const uint4 *recs = &lds[qi * STRIDE];
