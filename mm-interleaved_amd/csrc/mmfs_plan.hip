@@ -307,6 +307,9 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     __shared__ LevelLds levels;
     __shared__ float2 stat[QPB];                          // softmax max and 1 / sum per query of the tile
     __shared__ float4 plan[QPB * KC];                     // {x, y, weight} of the chunk's samples
+    constexpr bool kPipe = KC <= 64;                      // live-tap mask + pipelined walk, as in msda_fwd_vec
+    constexpr int QPW = 64 / LPI > 0 ? 64 / LPI : 1;
+    __shared__ unsigned long long live[kThreads / 64];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
@@ -320,6 +323,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const uint32_t lane_off = (uint32_t)(lig * 16);
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
     levels.load(shapes, start, nL, tid, kThreads);
+    if (kPipe && tid < kThreads / 64) live[tid] = 0ull;
     const float sink_logit = -logf((float)nL);
 
     // logits of row gl (= image k, level l) of the item (bc.b, sq, bc.h), as plan_forward_kernel forms them
@@ -423,11 +427,60 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             for (int c = 0; c < 4; ++c)
                 off[c] = (a != 0.f && t.row[c] >= 0) ? (uint32_t)t.row[c] * row_bytes : kOobOffset;
             uint4 *dst = &lds[rq * STRIDE + 2 * kk];
+            const uint4 ww = make_uint4(__float_as_uint(gy * gx * a), __float_as_uint(gy * t.fx * a),
+                                        __float_as_uint(t.fy * gx * a), __float_as_uint(t.fy * t.fx * a));
             dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
-            dst[1] = make_uint4(__float_as_uint(gy * gx * a), __float_as_uint(gy * t.fx * a),
-                                __float_as_uint(t.fy * gx * a), __float_as_uint(t.fy * t.fx * a));
+            dst[1] = ww;
+            if (kPipe && ((ww.x | ww.y | ww.z | ww.w) << 1) != 0u) atomicOr(&live[rq / QPW], 1ull << kk);
         }
         __syncthreads();
+        if (kPipe) {
+            const int wv = tid >> 6;
+            const unsigned long long mraw = live[wv];
+            unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mraw >> 32)) << 32) |
+                                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mraw);
+            if ((tid & 63) == 0) live[wv] = 0ull;
+            const uint4 *recs = &lds[qi * STRIDE];
+            uint4 rawA[4], rawB[4], wA, wB;
+            auto issue = [&](uint4 (&raw)[4], uint4 &wq) {
+                const int kk = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint4 rr = recs[2 * kk];
+                wq = recs[2 * kk + 1];
+                raw[0] = buffer_load16(rsrc, rr.x + lane_off);
+                raw[1] = buffer_load16(rsrc, rr.y + lane_off);
+                raw[2] = buffer_load16(rsrc, rr.z + lane_off);
+                raw[3] = buffer_load16(rsrc, rr.w + lane_off);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto consume = [&](const uint4 (&raw)[4], const uint4 &wq) {
+                const float w4[4] = {__uint_as_float(wq.x), __uint_as_float(wq.y), __uint_as_float(wq.z), __uint_as_float(wq.w)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v[VEC];
+                    V::unpack(raw[c], v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w4[c], v[i], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) asm volatile("" : "+v"(acc[i]));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int n_live = __builtin_popcountll(m);
+            if (n_live & 1) { issue(rawA, wA); consume(rawA, wA); }
+            if (n_live >= 2) {
+                issue(rawA, wA);
+                for (int i = 2; i < n_live - 1; i += 2) {
+                    issue(rawB, wB);
+                    consume(rawA, wA);
+                    issue(rawA, wA);
+                    consume(rawB, wB);
+                }
+                issue(rawB, wB);
+                consume(rawA, wA);
+                consume(rawB, wB);
+            }
+        } else
         // ---- gather (as msda_fwd_vec: 2 taps = 8 row reads in flight per lane, whole-wave skip of zero weights)
         if (q_ok) {
             const uint4 *recs = &lds[qi * STRIDE];
