@@ -396,6 +396,12 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             }
         }
     }
+#ifdef MMFS_PROFILE_TILE
+    {   // epilogue clocks and counts by kind of item: whole blocks / parts that leave a partial tile
+        const unsigned long long tn = __builtin_readcyclecounter();
+        if (it.partial_out) { tprof_t[6] += tn - tprof_c; tprof_t[7] += 1; } else { tprof_t[11] += tn - tprof_c; }
+    }
+#endif
     TPROF(5);                                                     // epilogue issued
     TPROF_FLUSH();
 }

@@ -33,3 +33,6 @@ print("items per call %.0f, rounds per item %.2f, steps per item %.2f" % (v[8] /
 for i, nm in enumerate(names):
     print("  %-28s %8.0f clk per item" % (nm, v[i] / items))
 print("  total %.0f clk per item" % (sum(v[:6]) / items))
+npart = max(v[7], 1)
+print("  epilogue of the %.0f items per call that leave a partial tile: %.0f clk each; of the %.0f whole blocks: %.0f clk each"
+      % (v[7] / n, v[6] / npart, (v[8] - v[7]) / n, v[11] / max(v[8] - v[7], 1)))
