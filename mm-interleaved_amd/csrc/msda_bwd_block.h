@@ -30,6 +30,7 @@ struct LevelRow {
     int bbase, nbx, nby, split;         // first (virtual) block index, blocks per row / column, lane groups per block
     int cap;                            // records of a block's list walked in place before the rest is queued
     int bbase4, nbx4, nby4;             // matrix-core reduce: first 4x4 block of the level, blocks per row / column
+    int band;                           // cell rows per sort tile when the level's tiles are whole rows, else 0
 };
 constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
 #ifndef MMFS_BLK_H
@@ -45,8 +46,8 @@ static_assert(kNPX % 4 == 0, "block weights travel as 16-byte vectors");
 
 struct CellHeader {
     int n_tiles, n_blocks, n_cells, L;
-    int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce); pad[0]: every row has exactly one owner level
-};
+    int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce); pad[0]: every row has exactly one owner level;
+};                                      // pad[1]: levels cut into more than one sort tile (their seams' blocks are planned by the slice's last workgroup)
 
 // workspace table: CellHeader | LevelRow[L] | CTile[cap]
 __device__ __host__ inline LevelRow *level_rows(CellHeader *h) { return reinterpret_cast<LevelRow *>(h + 1); }
@@ -102,11 +103,135 @@ struct TileReduceArgs {
 constexpr uint32_t kVoidPart = 0xffffffffu;
 
 #ifdef __HIPCC__
-// The blocks of one (b, h) slice: descriptor (record runs, position) and, from the length of the list,
-// the number of work items; the extra ones are queued (one queue lane per XCD, keyed by h like every
-// other kernel's head -> XCD affinity).  Run by the LAST sort workgroup of the slice (the cell table
-// it reads was written by the slice's sort workgroups, which share an XCD and so an L2): thread `tid`
-// of `nthreads` takes blocks tid, tid + nthreads, ...
+// A block's descriptor is complete but for its work items: from the length n of its list, the number of
+// items; the extra ones are queued (one queue lane per XCD, keyed by h like every other kernel's head ->
+// XCD affinity).
+__device__ inline void queue_block(const TileReduceArgs &a, const Dims &d, int64_t bh, int blk, TileDesc &td, int64_t n)
+{
+    const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
+    if (parts > 1) {
+        const int ql = (int)(bh % d.H) % kTileLanes;
+        const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
+        const uint32_t eb = atomicAdd(&a.th->n_extra[ql], parts - 1);
+        if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
+            td.parts = parts; td.pbase = pb;
+            for (uint32_t p = 1; p < parts; ++p) {
+                TileItem ti;
+                ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = p; ti.pidx = pb + p;
+                a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+            }
+        } else if (eb < a.th->cap_extra) {
+            // reserved queue entries that cannot be used must read as "nothing to do"
+            for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
+                TileItem ti;
+                ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = kVoidPart; ti.pidx = 0;
+                a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+            }
+        }
+    }
+    a.tdesc[bh * a.blocks_bound + blk] = td;
+}
+
+// A block whose five cell rows lie inside ONE sort tile of whole rows is planned by that tile's workgroup,
+// straight from its prefix sums in LDS (plan_tile_blocks); the others -- the seams between the bands of a
+// level cut into several tiles, and every block of a level whose tiles are not whole rows -- by the slice's
+// last workgroup from the cell table (plan_slice_blocks).
+__device__ __forceinline__ bool block_is_tile_local(const LevelRow &lr, int by)
+{
+    return lr.band > 0 && (kTB * by) / lr.band == min(kTB * by + kTB, lr.Hl) / lr.band;
+}
+
+// The blocks of tile `tl` (whole cell rows [ya, yb) of level row `lr`) that are local to it.  off[]: the tile's
+// exclusive prefix sums (off[ncell] = total), base: the tile's first record.  The cells of a row that touch a
+// block are one contiguous run, so a run's length is a difference of two prefix sums.
+// In two halves: plan_tile_begin stores the descriptors and ASKS for the queue places of the blocks that need
+// several work items (two returning device atomics, microseconds under the sort's store traffic);
+// plan_tile_finish, called after the workgroup has moved its records, takes the answers.
+struct PendingBlock { int blk; uint32_t parts, pb, eb; };          // blk < 0: nothing pending
+__device__ __forceinline__ int tile_local_blocks(const CTile &tl, const LevelRow &lr, int *by_lo)
+{
+    *by_lo = (tl.ya + kTB - 1) / kTB;
+    int by_hi = *by_lo;                                             // (exclusive)
+    while (by_hi < lr.nby4 && min(kTB * by_hi + kTB, lr.Hl) < tl.yb) ++by_hi;
+    return (by_hi - *by_lo) * lr.nbx4;
+}
+__device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTile &tl, const LevelRow &lr, int by, int bx,
+                                                        const uint32_t *off, int64_t base)
+{
+    const int tw = tl.Wl + 1;
+    int64_t n = 0;
+#pragma unroll
+    for (int r = 0; r <= kTB; ++r) {
+        const int cy = kTB * by + r;
+        td.first[r] = 0; td.cnt[r] = 0;
+        if (cy <= lr.Hl) {
+            const int p0 = (cy - tl.ya) * tw + kTB * bx, p1 = (cy - tl.ya) * tw + min(kTB * bx + kTB + 1, tw);
+            td.first[r] = (int)(uint32_t)(base + off[p0]);
+            td.cnt[r] = (int)(off[p1] - off[p0]);
+            n += td.cnt[r];
+        }
+    }
+    td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
+    td.lstart = lr.lstart;
+    td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
+    td.parts = 1; td.pbase = 0; td.arrived = 0;
+    return n;
+}
+__device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Dims &d, int64_t bh, const CTile &tl, const LevelRow &lr,
+                                               const uint32_t *off, int64_t base, int tid, int nthreads)
+{
+    PendingBlock pd;
+    pd.blk = -1; pd.parts = 0; pd.pb = 0; pd.eb = 0;
+    int by_lo;
+    const int nloc = tile_local_blocks(tl, lr, &by_lo);
+    // (a tile of <= kMaxTileCells cells has fewer local blocks than the workgroup has threads; were it otherwise,
+    // the rest is planned in one piece)
+    for (int i = tid + nthreads; i < nloc; i += nthreads) {
+        const int by = by_lo + i / lr.nbx4, bx = i % lr.nbx4;
+        TileDesc td;
+        const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
+        queue_block(a, d, bh, lr.bbase4 + by * lr.nbx4 + bx, td, n);
+    }
+    if (tid >= nloc) return pd;
+    const int by = by_lo + tid / lr.nbx4, bx = tid % lr.nbx4;
+    const int blk = lr.bbase4 + by * lr.nbx4 + bx;
+    TileDesc td;
+    const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
+    a.tdesc[bh * a.blocks_bound + blk] = td;
+    const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
+    if (parts > 1) {
+        pd.blk = blk; pd.parts = parts;
+        pd.pb = atomicAdd(&a.th->n_partials, parts);
+        pd.eb = atomicAdd(&a.th->n_extra[(int)(bh % d.H) % kTileLanes], parts - 1);
+    }
+    return pd;
+}
+__device__ inline void plan_tile_finish(const TileReduceArgs &a, const Dims &d, int64_t bh, const PendingBlock &pd)
+{
+    if (pd.blk < 0) return;
+    const int ql = (int)(bh % d.H) % kTileLanes;
+    const uint32_t parts = pd.parts, pb = pd.pb, eb = pd.eb;
+    if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
+        TileDesc *td = &a.tdesc[bh * a.blocks_bound + pd.blk];
+        td->parts = parts; td->pbase = pb;
+        for (uint32_t p = 1; p < parts; ++p) {
+            TileItem ti;
+            ti.bh = (uint32_t)bh; ti.blk = (uint32_t)pd.blk; ti.part = p; ti.pidx = pb + p;
+            a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+        }
+    } else if (eb < a.th->cap_extra) {
+        // reserved queue entries that cannot be used must read as "nothing to do"
+        for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
+            TileItem ti;
+            ti.bh = (uint32_t)bh; ti.blk = (uint32_t)pd.blk; ti.part = kVoidPart; ti.pidx = 0;
+            a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+        }
+    }
+}
+
+// The blocks of one (b, h) slice that no tile could plan by itself.  Run by the LAST sort workgroup of the
+// slice (the cell table it reads was written by the slice's sort workgroups, which share an XCD and so an
+// L2): thread `tid` of `nthreads` takes blocks tid, tid + nthreads, ...
 __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d, int64_t bh, int tid, int nthreads)
 {
     const LevelRow *lv = level_rows(a.hdr);
@@ -119,9 +244,11 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
 #pragma unroll
         for (int r = 0; r < 5; ++r) { td.first[r] = 0; td.cnt[r] = 0; }
         td.hw = 0; td.lstart = 0; td.byx = 0; td.parts = 1; td.pbase = 0; td.arrived = 0;
+        int64_t n = 0;
         if (level < d.L) {
             const LevelRow lr = lv[level];
             const int rel = blk - lr.bbase4, by = rel / lr.nbx4, bx = rel - by * lr.nbx4;
+            if (block_is_tile_local(lr, by)) continue;
             const uint2 *tab = a.celltab + bh * a.cell_stride + lr.cbase;
             uint2 ent[kTB + 1][kTB + 1];
 #pragma unroll
@@ -136,7 +263,6 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
                         ent[dy][dx] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
                     }
                 }
-            int64_t n = 0;
 #pragma unroll
             for (int dy = 0; dy <= kTB; ++dy) {
                 td.first[dy] = (int)ent[dy][0].x;               // (the cells of a row are one contiguous run)
@@ -149,29 +275,8 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
             td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
             td.lstart = lr.lstart;
             td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
-            const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
-            if (parts > 1) {
-                const int ql = (int)(bh % d.H) % kTileLanes;
-                const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
-                const uint32_t eb = atomicAdd(&a.th->n_extra[ql], parts - 1);
-                if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
-                    td.parts = parts; td.pbase = pb;
-                    for (uint32_t p = 1; p < parts; ++p) {
-                        TileItem ti;
-                        ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = p; ti.pidx = pb + p;
-                        a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
-                    }
-                } else if (eb < a.th->cap_extra) {
-                    // reserved queue entries that cannot be used must read as "nothing to do"
-                    for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
-                        TileItem ti;
-                        ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = kVoidPart; ti.pidx = 0;
-                        a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
-                    }
-                }
-            }
         }
-        a.tdesc[bh * a.blocks_bound + blk] = td;
+        queue_block(a, d, bh, blk, td, n);
     }
 }
 #endif

@@ -137,18 +137,18 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
     LevelRow *lv = level_rows(hdr);
     CTile *tile = tiles_of(hdr, L);
-    int n = 0, cbase = 0, bbase = 0, bbase4 = 0;
+    int n = 0, cbase = 0, bbase = 0, bbase4 = 0, seamed = 0;
     for (int l = 0; l < L; ++l) {
         const int Hl = (int)ltab[3 * l], Wl = (int)ltab[3 * l + 1];
         LevelRow r;
         r.Hl = Hl; r.Wl = Wl; r.lstart = (int)ltab[3 * l + 2]; r.cbase = cbase; r.bbase = bbase;
         r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
         r.bbase4 = bbase4; r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
+        r.band = 0;
         if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = r.nbx4 = r.nby4 = 0; lv[l] = r; continue; }
         bbase4 += r.nbx4 * r.nby4;
         r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
         r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
-        lv[l] = r;
         const int Hc = Hl + 1, Wc = Wl + 1, cells = Hc * Wc;
         int nt = max(nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
         nt = min(nt, cells);
@@ -157,6 +157,9 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         // are then one contiguous run of the record list (the matrix-core reduce relies on it)
         int R, C;
         if (Wc <= kMaxTileCells) { R = min(max(tc / Wc, 1), kMaxTileCells / Wc); C = Wc; } else { R = 1; C = min(tc, kMaxTileCells); }
+        r.band = C == Wc ? R : 0;
+        lv[l] = r;
+        if (R < Hc || C < Wc) ++seamed;
         for (int ya = 0; ya < Hc && n < cap; ya += R)
             for (int xa = 0; xa < Wc && n < cap; xa += C) {
                 CTile t;
@@ -169,7 +172,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
     }
     hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
-    hdr->n_blocks4 = bbase4; hdr->pad[1] = hdr->pad[2] = 0;
+    hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
     // The level table lives in device memory (reference API) and the caller may not have looked at it
     // (MMFS_BWD_DEVICE_CHECKED_LEVELS: no device->host copy per call).  Owner-computes needs every
     // grad_value row to belong to at most one level: checked here.  Rows that belong to NO level (a
@@ -272,7 +275,18 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
     __syncthreads();
 }
 
-enum ScanMode { kCount = 0, kScatter = 1 };
+// The sample's cell inside the tile, or -1: outside the level, zero weight, or another tile's.
+__device__ __forceinline__ int cell_in_tile(float lx, float ly, float a, const CTile &tl, int tw)
+{
+    const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
+    const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
+    if (!inside || a == 0.f) return -1;
+    const int cy = (int)floorf(y) + 1, cx = (int)floorf(x) + 1;
+    if (cy < tl.ya || cy >= tl.yb || cx < tl.xa || cx >= tl.xb) return -1;
+    return (cy - tl.ya) * tw + (cx - tl.xa);
+}
+
+enum ScanMode { kCount = 0, kScatter = 1, kScatterLds = 2 };
 
 // One sample against the tile: if its top-left cell is in the tile
 //   kCount  : off[cell] += 1
@@ -284,19 +298,17 @@ template <int MODE, bool COMPACT>
 __device__ __forceinline__ void visit_sample(float lx, float ly, float a, uint32_t xy_bits, uint32_t a_bits, int q,
                                              const CTile &tl, int tw, uint32_t *off, uint32_t *cur, void *__restrict__ list)
 {
-    const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
-    const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
     // a sample whose attention weight is exactly zero adds nothing to grad_value (images a token
     // cannot see get exactly 0 from the masked softmax, mmfs.py:203-231): no record for it
-    if (!inside || a == 0.f) return;
-    const float yf = floorf(y), xf = floorf(x);
-    const int cy = (int)yf + 1, cx = (int)xf + 1;
-    if (cy < tl.ya || cy >= tl.yb || cx < tl.xa || cx >= tl.xb) return;
-    const int pl = (cy - tl.ya) * tw + (cx - tl.xa);
+    const int pl = cell_in_tile(lx, ly, a, tl, tw);
+    if (pl < 0) return;
+    const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
     if (MODE == kCount) {
         atomicAdd(&off[pl], 1u);
     } else {
-        const uint32_t slot = off[pl] + atomicAdd(&cur[pl], 1u);
+        // kScatterLds: the whole tile's records fit the LDS window; off[] itself is the cursor (the cell table
+        // has been written from it already) and ``list`` is the window, slot = index inside the tile
+        const uint32_t slot = MODE == kScatterLds ? atomicAdd(&off[pl], 1u) : off[pl] + atomicAdd(&cur[pl], 1u);
         if (COMPACT) reinterpret_cast<uint2 *>(list)[slot] = make_uint2((uint32_t)q | (a_bits << 16), xy_bits);
         else reinterpret_cast<uint4 *>(list)[slot] = make_uint4((uint32_t)q, __float_as_uint(y), __float_as_uint(x), __float_as_uint(a));
     }
@@ -364,10 +376,116 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
     }
 }
 
+// Nq <= kThreads * kScanUnroll (one trip of the scan): a thread's samples stay in its registers between the
+// counting pass and the placing pass, with the cell and the RANK inside the cell the counting atomic returned
+// -- the placing pass then needs no atomic and no second read of loc / attn: slot = off[cell] + rank.
+// (The second scan with its returning LDS atomics was 12 of the workgroup's 36 kclk at the north star.)
+constexpr uint32_t kNoCell = 0xffffffffu;
+constexpr int kCellBits = 13;
+static_assert(kMaxTileCells <= (1 << kCellBits), "a cell index and a rank share one word");
+template <typename T, int NV, bool COMPACT>
+struct KeptScan {
+    typedef Vec16<T> V;
+    static constexpr int VEC = V::N, SPV = V::N / 2;
+    uint4 lraw[kScanUnroll][NV];
+    uint2 araw[kScanUnroll][NV];
+    uint32_t key[kScanUnroll][NV][SPV];
+    // Two vectors per query (P = 8 of 16-bit storage): the samples' words AND their keys do not fit the 128
+    // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits).
+    static constexpr bool kKeepRaw = NV == 1;
+
+    __device__ __forceinline__ void load(const T *__restrict__ loc, const T *__restrict__ attn, const Dims &d,
+                                         const CTile &tl, int b, int h)
+    {
+        const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = (int)threadIdx.x + u * kThreads;
+            const int64_t s0 = s_first + (int64_t)min(q, d.Nq - 1) * d.P;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
+                araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
+            }
+        }
+    }
+
+    __device__ __forceinline__ void count(const Dims &d, const CTile &tl, uint32_t *off)      // (after load())
+    {
+        const int tw = tl.xb - tl.xa;
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int q = (int)threadIdx.x + u * kThreads;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float l[VEC], a[VEC];
+                V::unpack(lraw[u][v], l);
+                V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
+#pragma unroll
+                for (int i = 0; i < SPV; ++i) {
+                    const int pl = q < d.Nq ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw) : -1;
+                    key[u][v][i] = pl < 0 ? kNoCell : ((uint32_t)pl | (atomicAdd(&off[pl], 1u) << kCellBits));
+                }
+            }
+        }
+    }
+
+    // list: the tile's records (the LDS window, or its place in the record area)
+    __device__ __forceinline__ void place(const T *__restrict__ loc, const T *__restrict__ attn, const Dims &d,
+                                          const CTile &tl, int b, int h, const uint32_t *off, void *__restrict__ list)
+    {
+        if (!kKeepRaw) load(loc, attn, d, tl, b, h);
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const uint32_t q = threadIdx.x + u * kThreads;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint32_t lw[4] = {lraw[u][v].x, lraw[u][v].y, lraw[u][v].z, lraw[u][v].w};
+                const uint32_t aw[2] = {araw[u][v].x, araw[u][v].y};
+                float l[VEC], a[VEC];
+                if (!COMPACT) {
+                    V::unpack(lraw[u][v], l);
+                    V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
+                }
+#pragma unroll
+                for (int i = 0; i < SPV; ++i) {
+                    const uint32_t k = key[u][v][i];
+                    if (k == kNoCell) continue;
+                    const uint32_t slot = off[k & ((1u << kCellBits) - 1u)] + (k >> kCellBits);
+                    if (COMPACT)
+                        reinterpret_cast<uint2 *>(list)[slot] =
+                            make_uint2(q | (((aw[(i >> 1) & 1] >> (16 * (i & 1))) & 0xffffu) << 16), lw[i & 3]);
+                    else
+                        reinterpret_cast<uint4 *>(list)[slot] =
+                            make_uint4(q, __float_as_uint(l[2 * i + 1] * (float)tl.Hl - 0.5f),
+                                       __float_as_uint(l[2 * i] * (float)tl.Wl - 0.5f), __float_as_uint(a[i]));
+                }
+            }
+        }
+    }
+};
+
 struct TileParams {
     int tiles_bound;
     int nt_min;
 };
+
+// Development aid (tools/exp_build.sh sprof "-DMMFS_PROFILE_SORT"; tools/sort_prof.py): shader clocks per phase of
+// a sort workgroup, summed per level (thread 0 of each workgroup).
+#ifdef MMFS_PROFILE_SORT
+}  // namespace
+__device__ unsigned long long g_sort_prof[8 * 8];       // [level % 8][phase]
+__device__ unsigned long long g_sort_wg[4096 * 3];      // [workgroup] start, own work done, end (100 MHz ticks)
+namespace {
+#define SPROF_WG(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sort_wg[blockIdx.x * 3 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SPROF_DECL SPROF_WG(0); unsigned long long sp_c = __builtin_readcyclecounter()
+#define SPROF(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+                      atomicAdd(&g_sort_prof[(tl.level & 7) * 8 + (i)], n_ - sp_c); sp_c = n_; } } while (0)
+#else
+#define SPROF_DECL do {} while (0)
+#define SPROF(i) do {} while (0)
+#define SPROF_WG(k) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------- kernel A: sort by cell
 template <typename T, int NV, bool COMPACT>
@@ -375,10 +493,16 @@ __global__ void __launch_bounds__(kThreads)
 msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
                    const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride,
-                   const TileReduceArgs ta)
+                   const uint32_t win_bytes, const TileReduceArgs ta)
 {
+    // A tile's sorted records leave through an LDS window when they fit it: scattered straight to memory, every
+    // wave-store hits 64 different lines and the scatter pass took 40 of the workgroup's 60-78 kclk
+    // (tools/sort_prof.py); out of the window they go as whole runs.  The window is the launch's dynamic LDS
+    // (sort_window_bytes: the level's samples when they fit, else only the cursors of the direct path -- a
+    // window that is never used would halve the workgroups a CU holds).
     __shared__ uint32_t off[kMaxTileCells + 1];
-    __shared__ uint32_t cur[kMaxTileCells];
+    extern __shared__ __attribute__((aligned(16))) unsigned char win[];
+    uint32_t *cur = reinterpret_cast<uint32_t *>(win);          // (the direct path's cursors: it does not use the window)
     __shared__ uint32_t wave_tot[kWaves];
     __shared__ uint32_t region;
 
@@ -388,47 +512,98 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
     const int b = (bid / d.H) / tp.tiles_bound;
     if (t >= hdr->n_tiles) return;
     const CTile tl = tiles_of(hdr, d.L)[t];
+    // (matrix-core reduce: the level's row, for the blocks this tile plans itself; asked for early)
+    LevelRow lr = {};
+    const int seamed = hdr->pad[1];
+    if (ta.th != nullptr) lr = level_rows(hdr)[tl.level];
 
     const int tid = threadIdx.x;
     const int tw = tl.xb - tl.xa;
     const int ncell = (tl.yb - tl.ya) * tw;
 
-    for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; cur[i] = 0u; }
+    // one trip of the scan: the samples stay in registers between the two passes (KeptScan)
+    constexpr int KNV = NV > 0 ? NV : 1;
+    // (only where the launch expects windows: into memory, the two-scan path's stores are the faster -- SD 512 px
+    // geometry, 32768 samples per level: 151 us against 196)
+    const bool kept = NV > 0 && d.Nq <= kThreads * kScanUnroll && win_bytes > kMaxTileCells * 4u;
+    KeptScan<T, KNV, COMPACT> ks;
+
+    SPROF_DECL;
+    if (kept) ks.load(loc, attn, d, tl, b, h);                    // (in flight while the counters are cleared)
+    for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; if (!kept) cur[i] = 0u; }
     __syncthreads();
-    scan_samples<T, kCount, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, nullptr);
+    SPROF(0);
+    if (kept) ks.count(d, tl, off);
+    else scan_samples<T, kCount, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
+    SPROF(1);
     block_exclusive_scan(off, ncell, wave_tot);
+    SPROF(2);
     const uint32_t total = off[ncell];
     // this tile's slice of the (b, h, level) record area: the level's tiles share Nq*P slots
     const int64_t slot = ((int64_t)b * d.H + h) * d.L + tl.level;
     if (tid == 0) region = total ? atomicAdd(&level_cursor[slot], total) : 0u;
     __syncthreads();
     const int64_t base = slot * ((int64_t)d.Nq * d.P) + region;
-    if (total) scan_samples<T, kScatter, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur,
-                                                      COMPACT ? (void *)(reinterpret_cast<uint2 *>(records) + base) : (void *)(records + base));
+    void *const area = COMPACT ? (void *)(reinterpret_cast<uint2 *>(records) + base) : (void *)(records + base);
+    const bool windowed = (uint64_t)total * (COMPACT ? 8u : 16u) <= win_bytes;
+    // The cell table: read by the vector-ALU reduce and, for the matrix-core one, by the slice's last workgroup
+    // for the blocks on the seams between tiles -- with no seam, by nobody.
     uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + tl.cbase;
-    for (int p = tid; p < ncell; p += kThreads) {
+    for (int p = tid; p < (ta.th != nullptr && !seamed ? 0 : ncell); p += kThreads) {
         const int cg = (tl.ya + p / tw) * (tl.Wl + 1) + tl.xa + p % tw;
         // (written through, agent scope: the slice's last workgroup reads the table within this launch)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&tab[cg]),
                            ((unsigned long long)(off[p + 1] - off[p]) << 32) | (unsigned long long)(uint32_t)(base + off[p]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Matrix-core reduce: the LAST workgroup of the (b, h) slice turns the slice's cell table into block
-    // descriptors and work items.  Hand-off inside the launch without the L2 write-back of a release
+    PendingBlock pending;
+    pending.blk = -1;
+    if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, kThreads);
+    SPROF(3);
+    if (total) {
+        if (kept) {
+            ks.place(loc, attn, d, tl, b, h, off, windowed ? (void *)win : area);
+        } else if (windowed) {
+            __syncthreads();                                      // the table and the plan have read off[]; now off[] becomes the cursors
+            scan_samples<T, kScatterLds, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, win);
+        } else {
+            scan_samples<T, kScatter, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, area);
+        }
+        if (windowed) {
+            __syncthreads();
+            if (COMPACT) {
+                const uint2 *src = reinterpret_cast<const uint2 *>(win);
+                uint2 *dst = reinterpret_cast<uint2 *>(area);
+                for (uint32_t i = tid; i < total; i += kThreads) dst[i] = src[i];
+            } else {
+                const uint4 *src = reinterpret_cast<const uint4 *>(win);
+                uint4 *dst = reinterpret_cast<uint4 *>(area);
+                for (uint32_t i = tid; i < total; i += kThreads) dst[i] = src[i];
+            }
+        }
+    }
+    if (ta.th != nullptr) plan_tile_finish(ta, d, (int64_t)b * d.H + h, pending);
+    // Matrix-core reduce, levels cut into several tiles: the LAST workgroup of the (b, h) slice turns the slice's
+    // cell table into the descriptors and work items of the blocks on the seams.  Hand-off inside the launch without the L2 write-back of a release
     // fence (with the record scatter in flight that write-back costs more than the sort): the table is
     // stored and read with 8-byte agent-scope accesses, the stores are drained before the arrival
     // counter moves (cdna_hip_programming.md guideline 16, "8-B agent atomics both sides").
-    if (ta.th != nullptr) {
+    SPROF(4);
+    SPROF_WG(1);
+    if (ta.th != nullptr && seamed) {
         __shared__ uint32_t arrived;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
             arrived = __hip_atomic_fetch_add(&ta.slice_done[(int64_t)b * d.H + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        SPROF(5);
         if (arrived == (uint32_t)hdr->n_tiles - 1u)
             plan_slice_blocks(ta, d, (int64_t)b * d.H + h, tid, kThreads);
+        SPROF(6);
     }
+    SPROF_WG(2);
 }
 
 // ---------------------------------------------------------------- kernel B: reduce by 2x2 block
@@ -862,6 +1037,20 @@ TileParams make_params(const Dims &d)
     return tp;
 }
 
+// Dynamic LDS of a sort workgroup: the record window (msda_bwd_cell_sort) when a tile's records are expected
+// to fit one -- a tile never holds more than the level's Nq*P samples, about 1/nt of them when the level is
+// cut into nt tiles -- else just the direct path's cursors (two workgroups per CU instead of one).
+constexpr uint32_t kMaxSortWindow = 128 * 1024;
+uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
+{
+    const uint32_t floor_bytes = kMaxTileCells * 4;
+    int64_t want = (int64_t)d.Nq * d.P * (compact ? 8 : 16);
+    if (tp.nt_min > 1) want = want / tp.nt_min + want / tp.nt_min / 4;
+    if (const char *e = getenv("MMFS_SORT_WINDOW_KB")) want = std::min<int64_t>(atoll(e) * 1024, kMaxSortWindow);
+    if (want > kMaxSortWindow) return floor_bytes;
+    return (uint32_t)std::max<int64_t>(floor_bytes, (want + 15) / 16 * 16);
+}
+
 int cell_stride_of(const Dims &d) { return 2 * d.S + 2 * d.L; }      // >= sum (H+1)(W+1)
 // >= sum over levels of blocks * split, each level padded to kMaxSplit:
 // blocks <= pixels + 1, and split * blocks <= blocks + 2 * (2.25 * Nq * P) / 128 + kMaxSplit
@@ -995,14 +1184,23 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     if (!planned)
         hipLaunchKernelGGL(plan_cells_kernel, dim3(1), dim3(64), 0, st, plan_args(shapes, start, sc, d, tp));
     // the matrix-core reduce takes 8-byte records (its support test bounds Nq by 65536), the others 16-byte ones
-    if (sizeof(T) == 2 && sc.th != nullptr)
-        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, sizeof(T) == 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+    const bool compact = sizeof(T) == 2 && sc.th != nullptr;
+    const uint32_t win = sort_window_bytes(d, tp, compact);
+    if (compact) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, sizeof(T) == 2>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
+        (void)once;
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, sizeof(T) == 2>), dim3((unsigned)blocks), dim3(kThreads), win, st,
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                           cell_stride_of(d), tile_args(sc, d));
-    else
-        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+                           cell_stride_of(d), win, tile_args(sc, d));
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
+        (void)once;
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, false>), dim3((unsigned)blocks), dim3(kThreads), win, st,
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                           cell_stride_of(d), tile_args(sc, d));
+                           cell_stride_of(d), win, tile_args(sc, d));
+    }
     return hipGetLastError();
 }
 
@@ -1156,3 +1354,19 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
 }
 
 }  // namespace mmfs
+
+#ifdef MMFS_PROFILE_SORT
+extern "C" int mmfs_debug_sort_profile(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mmfs::g_sort_prof), 64 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_sort_prof), z, sizeof z);
+    }
+    return (int)e;
+}
+extern "C" int mmfs_debug_sort_timeline(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmfs::g_sort_wg), 4096 * 3 * sizeof(unsigned long long));
+}
+#endif
