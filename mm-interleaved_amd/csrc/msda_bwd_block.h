@@ -47,7 +47,9 @@ static_assert(kNPX % 4 == 0, "block weights travel as 16-byte vectors");
 struct CellHeader {
     int n_tiles, n_blocks, n_cells, L;
     int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce); pad[0]: every row has exactly one owner level;
-};                                      // pad[1]: levels cut into more than one sort tile (their seams' blocks are planned by the slice's last workgroup)
+                                        // pad[1]: levels cut into more than one sort tile (their seams' blocks are planned by the slice's last workgroup)
+    const void *loc_src, *attn_src;     // the op's own loc / attn when the sort reads them in place (no re-pack), else null
+};
 
 // workspace table: CellHeader | LevelRow[L] | CTile[cap]
 __device__ __host__ inline LevelRow *level_rows(CellHeader *h) { return reinterpret_cast<LevelRow *>(h + 1); }

@@ -106,6 +106,7 @@ struct PlanArgs {
     uint32_t cap_slots, cap_entries, cap_partials;
     TileHeader *th;
     uint32_t tile_cap_extra, tile_cap_partials;
+    const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
 };
 
 // The plan: one workgroup's job (its lanes 0-31 clear a row, lane 0 does the serial part).
@@ -173,6 +174,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     }
     hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
     hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
+    hdr->loc_src = pa.loc_src; hdr->attn_src = pa.attn_src;
     // The level table lives in device memory (reference API) and the caller may not have looked at it
     // (MMFS_BWD_DEVICE_CHECKED_LEVELS: no device->host copy per call).  Owner-computes needs every
     // grad_value row to belong to at most one level: checked here.  Rows that belong to NO level (a
@@ -394,14 +396,20 @@ struct KeptScan {
     // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits).
     static constexpr bool kKeepRaw = NV == 1;
 
+    // in_place: loc / attn are the op's own [B, Nq, H, L, P] arrays (a query's P samples of this (h, level) are
+    // contiguous there too: the same vectors, one per 2 * H * L * P elements instead of back to back -- the
+    // (b, h) slice's other levels, sorted on the same XCD at the same time, use the rest of the lines), else
+    // the [B, H, L, Nq, P] copies of msda_bwd_prepare.
     __device__ __forceinline__ void load(const T *__restrict__ loc, const T *__restrict__ attn, const Dims &d,
-                                         const CTile &tl, int b, int h)
+                                         const CTile &tl, int b, int h, bool in_place)
     {
         const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const int q = (int)threadIdx.x + u * kThreads;
-            const int64_t s0 = s_first + (int64_t)min(q, d.Nq - 1) * d.P;
+            const int qq = min(q, d.Nq - 1);
+            const int64_t s0 = in_place ? ((((int64_t)b * d.Nq + qq) * d.H + h) * d.L + tl.level) * d.P
+                                        : s_first + (int64_t)qq * d.P;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
@@ -432,9 +440,9 @@ struct KeptScan {
 
     // list: the tile's records (the LDS window, or its place in the record area)
     __device__ __forceinline__ void place(const T *__restrict__ loc, const T *__restrict__ attn, const Dims &d,
-                                          const CTile &tl, int b, int h, const uint32_t *off, void *__restrict__ list)
+                                          const CTile &tl, int b, int h, bool in_place, const uint32_t *off, void *__restrict__ list)
     {
-        if (!kKeepRaw) load(loc, attn, d, tl, b, h);
+        if (!kKeepRaw) load(loc, attn, d, tl, b, h, in_place);
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const uint32_t q = threadIdx.x + u * kThreads;
@@ -490,7 +498,7 @@ namespace {
 // ---------------------------------------------------------------- kernel A: sort by cell
 template <typename T, int NV, bool COMPACT>
 __global__ void __launch_bounds__(kThreads)
-msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 *__restrict__ records,
+msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
                    const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride,
                    const uint32_t win_bytes, const TileReduceArgs ta)
@@ -528,8 +536,15 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
     const bool kept = NV > 0 && d.Nq <= kThreads * kScanUnroll && win_bytes > kMaxTileCells * 4u;
     KeptScan<T, KNV, COMPACT> ks;
 
+    // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
+    const bool in_place = hdr->loc_src != nullptr;
+    if (in_place) {
+        if (!kept) __builtin_trap();
+        loc = reinterpret_cast<const T *>(hdr->loc_src); attn = reinterpret_cast<const T *>(hdr->attn_src);
+    }
+
     SPROF_DECL;
-    if (kept) ks.load(loc, attn, d, tl, b, h);                    // (in flight while the counters are cleared)
+    if (kept) ks.load(loc, attn, d, tl, b, h, in_place);          // (in flight while the counters are cleared)
     for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; if (!kept) cur[i] = 0u; }
     __syncthreads();
     SPROF(0);
@@ -563,7 +578,7 @@ msda_bwd_cell_sort(const T *__restrict__ loc, const T *__restrict__ attn, uint4 
     SPROF(3);
     if (total) {
         if (kept) {
-            ks.place(loc, attn, d, tl, b, h, off, windowed ? (void *)win : area);
+            ks.place(loc, attn, d, tl, b, h, in_place, off, windowed ? (void *)win : area);
         } else if (windowed) {
             __syncthreads();                                      // the table and the plan have read off[]; now off[] becomes the cursors
             scan_samples<T, kScatterLds, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, win);
@@ -1051,6 +1066,16 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
     return (uint32_t)std::max<int64_t>(floor_bytes, (want + 15) / 16 * 16);
 }
 
+// One trip of the scan with a window to sort into: the sort keeps its samples in registers (KeptScan) -- and can
+// then read them from the op's own arrays, so that nothing has to be re-packed.  (MMFS_SORT_REPACK=1 re-packs anyway.)
+bool sort_keeps_samples(int dtype, const Dims &d, const TileParams &tp)
+{
+    const int es = dtype == 0 ? 4 : 2, loc_bytes = d.P * 2 * es;
+    if (loc_bytes % 16 != 0 || loc_bytes / 16 > 2) return false;
+    const bool compact = es == 2 && tile_reduce_supported(dtype, d);
+    return d.Nq <= kThreads * kScanUnroll && sort_window_bytes(d, tp, compact) > kMaxTileCells * 4u;
+}
+
 int cell_stride_of(const Dims &d) { return 2 * d.S + 2 * d.L; }      // >= sum (H+1)(W+1)
 // >= sum over levels of blocks * split, each level padded to kMaxSplit:
 // blocks <= pixels + 1, and split * blocks <= blocks + 2 * (2.25 * Nq * P) / 128 + kMaxSplit
@@ -1170,6 +1195,7 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
     pa.samples_per_level = (int64_t)d.Nq * d.P; pa.hdr = sc.hdr; pa.ovf_header = reinterpret_cast<uint32_t *>(sc.ovf);
     pa.cap_slots = sc.cap_slots; pa.cap_entries = sc.cap_entries; pa.cap_partials = sc.cap_partials;
     pa.th = sc.th; pa.tile_cap_extra = sc.tile_cap_extra; pa.tile_cap_partials = sc.tile_cap_partials;
+    pa.loc_src = pa.attn_src = nullptr;
     return pa;
 }
 
@@ -1304,11 +1330,21 @@ hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *
     const int vb_l = gran(loc, sc.loc_t, cl), vb_a = gran(attn, sc.attn_t, ca);
     const int vpc_l = cl / vb_l, vpc_a = ca / vb_a;
     const int64_t groups = (int64_t)d.B * d.Nq * d.H * d.L;
-    const int64_t total_l = groups * vpc_l, total_a = groups * vpc_a;
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total_l + 255) / 256, 256 * 64));
+    int64_t total_l = groups * vpc_l, total_a = groups * vpc_a;
     PlanArgs pa;
     pa.shapes = nullptr;
-    if (shapes != nullptr && start != nullptr) pa = plan_args(shapes, start, sc, d, make_params(d));
+    if (shapes != nullptr && start != nullptr) {
+        const TileParams tp = make_params(d);
+        pa = plan_args(shapes, start, sc, d, tp);
+        // the sort can read loc / attn where they are (the header tells it): no re-pack
+        const bool aligned = (uintptr_t)loc % 16 == 0 && (uintptr_t)attn % 8 == 0;
+        const char *e = getenv("MMFS_SORT_REPACK");
+        if (aligned && sort_keeps_samples(dtype, d, tp) && !(e && e[0] == '1')) {
+            pa.loc_src = loc; pa.attn_src = attn;
+            total_l = total_a = 0;
+        }
+    }
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total_l + 255) / 256, 256 * 64));
     hipLaunchKernelGGL(msda_bwd_prepare, dim3((unsigned)blocks), dim3(256), 0, st,
                        (const char *)loc, (char *)sc.loc_t, vb_l, vpc_l, total_l,
                        (const char *)attn, (char *)sc.attn_t, vb_a, vpc_a, total_a,

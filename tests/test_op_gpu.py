@@ -154,6 +154,42 @@ def test_grad_value_generations_agree_with_oracle(algo, dtype, monkeypatch):
     check(run_hip(x, dtype), run_oracle(x), dtype, f"value algo {algo}")
 
 
+SORT_ROUTES = {
+    # name: (dtype, P, Nq, MMFS_NT_MIN, MMFS_SORT_WINDOW_KB)      what the cell sort does (csrc/msda_bwd_block.hip)
+    "kept_window":          (torch.bfloat16, 4, 301, None, None),   # samples kept in registers, records through the LDS window, tiles plan their own blocks
+    "kept_window_seams":    (torch.bfloat16, 4, 302, "3", None),    # levels cut into bands: local blocks + the seams' blocks by the slice's last workgroup
+    "kept_window_p8":       (torch.float16, 8, 303, "2", None),     # two vectors per query: the placing pass reads the words again
+    "kept_window_too_small": (torch.bfloat16, 4, 1000, None, "21"), # a tile's records exceed the window: placed straight into memory
+    "two_scan_window":      (torch.bfloat16, 2, 304, None, None),   # 8-byte query rows (scalar scan): second scan into the window
+    "two_scan_window_seams": (torch.bfloat16, 3, 305, "4", None),
+    "direct":               (torch.bfloat16, 4, 306, None, "0"),    # no window: cursors + scattered stores
+    "direct_seams":         (torch.bfloat16, 4, 307, "3", "0"),
+    "fp32_records":         (torch.float32, 4, 308, None, None),    # 16-byte records, vector-ALU reduce off the cell table
+    "fp32_records_seams":   (torch.float32, 4, 309, "3", None),
+}
+
+
+@pytest.mark.parametrize("route", sorted(SORT_ROUTES))
+def test_cell_sort_routes_match_oracle(route, monkeypatch):
+    """Every way the cell sort moves a tile's records (LDS window or straight to memory, samples kept in registers
+    or scanned twice) and plans the 4x4 blocks (by the tile itself, or on the seams between a level's tiles by
+    the slice's last workgroup) gives the oracle's gradients.  B*H*L = 128 slices: one tile per level unless
+    MMFS_NT_MIN cuts the levels into bands."""
+    import MultiScaleDeformableAttention as MSDA
+    dtype, P, Nq, nt, win = SORT_ROUTES[route]
+    monkeypatch.setattr(MSDA, "_ws_cache", {})                  # (the tile bound of the workspace depends on MMFS_NT_MIN)
+    for k, v in (("MMFS_NT_MIN", nt), ("MMFS_SORT_WINDOW_KB", win)):
+        monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
+    # (extents that are powers of two: loc * extent is then exact in fp32 as in the oracle's fp64, and no sample
+    # sits on the other side of a pixel boundary, where grad_loc jumps)
+    x = make_inputs(4, 8, 32, Nq, P, [(32, 16), (16, 8), (8, 4), (4, 2)], seed=31, loc_range=(-0.1, 1.1), dtype=dtype)
+    x["attn"][:, ::7, :, 1] = 0.0                               # zero weights leave no record
+    try:
+        check(run_hip(x, dtype), run_oracle(x), dtype, f"sort route {route}")
+    finally:
+        MSDA._ws_cache.clear()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_every_query_on_one_spot_overflows_the_block_lists(dtype):
     """The LLM path's distribution: every token samples around the SAME reference point, so a few
