@@ -109,97 +109,130 @@ struct PlanArgs {
     const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
 };
 
-// The plan: one workgroup's job (its lanes 0-31 clear a row, lane 0 does the serial part).
+// The plan: one workgroup's job.  A lane per level for everything that divides (the 64-bit divisions of one
+// level cost a single lane ~2 us: serial, the plan was 7.5 us at 4 levels and the opening launch of the backward
+// is nothing but the plan since the sort reads loc / attn in place); lane 0 only adds up the levels' bases.
 __device__ void plan_cells_body(const PlanArgs &pa)
 {
     const int L = pa.L, S = pa.S, nt_min = pa.nt_min, cap = pa.cap;
     const int64_t samples_per_level = pa.samples_per_level;
     CellHeader *__restrict__ hdr = pa.hdr;
     uint32_t *__restrict__ ovf_header = pa.ovf_header;
-    const uint32_t cap_slots = pa.cap_slots, cap_entries = pa.cap_entries, cap_partials = pa.cap_partials;
     TileHeader *__restrict__ th = pa.th;
-    const uint32_t tile_cap_extra = pa.tile_cap_extra, tile_cap_partials = pa.tile_cap_partials;
-    if (th != nullptr && threadIdx.x < 32) th->zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    // the level table once, in parallel, into LDS: the serial part below reads every row O(L) times, and a
-    // dependent global load costs microseconds while the rest of the launch streams loc / attn
-    __shared__ int64_t ltab[3 * kMaxLevels];
-    for (int l = threadIdx.x; l < L && l < kMaxLevels; l += blockDim.x) {
-        ltab[3 * l] = pa.shapes[2 * l]; ltab[3 * l + 1] = pa.shapes[2 * l + 1]; ltab[3 * l + 2] = pa.start[l];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (th != nullptr && tid < 32) th->zero_row[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == nthr - 1) {
+        if (th != nullptr) {
+            for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
+            th->n_partials = 0u; th->cap_extra = pa.tile_cap_extra; th->cap_partials = pa.tile_cap_partials; th->n_multi = 0u;
+            th->null_rec = make_uint4(0u, __float_as_uint(-8.f), __float_as_uint(-8.f), 0u);
+        }
+        ovf_header[0] = 0u; ovf_header[1] = pa.cap_slots; ovf_header[2] = pa.cap_entries;               // OvfHeader
+        ovf_header[3] = 0u; ovf_header[4] = pa.cap_partials; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
+        for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
+    }
+    __shared__ int64_t ltab[3 * kMaxLevels];            // the level table as given: H, W, first row
+    __shared__ LevelRow rows[kMaxLevels];               // bases filled in by lane 0
+    __shared__ int tile_r[kMaxLevels], tile_c[kMaxLevels], tile_n[kMaxLevels], tile_base[kMaxLevels];
+    __shared__ int bad_s, totals[5];
+    if (tid == 0) bad_s = 0;
+    for (int l = tid; l < L && l < kMaxLevels; l += nthr) {
+        const int64_t Hl64 = pa.shapes[2 * l], Wl64 = pa.shapes[2 * l + 1], a0 = pa.start[l];
+        ltab[3 * l] = Hl64; ltab[3 * l + 1] = Wl64; ltab[3 * l + 2] = a0;
+        const int Hl = (int)Hl64, Wl = (int)Wl64;
+        LevelRow r;
+        r.Hl = Hl; r.Wl = Wl; r.lstart = (int)a0; r.cbase = 0; r.bbase = 0; r.bbase4 = 0;
+        r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
+        r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
+        r.band = 0;
+        int R = 0, C = 0, n = 0;
+        if (Hl64 <= 0 || Wl64 <= 0) {
+            r.nbx = r.nby = r.nbx4 = r.nby4 = 0;
+        } else if (Hl64 >= 65536 || Wl64 >= 65536) {
+            r.nbx = r.nby = r.nbx4 = r.nby4 = 0;                   // (refused below: no tiles)
+        } else {
+            r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
+            r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
+            const int Hc = Hl + 1, Wc = Wl + 1;
+            const int64_t cells = (int64_t)Hc * Wc;
+            int64_t nt = max((int64_t)nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
+            nt = min(nt, cells);
+            const int64_t tc = (cells + nt - 1) / nt;
+            // whole cell rows whenever one fits the tile's counters: the cells of a row that touch a block
+            // are then one contiguous run of the record list (the matrix-core reduce relies on it)
+            if (Wc <= kMaxTileCells) { R = (int)min(max(tc / Wc, (int64_t)1), (int64_t)(kMaxTileCells / Wc)); C = Wc; }
+            else { R = 1; C = (int)min(tc, (int64_t)kMaxTileCells); }
+            r.band = C == Wc ? R : 0;
+            n = (int)min((int64_t)((Hc + R - 1) / R) * ((Wc + C - 1) / C), (int64_t)0x3fffffff);
+        }
+        rows[l] = r; tile_r[l] = R; tile_c[l] = C; tile_n[l] = n;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    if (th != nullptr) {
-        for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
-        th->n_partials = 0u; th->cap_extra = tile_cap_extra; th->cap_partials = tile_cap_partials; th->n_multi = 0u;
-        th->null_rec = make_uint4(0u, __float_as_uint(-8.f), __float_as_uint(-8.f), 0u);
+    if (tid == 0) {
+        int cbase = 0, bbase = 0, bbase4 = 0, seamed = 0;
+        int64_t covered = 0, n = 0;
+        for (int l = 0; l < L; ++l) {
+            LevelRow &r = rows[l];
+            r.cbase = cbase; r.bbase = bbase; r.bbase4 = bbase4;
+            tile_base[l] = (int)min(n, (int64_t)cap);
+            if (tile_n[l] == 0) continue;                                // (empty, or refused below)
+            bbase4 += r.nbx4 * r.nby4;
+            n += tile_n[l];
+            if (tile_n[l] > 1) ++seamed;
+            cbase += (r.Hl + 1) * (r.Wl + 1);
+            bbase += r.nbx * r.nby * r.split;
+            bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
+            covered += (int64_t)r.Hl * r.Wl;
+        }
+        hdr->n_tiles = (int)min(n, (int64_t)cap); hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
+        hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
+        hdr->loc_src = pa.loc_src; hdr->attn_src = pa.attn_src;
+        totals[0] = covered == (int64_t)S;
     }
-    ovf_header[0] = 0u; ovf_header[1] = cap_slots; ovf_header[2] = cap_entries;                         // OvfHeader
-    ovf_header[3] = 0u; ovf_header[4] = cap_partials; ovf_header[5] = ovf_header[6] = ovf_header[7] = 0u;
-    for (int i = 0; i < kOvfLanes; ++i) ovf_header[8 + i] = 0u;
+    __syncthreads();
     LevelRow *lv = level_rows(hdr);
     CTile *tile = tiles_of(hdr, L);
-    int n = 0, cbase = 0, bbase = 0, bbase4 = 0, seamed = 0;
-    for (int l = 0; l < L; ++l) {
-        const int Hl = (int)ltab[3 * l], Wl = (int)ltab[3 * l + 1];
-        LevelRow r;
-        r.Hl = Hl; r.Wl = Wl; r.lstart = (int)ltab[3 * l + 2]; r.cbase = cbase; r.bbase = bbase;
-        r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
-        r.bbase4 = bbase4; r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
-        r.band = 0;
-        if (Hl <= 0 || Wl <= 0) { r.nbx = r.nby = r.nbx4 = r.nby4 = 0; lv[l] = r; continue; }
-        bbase4 += r.nbx4 * r.nby4;
-        r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
-        r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
-        const int Hc = Hl + 1, Wc = Wl + 1, cells = Hc * Wc;
-        int nt = max(nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
-        nt = min(nt, cells);
-        const int tc = (cells + nt - 1) / nt;
-        // whole cell rows whenever one fits the tile's counters: the cells of a row that touch a block
-        // are then one contiguous run of the record list (the matrix-core reduce relies on it)
-        int R, C;
-        if (Wc <= kMaxTileCells) { R = min(max(tc / Wc, 1), kMaxTileCells / Wc); C = Wc; } else { R = 1; C = min(tc, kMaxTileCells); }
-        r.band = C == Wc ? R : 0;
-        lv[l] = r;
-        if (R < Hc || C < Wc) ++seamed;
-        for (int ya = 0; ya < Hc && n < cap; ya += R)
-            for (int xa = 0; xa < Wc && n < cap; xa += C) {
-                CTile t;
-                t.level = l; t.Hl = Hl; t.Wl = Wl; t.cbase = cbase;
-                t.ya = ya; t.yb = min(Hc, ya + R); t.xa = xa; t.xb = min(Wc, xa + C);
-                tile[n++] = t;
-            }
-        cbase += cells;
-        bbase += r.nbx * r.nby * r.split;
-        bbase = (bbase + kMaxSplit - 1) / kMaxSplit * kMaxSplit;     // a block's groups never straddle workgroups
-    }
-    hdr->n_tiles = n; hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
-    hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
-    hdr->loc_src = pa.loc_src; hdr->attn_src = pa.attn_src;
     // The level table lives in device memory (reference API) and the caller may not have looked at it
     // (MMFS_BWD_DEVICE_CHECKED_LEVELS: no device->host copy per call).  Owner-computes needs every
     // grad_value row to belong to at most one level: checked here.  Rows that belong to NO level (a
     // table with gaps; canonical tables have none) are zero-filled by zero_uncovered_rows.  Overlapping
     // levels -- the reference would add both levels' gradients into the shared rows -- cannot be served
     // by this path: loud, device-side failure (callers that know their table take the atomic path).
-    int64_t covered = 0;
-    bool bad = false;
-    for (int l = 0; l < L; ++l) {
+    for (int l = tid; l < L && l < kMaxLevels; l += nthr) {
+        const LevelRow r = rows[l];
+        lv[l] = r;
+        int n = tile_base[l];
+        const int Hc = r.Hl + 1, Wc = r.Wl + 1, R = tile_r[l], C = tile_c[l];
+        if (tile_n[l] > 0)
+            for (int ya = 0; ya < Hc && n < cap; ya += R)
+                for (int xa = 0; xa < Wc && n < cap; xa += C, ++n) {
+                    CTile t;
+                    t.level = l; t.Hl = r.Hl; t.Wl = r.Wl; t.cbase = r.cbase;
+                    t.ya = ya; t.yb = min(Hc, ya + R); t.xa = xa; t.xb = min(Wc, xa + C);
+                    tile[n] = t;
+                }
         const int64_t Hl = ltab[3 * l], Wl = ltab[3 * l + 1], a0 = ltab[3 * l + 2];
-        if (Hl < 0 || Wl < 0 || Hl >= 65536 || Wl >= 65536) { bad = true; continue; }
-        if (Hl == 0 || Wl == 0) continue;
-        const int64_t a1 = a0 + Hl * Wl;
-        if (a0 < 0 || a1 > S) bad = true;
-        covered += Hl * Wl;
-        for (int k = 0; k < l; ++k) {
-            const int64_t b0 = ltab[3 * k + 2], b1 = b0 + ltab[3 * k] * ltab[3 * k + 1];
-            if (ltab[3 * k] > 0 && ltab[3 * k + 1] > 0 && a0 < b1 && b0 < a1) bad = true;
+        bool bad = false;
+        if (Hl < 0 || Wl < 0 || Hl >= 65536 || Wl >= 65536) bad = true;
+        else if (Hl > 0 && Wl > 0) {
+            const int64_t a1 = a0 + Hl * Wl;
+            if (a0 < 0 || a1 > S) bad = true;
+            for (int k = 0; k < l; ++k) {
+                const int64_t b0 = ltab[3 * k + 2], b1 = b0 + ltab[3 * k] * ltab[3 * k + 1];
+                if (ltab[3 * k] > 0 && ltab[3 * k + 1] > 0 && a0 < b1 && b0 < a1) bad = true;
+            }
         }
+        if (bad) atomicOr(&bad_s, 1);
     }
-    hdr->pad[0] = (!bad && covered == S) ? 1 : 0;          // canonical in the sense that matters: every row has exactly one owner
-    if (bad) {
-        printf("mmfs_msda backward: level table has overlapping / out-of-range / oversized levels; "
-               "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
-        __builtin_trap();
+    __syncthreads();
+    if (tid == 0) {
+        const bool bad = bad_s != 0;
+        hdr->pad[0] = (!bad && totals[0]) ? 1 : 0;         // canonical in the sense that matters: every row has exactly one owner
+        if (bad) {
+            printf("mmfs_msda backward: level table has overlapping / out-of-range / oversized levels; "
+                   "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
+            __builtin_trap();
+        }
     }
 }
 
