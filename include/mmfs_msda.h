@@ -216,7 +216,11 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
  * not only to the queries that sample it.  Environment MMFS_HYBRID=0 disables the routing.
  *
  * ``stages`` selects which launches a call issues (OR of the bits; all of them = the whole
- * pass, in this order), so each kernel can be timed on its own.
+ * pass, in this order), so each kernel can be timed on its own.  The stages of one pass share the
+ * workspace and run in this order: VALUE_PREPARE also plans the sort (level rows, tiles) and may tell
+ * the sort to read ``loc`` / ``attn`` where they are instead of re-packing them, so VALUE_SORT needs
+ * the VALUE_PREPARE of THIS entry point on the same workspace, and ``loc`` / ``attn`` unchanged until
+ * the sort has run.
  */
 #define MMFS_HYB_BWD_TAPS_FINE      1u
 #define MMFS_HYB_BWD_TAPS_COARSE    2u

@@ -361,13 +361,12 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
         e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
     // (the plan rides in the prepare launch only when this very call also sorts; the hybrid path needs
     // MMFS_BWD_CANONICAL_LEVELS, so every grad_value row has an owner and no zero-fill pass is due)
+    // (the prepare stage always plans: a staged pass then runs the very kernels of the one-call pass)
     bool planned = false;
-    const bool fuse_plan = (stages & MMFS_HYB_BWD_VALUE_SORT) != 0;
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE))
-        e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st, fuse_plan ? shapes : nullptr,
-                                         fuse_plan ? start : nullptr, &planned);
+        e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st, shapes, start, &planned);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT))
-        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, planned);
+        e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, true);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE))
         e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, true);
     return (int)e;
