@@ -134,7 +134,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     __shared__ int64_t ltab[3 * kMaxLevels];            // the level table as given: H, W, first row
     __shared__ LevelRow rows[kMaxLevels];               // bases filled in by lane 0
     __shared__ int tile_r[kMaxLevels], tile_c[kMaxLevels], tile_n[kMaxLevels], tile_base[kMaxLevels];
-    __shared__ int bad_s, totals[5];
+    __shared__ int bad_s, covered_all;
     if (tid == 0) bad_s = 0;
     for (int l = tid; l < L && l < kMaxLevels; l += nthr) {
         const int64_t Hl64 = pa.shapes[2 * l], Wl64 = pa.shapes[2 * l + 1], a0 = pa.start[l];
@@ -187,7 +187,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         hdr->n_tiles = (int)min(n, (int64_t)cap); hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
         hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
         hdr->loc_src = pa.loc_src; hdr->attn_src = pa.attn_src;
-        totals[0] = covered == (int64_t)S;
+        covered_all = covered == (int64_t)S;
     }
     __syncthreads();
     LevelRow *lv = level_rows(hdr);
@@ -227,7 +227,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     __syncthreads();
     if (tid == 0) {
         const bool bad = bad_s != 0;
-        hdr->pad[0] = (!bad && totals[0]) ? 1 : 0;         // canonical in the sense that matters: every row has exactly one owner
+        hdr->pad[0] = (!bad && covered_all) ? 1 : 0;         // canonical in the sense that matters: every row has exactly one owner
         if (bad) {
             printf("mmfs_msda backward: level table has overlapping / out-of-range / oversized levels; "
                    "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
