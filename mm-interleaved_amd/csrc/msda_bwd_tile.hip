@@ -128,10 +128,6 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-__device__ __forceinline__ void dma16(const void *src, void *lds_dst)
-{
-    __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 16, 0, 0);
-}
 __device__ __forceinline__ void dma4(const void *src, void *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 4, 0, 0);

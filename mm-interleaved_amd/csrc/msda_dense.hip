@@ -255,8 +255,6 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
     PROF_END(0);
 }
 
-int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
-
 // chunks of query tiles per (b, h) so that about ``target`` workgroups exist
 int tile_chunks(const Dims &d, int tile_q = kTileQ, int target = 256)
 {
