@@ -228,7 +228,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel event pass; prints ms/step only")
-    ap.add_argument("--event-steps", type=int, default=10, help="steps of the per-kernel event pass (after the timed region)")
+    ap.add_argument("--event-steps", type=int, default=10, help="steps of the per-kernel event pass (before the warm-up)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed steps for this long before anything is measured: a GPU coming out of idle runs its "
+                         "first ~30-50 ms of work 7 %% slower (profiles/r02s_clock_ramp.log), which is the whole "
+                         "timed region of a --steps 20 run")
     ap.add_argument("--visible", default="all", choices=["all", "causal"],
                     help="causal: image k of n is visible to the queries after k/n of the sequence, zero attention elsewhere")
     ap.add_argument("--loc-dist", default="uniform", choices=["uniform", "centre"],
@@ -292,6 +296,11 @@ def main():
     # ---- per-kernel HIP events, recorded on the launch stream around every C-ABI launch: a pass of its
     # own, BEFORE the warm-up (bracketing every launch costs ~45 us of host work per step, and the stage-by-
     # stage calls are not what production issues: neither belongs in the timed region)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     log = []
     if not args.no_kernel_events:
         for _ in range(max(args.warmup, 40)):      # (its own warm-up: the averages are of a warm GPU, like the rocprofv3 trace's)
