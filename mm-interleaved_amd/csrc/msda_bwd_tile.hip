@@ -32,7 +32,8 @@
 //   * A list longer than kTileChunk records (small levels, hot spots -- every text token of the LLM
 //     path samples around the same reference point) is cut into work items planned on the device; a
 //     block of several items leaves fp32 partial tiles; the item that finishes last adds them up and rounds.
-//     The planning itself rides on the tail of the sort kernel (plan_slice_blocks, msda_bwd_block.h).
+//     The planning itself rides on the sort kernel: a sort tile plans the blocks it holds whole, the slice's last
+//     workgroup those on the seams between tiles (plan_tile_begin / plan_slice_blocks, msda_bwd_block.h).
 //
 // Semantics that differ from the gather kernels, by construction of a matrix product: a non-finite
 // grad_out element reaches all 16 pixels of the blocks its sample touches (0 * Inf = NaN), not only
