@@ -66,6 +66,12 @@ const char *mmfs_msda_build_info(void);
 /* Text for a status returned by any entry point.  Host string, never NULL. */
 const char *mmfs_msda_status_string(int status);
 
+/* Host-only self-check of the sorted backward's tiling rules for one H x W level cut into at least
+ * ``nt_min`` sort tiles (the functions the device plan uses, run on the host): 0 when the tiles cover every
+ * cell exactly once and every 4x4 block of the level is planned exactly once, -1 when the level owns no
+ * tile (empty, or an extent >= 65536), else a count of violations.  No reference counterpart: test hook. */
+int mmfs_msda_plan_selfcheck(int64_t H, int64_t W, int nt_min);
+
 /*
  * Forward.  Replaces ``ms_deform_attn_forward`` of the reference extension
  *   mm_interleaved/models/utils/ops/src/vision.cpp:14

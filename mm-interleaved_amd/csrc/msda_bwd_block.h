@@ -33,6 +33,35 @@ struct LevelRow {
     int band;                           // cell rows per sort tile when the level's tiles are whole rows, else 0
 };
 constexpr int kMaxSplit = 8;            // <= lane groups per reduce workgroup for every head width
+
+// How a level's (H+1) x (W+1) cells are cut into sort tiles: R rows x C columns of cells per tile, n tiles
+// (n = 0: the level owns no tile -- empty, or an extent the sorted backward refuses).  Whole cell rows
+// whenever one fits a tile's counters: the cells of a row that touch a block are then one contiguous run of
+// the record list (the matrix-core reduce relies on it).  At least nt_min tiles (few (b, h, level) slices).
+struct LevelTiling { int R, C, n; };
+__device__ __host__ inline LevelTiling level_tiling(int64_t Hl, int64_t Wl, int nt_min)
+{
+    LevelTiling t;
+    t.R = 0; t.C = 0; t.n = 0;
+    if (Hl <= 0 || Wl <= 0 || Hl >= 65536 || Wl >= 65536) return t;
+    const int Hc = (int)Hl + 1, Wc = (int)Wl + 1;
+    const int64_t cells = (int64_t)Hc * Wc;
+    int64_t nt = (cells + kMaxTileCells - 1) / kMaxTileCells;
+    if (nt < nt_min) nt = nt_min;
+    if (nt > cells) nt = cells;
+    const int64_t tc = (cells + nt - 1) / nt;
+    if (Wc <= kMaxTileCells) {
+        int64_t r = tc / Wc;
+        if (r < 1) r = 1;
+        if (r > kMaxTileCells / Wc) r = kMaxTileCells / Wc;
+        t.R = (int)r; t.C = Wc;
+    } else {
+        t.R = 1; t.C = (int)(tc < kMaxTileCells ? tc : kMaxTileCells);
+    }
+    const int64_t n = (int64_t)((Hc + t.R - 1) / t.R) * ((Wc + t.C - 1) / t.C);
+    t.n = (int)(n < 0x3fffffff ? n : 0x3fffffff);
+    return t;
+}
 #ifndef MMFS_BLK_H
 #define MMFS_BLK_H 2
 #endif
@@ -138,9 +167,10 @@ __device__ inline void queue_block(const TileReduceArgs &a, const Dims &d, int64
 // straight from its prefix sums in LDS (plan_tile_blocks); the others -- the seams between the bands of a
 // level cut into several tiles, and every block of a level whose tiles are not whole rows -- by the slice's
 // last workgroup from the cell table (plan_slice_blocks).
-__device__ __forceinline__ bool block_is_tile_local(const LevelRow &lr, int by)
+__device__ __host__ inline bool block_is_tile_local(const LevelRow &lr, int by)
 {
-    return lr.band > 0 && (kTB * by) / lr.band == min(kTB * by + kTB, lr.Hl) / lr.band;
+    const int last = kTB * by + kTB < lr.Hl ? kTB * by + kTB : lr.Hl;      // the block's last cell row
+    return lr.band > 0 && (kTB * by) / lr.band == last / lr.band;
 }
 
 // The blocks of tile `tl` (whole cell rows [ya, yb) of level row `lr`) that are local to it.  off[]: the tile's
@@ -150,11 +180,11 @@ __device__ __forceinline__ bool block_is_tile_local(const LevelRow &lr, int by)
 // several work items (two returning device atomics, microseconds under the sort's store traffic);
 // plan_tile_finish, called after the workgroup has moved its records, takes the answers.
 struct PendingBlock { int blk; uint32_t parts, pb, eb; };          // blk < 0: nothing pending
-__device__ __forceinline__ int tile_local_blocks(const CTile &tl, const LevelRow &lr, int *by_lo)
+__device__ __host__ inline int tile_local_blocks(const CTile &tl, const LevelRow &lr, int *by_lo)
 {
     *by_lo = (tl.ya + kTB - 1) / kTB;
     int by_hi = *by_lo;                                             // (exclusive)
-    while (by_hi < lr.nby4 && min(kTB * by_hi + kTB, lr.Hl) < tl.yb) ++by_hi;
+    while (by_hi < lr.nby4 && (kTB * by_hi + kTB < lr.Hl ? kTB * by_hi + kTB : lr.Hl) < tl.yb) ++by_hi;
     return (by_hi - *by_lo) * lr.nbx4;
 }
 __device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTile &tl, const LevelRow &lr, int by, int bx,

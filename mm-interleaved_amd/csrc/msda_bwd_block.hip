@@ -23,6 +23,7 @@
 #include "msda_device.h"
 #include "msda_launch.h"
 #include "msda_bwd_block.h"
+#include <vector>
 #include <cstdlib>
 
 namespace mmfs {
@@ -145,25 +146,14 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
         r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
         r.band = 0;
-        int R = 0, C = 0, n = 0;
-        if (Hl64 <= 0 || Wl64 <= 0) {
-            r.nbx = r.nby = r.nbx4 = r.nby4 = 0;
-        } else if (Hl64 >= 65536 || Wl64 >= 65536) {
-            r.nbx = r.nby = r.nbx4 = r.nby4 = 0;                   // (refused below: no tiles)
+        const LevelTiling lt = level_tiling(Hl64, Wl64, nt_min);
+        const int R = lt.R, C = lt.C, n = lt.n;
+        if (n == 0) {
+            r.nbx = r.nby = r.nbx4 = r.nby4 = 0;                   // (empty; or refused below: no tiles)
         } else {
             r.split = split_of(samples_per_level, (int64_t)r.nbx * r.nby);
             r.cap = cap_of(samples_per_level, (int64_t)r.nbx * r.nby);
-            const int Hc = Hl + 1, Wc = Wl + 1;
-            const int64_t cells = (int64_t)Hc * Wc;
-            int64_t nt = max((int64_t)nt_min, (cells + kMaxTileCells - 1) / kMaxTileCells);
-            nt = min(nt, cells);
-            const int64_t tc = (cells + nt - 1) / nt;
-            // whole cell rows whenever one fits the tile's counters: the cells of a row that touch a block
-            // are then one contiguous run of the record list (the matrix-core reduce relies on it)
-            if (Wc <= kMaxTileCells) { R = (int)min(max(tc / Wc, (int64_t)1), (int64_t)(kMaxTileCells / Wc)); C = Wc; }
-            else { R = 1; C = (int)min(tc, (int64_t)kMaxTileCells); }
-            r.band = C == Wc ? R : 0;
-            n = (int)min((int64_t)((Hc + R - 1) / R) * ((Wc + C - 1) / C), (int64_t)0x3fffffff);
+            r.band = C == Wl + 1 ? R : 0;
         }
         rows[l] = r; tile_r[l] = R; tile_c[l] = C; tile_n[l] = n;
     }
@@ -1423,6 +1413,47 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
 }
 
 }  // namespace mmfs
+
+// Host-only self-check of the sort's tiling rules for ONE level (tests/test_plan_cpu.py sweeps it): the very
+// functions the device plan uses (level_tiling, tile_local_blocks, block_is_tile_local).  Returns 0 when
+// the tiles cover every cell exactly once within the counters' capacity AND every 4x4 block is planned exactly
+// once -- by the one tile that holds its five cell rows, or, on a seam, by the slice's last workgroup;
+// else a positive count of what is wrong.  -1: the level owns no tile (empty / refused extents).
+extern "C" int mmfs_msda_plan_selfcheck(int64_t Hl, int64_t Wl, int nt_min)
+{
+    using namespace mmfs::blk;
+    const LevelTiling lt = level_tiling(Hl, Wl, nt_min);
+    if (lt.n == 0) return -1;
+    const int Hc = (int)Hl + 1, Wc = (int)Wl + 1;
+    LevelRow lr = {};
+    lr.Hl = (int)Hl; lr.Wl = (int)Wl;
+    lr.nbx4 = ((int)Wl + kTB - 1) / kTB; lr.nby4 = ((int)Hl + kTB - 1) / kTB;
+    lr.band = lt.C == Wc ? lt.R : 0;
+    int wrong = 0;
+    int64_t covered = 0, n = 0;
+    std::vector<int> planned((size_t)lr.nby4, 0);                  // per block row: tiles that plan it
+    for (int ya = 0; ya < Hc; ya += lt.R)
+        for (int xa = 0; xa < Wc; xa += lt.C, ++n) {
+            CTile t;
+            t.level = 0; t.Hl = lr.Hl; t.Wl = lr.Wl; t.cbase = 0;
+            t.ya = ya; t.yb = std::min(Hc, ya + lt.R); t.xa = xa; t.xb = std::min(Wc, xa + lt.C);
+            const int64_t cells = (int64_t)(t.yb - t.ya) * (t.xb - t.xa);
+            if (cells > kMaxTileCells) ++wrong;
+            covered += cells;
+            if (lr.band == 0) continue;                             // (tiles that are not whole rows plan nothing)
+            int by_lo;
+            const int nloc = tile_local_blocks(t, lr, &by_lo);
+            if (nloc % lr.nbx4 != 0 || nloc > 1024) ++wrong;        // whole block rows; one block per sort lane
+            for (int by = by_lo; by < by_lo + nloc / lr.nbx4; ++by) {
+                if (!block_is_tile_local(lr, by)) ++wrong;          // the two rules must agree
+                ++planned[(size_t)by];
+            }
+        }
+    if (n != lt.n || covered != (int64_t)Hc * Wc) ++wrong;
+    for (int by = 0; by < lr.nby4; ++by)
+        if (planned[(size_t)by] + (block_is_tile_local(lr, by) ? 0 : 1) != 1) ++wrong;
+    return wrong;
+}
 
 #ifdef MMFS_PROFILE_SORT
 extern "C" int mmfs_debug_sort_profile(unsigned long long *out, int reset)
