@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 6   /* 6: + mmfs_sample_forward (plan -> sampler in one kernel)
+#define MMFS_MSDA_ABI_VERSION 7   /* 7: + mmfs_msda_forward_flags (the forward's two formulations, selectable)
+                                   * 6: + mmfs_sample_forward (plan -> sampler in one kernel)
                                    * 5: + MMFS_BWD_DEVICE_CHECKED_LEVELS; the dense forward / grad_value products
                                    *    (mmfs_msda_forward_hybrid*, MMFS_BWD_DENSE_VALUE) are gone: measured slower than
                                    *    the row-gather forward and the matrix-core tile reduce on every shipped geometry */
@@ -86,6 +87,25 @@ int mmfs_msda_forward(int dtype,
                       const void *loc, const void *attn, void *out,
                       int64_t B, int64_t S, int64_t H, int64_t D,
                       int64_t L, int64_t Nq, int64_t P, void *stream);
+
+/*
+ * The same forward with the formulation chosen by the caller (tests, measurements; mmfs_msda_forward is
+ * flags = 0).  Two kernels implement it:
+ *   row gather   (csrc/msda_fwd.hip)      every sample's four pixel rows through the vector-memory path;
+ *                any storage type, any head width;
+ *   LDS levels   (csrc/msda_fwd_mma.hip)  16-bit storage, D in {64, 128}, L <= 64: the levels of the pyramid
+ *                that fit in the CU's LDS (smallest first, decided on the device from the table) are copied
+ *                there once per workgroup and sampled by the matrix cores, the others by row gather.
+ * flags = 0 picks LDS levels when the shape allows it and a (b, h) slab has at least 256 queries.
+ * MMFS_FWD_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED.
+ */
+#define MMFS_FWD_ROW_GATHER 1u
+#define MMFS_FWD_LDS_LEVELS 2u
+int mmfs_msda_forward_flags(int dtype,
+                            const void *value, const int64_t *shapes, const int64_t *start,
+                            const void *loc, const void *attn, void *out,
+                            int64_t B, int64_t S, int64_t H, int64_t D,
+                            int64_t L, int64_t Nq, int64_t P, unsigned flags, void *stream);
 
 /* Flags of mmfs_msda_backward(). */
 #define MMFS_BWD_CANONICAL_LEVELS 1u

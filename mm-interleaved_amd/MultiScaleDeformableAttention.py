@@ -40,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 6
+_ABI_VERSION = 7
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -51,6 +51,8 @@ _lib.mmfs_msda_status_string.restype = ctypes.c_char_p
 _lib.mmfs_msda_status_string.argtypes = [_int]
 _lib.mmfs_msda_forward.restype = _int
 _lib.mmfs_msda_forward.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [_vp]
+_lib.mmfs_msda_forward_flags.restype = _int
+_lib.mmfs_msda_forward_flags.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [ctypes.c_uint, _vp]
 _lib.mmfs_msda_backward.restype = _int
 _lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp]
 _lib.mmfs_msda_backward_workspace_bytes.restype = _i64
@@ -214,11 +216,17 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     with _on_device(value.device):
         stream = _stream(value.device)
         status = _launch(
-            "msda_fwd", value.device, _lib.mmfs_msda_forward, code, value.data_ptr(), spatial_shapes.data_ptr(),
+            "msda_fwd", value.device, _lib.mmfs_msda_forward_flags, code, value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-            out.data_ptr(), *dims, stream)
+            out.data_ptr(), *dims, _FWD_FLAGS[_fwd_algo], stream)
     _check(status, "ms_deform_attn_forward")
     return out
+
+
+# tests / measurements: which formulation of the forward runs (include/mmfs_msda.h, mmfs_msda_forward_flags):
+# "auto" | "gather" (csrc/msda_fwd.hip) | "lds" (csrc/msda_fwd_mma.hip; unsupported shapes raise)
+_fwd_algo = "auto"
+_FWD_FLAGS = {"auto": 0, "gather": 1, "lds": 2}
 
 
 # flags of mmfs_msda_backward (include/mmfs_msda.h)

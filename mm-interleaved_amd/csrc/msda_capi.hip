@@ -70,6 +70,14 @@ int mmfs_msda_forward(int dtype, const void *value, const int64_t *shapes, const
                       int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
                       void *stream)
 {
+    return mmfs_msda_forward_flags(dtype, value, shapes, start, loc, attn, out, B, S, H, D, L, Nq, P, 0u, stream);
+}
+
+int mmfs_msda_forward_flags(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                            const void *loc, const void *attn, void *out,
+                            int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                            unsigned flags, void *stream)
+{
     const int es = elem_size(dtype);
     if (!es) return MMFS_E_DTYPE;
     mmfs::Dims d;
@@ -87,7 +95,9 @@ int mmfs_msda_forward(int dtype, const void *value, const int64_t *shapes, const
     const int al = ((D * es) % 16 == 0) ? 16 : es;
     if (misaligned(value, al) || misaligned(out, al) || misaligned(loc, es) || misaligned(attn, es))
         return MMFS_E_ALIGN;
-    return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st);
+    if ((flags & MMFS_FWD_LDS_LEVELS) && !mmfs::fwd_mma_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    const int algo = (flags & MMFS_FWD_LDS_LEVELS) ? 2 : (flags & MMFS_FWD_ROW_GATHER) ? 1 : 0;
+    return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st, algo);
 }
 
 static bool use_tiled(int dtype, const mmfs::Dims &d, unsigned flags)

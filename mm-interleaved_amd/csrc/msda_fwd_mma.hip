@@ -1,0 +1,467 @@
+// msda_fwd_mma.hip -- forward of multi-scale deformable attention for gfx950, second formulation:
+// the SMALL levels of the pyramid live in LDS and are sampled by the matrix cores.
+//
+// Replaces the reference forward
+//   mm_interleaved/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:240-302
+// for 16-bit storage and head widths of 64 / 128 channels.  Why a second formulation (round 2's
+// counters): msda_fwd_vec IS its row stream -- 4 pixel rows per sample through the texture
+// path, 4.29 GB at the north-star shape, and that path returns 64 B per clock per CU whatever level of
+// the cache answers; the unpack + multiply-add of every 16-bit row element keeps the vector ALU busy
+// next to it.  But every level receives the same number of samples whatever its size, and the small
+// levels of the pyramid (16x16 and 8x8: half of all samples at the north star) are 80 KiB per (b, h):
+//
+//   * a 1024-lane workgroup owns a run of queries of ONE (batch, head) and first copies that slab's
+//     small levels into LDS (which levels fit is decided on the device from the level table: smallest
+//     first, until the budget is full), channel-permuted and with a row pitch of D*e + 32 bytes;
+//   * its 16 waves then work on their own: a wave stages the samples of QPW = 1024/D queries, one
+//     sample per lane (locations, bilinear weights), into wave-private LDS records -- no workgroup
+//     barrier after the fill;
+//   * samples of the LARGE levels take the row-gather path of msda_fwd_vec (buffer loads of whole
+//     D*e-byte rows, fp32 multiply-add in the vector ALU, counted software pipeline over the live taps);
+//   * samples of the LDS-resident levels never touch the texture path or the vector ALU's
+//     multiply-adds: the 32 pixel rows of 8 samples x 4 corners of a query are the B operand of
+//     v_mfma_f32_16x16x32_{bf16,f16} (K = row, N = 16 channels), fetched straight out of the LDS image
+//     with the transposing ds_read_b64_tr_b16 (every lane supplies the address of 8 bytes of "its"
+//     row, so the rows of a product are gathered, not contiguous); the A operand holds the queries'
+//     weights -- row 4j the leading 16 bits of the fp32 weight (corner weight x attention weight) of
+//     query j's samples, row 4j+1 the rounded remainder, as in the grad_value product of
+//     msda_bwd_tile.hip: hi + lo carries >= 16 significant bits, inside the storage type's rounding.
+//     The product's rows 4j, 4j+1 land in the 16 lanes that own query j in the row-gather layout, and
+//     the LDS image is channel-permuted so that column n of column group g is channel 8n + g: exactly
+//     accumulator g of lane n.  One product serves ONE query (its B rows are its own), the other
+//     queries' rows of the result are discarded: a non-finite value row reaches the queries that sample
+//     it and no other (cuh:58-81).  Corners outside the map, samples that fail the range test and
+//     samples of zero attention weight point at a row of zeros kept in the image.
+//
+// Bank conflicts of the transposing read (32-lane groups, 8 rows x 32 bytes each): the pitch D*e + 32
+// puts a footprint's x-neighbours 32 bytes apart (mod 256), and every level's line pitch is padded so
+// that its y-neighbours are 64 bytes apart: the four corners of a sample never collide.
+//
+// fp32 storage, other head widths, L > 64 and small query counts stay on msda_fwd_vec (msda_fwd.hip).
+#include "msda_device.h"
+#include "msda_launch.h"
+#include <cstdlib>
+
+namespace mmfs {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMmaWaves = 16;                 // waves per workgroup (one workgroup per CU: the LDS image is shared)
+constexpr int kMmaThreads = kMmaWaves * 64;
+constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
+constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
+constexpr int kLdsTotal = 160 * 1024;         // LDS of a CU (MI355X_MICROARCH.md)
+constexpr int kTabInts = 6;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes
+
+template <typename T> struct FwdMma;
+template <> struct FwdMma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    // fp32 weight -> leading 16 bits, rounded remainder (the difference is exact)
+    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
+        const uint32_t h = __float_as_uint(w) & 0xffff0000u;
+        hi = h >> 16;
+        lo = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(w - __uint_as_float(h)));
+    }
+};
+template <> struct FwdMma<half_t> {
+    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
+        const float c = w != w ? w : fminf(fmaxf(w, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        const _Float16 l = (_Float16)(c - (float)h);
+        hi = (uint32_t)__builtin_bit_cast(uint16_t, h);
+        lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
+    }
+};
+
+// Geometry of the kernel for a head of D channels of 2 bytes.
+template <int D> struct MmaGeom {
+    static constexpr int RB = D * 2;                  // bytes of a pixel row of one head
+    static constexpr int LPI = RB / 16;               // lanes per query in the row-gather layout (16-byte vectors)
+    static constexpr int QPW = 64 / LPI;              // queries a wave works on at a time
+    static constexpr int NG = D / 16;                 // column groups = products per (query, batch of 8 samples)
+    static constexpr int RP = RB + 32;                // pitch of a pixel row in the LDS image
+    static constexpr int QSTRIDE = (2 * kChunk + 1) * 16;       // bytes between the record rows of two queries (+16: banks)
+    static constexpr int WSCR = QPW * QSTRIDE;        // wave-private record bytes
+    static constexpr int TAB_BYTES = ((kMmaMaxLevels * kTabInts * 4 + 64) + 255) & ~255;
+    static constexpr int IMG0 = (TAB_BYTES + kMmaWaves * WSCR + 255) & ~255;    // image offset in the dynamic LDS (256-aligned)
+    static constexpr int IMG_BUDGET = kLdsTotal - IMG0;                           // zero row + resident levels
+    // position (in halfwords) of channel 8 * lig + i inside the LDS image of a pixel row
+    static __device__ __forceinline__ int img_pos(int lig, int i) {
+        if (D == 128) return i * 16 + lig;                                        // [g = i][n = lig]
+        return i < 4 ? i * 16 + lig : (i - 4) * 16 + lig + 8;                     // D == 64: [g = i % 4][n = lig + 8 * (i / 4)]
+    }
+};
+
+// bytes between two lines of a W-pixel-wide level: y-neighbours 64 bytes apart modulo the 256-byte bank row
+template <int D> __host__ __device__ __forceinline__ int line_pitch(int W)
+{
+    const int raw = W * MmaGeom<D>::RP;
+    return raw + ((64 - raw % 256) & 255);
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    // same wave writes and reads: LDS keeps program order; the fences keep the compiler from moving
+    // the accesses of OTHER lanes' data across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+}  // namespace
+
+template <typename T, int D>
+__global__ void __launch_bounds__(kMmaThreads)
+msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+             const int64_t *__restrict__ start, const T *__restrict__ loc,
+             const T *__restrict__ attn, T *__restrict__ out, const Dims d, const int q_per_wg, const int img_budget)
+{
+    typedef MmaGeom<D> G;
+    typedef FwdMma<T> M;
+    typedef Vec16<T> V;
+    constexpr int VEC = 8;
+    constexpr int LPI = G::LPI, QPW = G::QPW, NG = G::NG;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    int *tab = reinterpret_cast<int *>(smem);
+    unsigned char *img = smem + G::IMG0;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    // workgroup -> (b, h, run of queries); h from the block index: a head's slab stays in one XCD's L2
+    const int bid = blockIdx.x;
+    const int h = bid % d.H;
+    const int tq = bid / d.H;
+    const int q_wg0 = (tq % d.q_tiles) * q_per_wg;
+    const int b = tq / d.q_tiles;
+    const int L = d.L;
+
+    const int64_t HD = (int64_t)d.H * d.D;
+    const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
+
+    // ---- level table; which levels live in LDS: smallest first (ties: lower index), while they fit
+    for (int l = tid; l < L; l += kMmaThreads) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        tab[kTabInts * l] = Hl; tab[kTabInts * l + 1] = Wl; tab[kTabInts * l + 2] = (int)start[l];
+        int bytes = (Hl > 0 && Wl > 0) ? 1 << 24 : 0;                     // "never fits"; an empty level takes no room
+        int lp = 0;
+        if (Hl > 0 && Wl > 0 && Hl <= 1024 && Wl <= 1024) {
+            lp = line_pitch<D>(Wl);
+            const int64_t bb = (int64_t)Hl * lp;
+            if (bb < (1 << 24)) bytes = (int)bb;
+        }
+        tab[kTabInts * l + 4] = lp; tab[kTabInts * l + 5] = bytes;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += kMmaThreads) {
+        const int px = tab[kTabInts * l] * tab[kTabInts * l + 1], bytes = tab[kTabInts * l + 5];
+        int cum = 0;
+        for (int l2 = 0; l2 < L; ++l2) {
+            const int px2 = tab[kTabInts * l2] * tab[kTabInts * l2 + 1];
+            if (px2 < px || (px2 == px && l2 <= l)) cum += tab[kTabInts * l2 + 5];
+        }
+        // (cum includes this level; the zero row sits in front of the first level)
+        tab[kTabInts * l + 3] = (cum + G::RP <= img_budget && px > 0) ? G::RP + cum - bytes : -1;
+    }
+    // the zero row
+    if (tid < G::RP / 4) reinterpret_cast<uint32_t *>(img)[tid] = 0u;
+    __syncthreads();
+
+    // ---- fill: resident levels global -> LDS, channel-permuted (16-bit writes: once per workgroup)
+    for (int l = 0; l < L; ++l) {
+        const int base = tab[kTabInts * l + 3];
+        if (base < 0) continue;
+        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
+        const int units = Hl * Wl * LPI;
+        for (int u = tid; u < units; u += kMmaThreads) {
+            const int p = u / LPI, lig = u % LPI;
+            const int y = p / Wl, x = p - y * Wl;
+            const uint32_t goff = (uint32_t)(st + p) < (uint32_t)d.S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
+            const uint4 raw = buffer_load16(rsrc, goff);
+            uint16_t *dst = reinterpret_cast<uint16_t *>(img + base + y * lp + x * G::RP);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                dst[G::img_pos(lig, i)] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+        }
+    }
+    __syncthreads();
+
+    // ---- from here on every wave works on its own
+    unsigned char *wrec = smem + G::TAB_BYTES + wave * G::WSCR;         // records: [QPW][kChunk] x 32 bytes
+    const int qi = lane / LPI, lig = lane % LPI;                          // row-gather role: query of the wave, 16-byte vector
+    const int kk = lane & 15;                                             // staging role: sample of the chunk
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    const bool pair_ok = ((uintptr_t)loc & (2 * sizeof(T) - 1)) == 0;
+    // product roles
+    const int am = lane & 15, akb = lane >> 4;                            // A operand: row m, K block
+    const int a_q = (D == 128) ? (am >> 2) : (2 * (am >> 2) + ((am >> 1) & 1));       // whose weights this row holds
+    const int a_part = (D == 128) ? (am & 3) : (am & 1);                  // 0: hi, 1: lo, (D == 128) 2, 3: zero rows
+    const int bG = lane >> 4, be = (lane >> 2) & 3, bc = lane & 3;        // B operand: K block, corner (row of the read), 8-byte piece
+
+    const int q_wg1 = min(d.Nq, q_wg0 + q_per_wg);
+    for (int q0 = q_wg0 + wave * QPW; q0 < q_wg1; q0 += kMmaWaves * QPW) {
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+        for (int k0 = 0; k0 < d.K; k0 += kChunk) {
+            // ---- the chunk's samples by kind (the same for every query: the level decides)
+            const int k = k0 + kk;
+            const bool k_ok = k < d.K;
+            const int l = k_ok ? k / d.P : 0;
+            const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], lstart = tab[kTabInts * l + 2];
+            const int ibase = tab[kTabInts * l + 3], lp = tab[kTabInts * l + 4];
+            const bool in_lds = k_ok && ibase >= 0;
+            const uint32_t lmask = (uint32_t)__builtin_amdgcn_ballot_w64(in_lds) & 0xffffu;            // by kk (lanes 0..15)
+            const uint32_t gmask = (uint32_t)__builtin_amdgcn_ballot_w64(k_ok && !in_lds) & 0xffffu;
+            const int n_l = __builtin_popcount(lmask);
+            const uint32_t below = (1u << kk) - 1u;
+            // records: row-gather samples from the bottom (index = rank among them), LDS samples from the top
+            const int ridx = in_lds ? kChunk - 1 - __builtin_popcount(lmask & below) : __builtin_popcount(gmask & below);
+
+            wave_sync();                                                  // the previous chunk's records are consumed
+            // ---- stage: one sample per lane, QPW / 4 passes
+            uint32_t live = 0u;                                           // row-gather samples (by kk) that weigh something for some query
+#pragma unroll
+            for (int ps = 0; ps < QPW / 4; ++ps) {
+                const int sq = ps * 4 + (lane >> 4);                      // query of the wave this lane stages
+                const int q = q0 + sq;
+                uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+                bool weighs = false;
+                if (k_ok && q < d.Nq) {
+                    const int64_t s = (((int64_t)b * d.Nq + q) * d.H + h) * d.K + k;
+                    float lx, ly;
+                    load_xy(loc, s, pair_ok, lx, ly);
+                    const float a = to_f32(attn[s]);
+                    const float y = ly * (float)Hl - 0.5f, x = lx * (float)Wl - 0.5f;
+                    // strict comparisons: NaN fails, exactly -1 / Hl / Wl fail (cuh:291)
+                    const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)Hl) && (x < (float)Wl);
+                    const float yf = floorf(y), xf = floorf(x);
+                    const int y0 = inside ? (int)yf : 0, x0 = inside ? (int)xf : 0;
+                    const float fy = inside ? y - yf : 0.f, fx = inside ? x - xf : 0.f;
+                    const float gy = 1.f - fy, gx = 1.f - fx;
+                    // a zero attention weight (an image the token cannot see) reads nothing
+                    const bool on = inside && a != 0.f;
+                    const bool top = y0 >= 0, left = x0 >= 0, bottom = y0 + 1 <= Hl - 1, right = x0 + 1 <= Wl - 1;
+                    const bool ok[4] = {on && top && left, on && top && right, on && bottom && left, on && bottom && right};
+                    // (a corner that contributes nothing weighs nothing: a sample outside the map is not "live")
+                    const float w[4] = {ok[0] ? gy * gx * a : 0.f, ok[1] ? gy * fx * a : 0.f, ok[2] ? fy * gx * a : 0.f, ok[3] ? fy * fx * a : 0.f};
+                    if (in_lds) {
+                        const int o00 = ibase + y0 * lp + x0 * G::RP;
+                        const int off[4] = {o00, o00 + G::RP, o00 + lp, o00 + lp + G::RP};
+                        uint32_t hi[4], lo[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            M::split(w[c], hi[c], lo[c]);
+                        }
+                        r0 = make_uint4(ok[0] ? off[0] : 0, ok[1] ? off[1] : 0, ok[2] ? off[2] : 0, ok[3] ? off[3] : 0);
+                        r1 = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                    } else {
+                        const int p00 = lstart + y0 * Wl + x0;
+                        const int row[4] = {p00, p00 + 1, p00 + Wl, p00 + Wl + 1};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            o[c] = ok[c] ? (uint32_t)row[c] * row_bytes : kOobOffset;
+                        r0 = make_uint4(o[0], o[1], o[2], o[3]);
+                        r1 = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+                        weighs = ((r1.x | r1.y | r1.z | r1.w) << 1) != 0u;                   // (-0 is zero too)
+                    }
+                } else if (!in_lds) {
+                    r0 = make_uint4(kOobOffset, kOobOffset, kOobOffset, kOobOffset);
+                }
+                if (k_ok) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(wrec + sq * G::QSTRIDE + ridx * 32);
+                    dst[0] = r0; dst[1] = r1;
+                }
+                const unsigned long long bl = __builtin_amdgcn_ballot_w64(weighs);
+                live |= (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
+            }
+            wave_sync();
+
+            // ---- row gather of the large levels: counted, software-pipelined walk over the live samples
+            {
+                unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
+                const unsigned gm = (unsigned)__builtin_amdgcn_readfirstlane((int)gmask);
+                const uint4 *recs = reinterpret_cast<const uint4 *>(wrec + qi * G::QSTRIDE);
+                uint4 rawA[4], rawB[4], wA, wB;
+                auto issue = [&](uint4 (&raw)[4], uint4 &ww) {
+                    const int kq = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const int gi = __builtin_popcount(gm & ((1u << kq) - 1u));
+                    const uint4 rr = recs[2 * gi];
+                    ww = recs[2 * gi + 1];
+                    raw[0] = buffer_load16(rsrc, rr.x + lane_off);
+                    raw[1] = buffer_load16(rsrc, rr.y + lane_off);
+                    raw[2] = buffer_load16(rsrc, rr.z + lane_off);
+                    raw[3] = buffer_load16(rsrc, rr.w + lane_off);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto consume = [&](const uint4 (&raw)[4], const uint4 &ww) {
+                    const float w4[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v[VEC];
+                        V::unpack(raw[c], v);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w4[c], v[i], acc[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) asm volatile("" : "+v"(acc[i]));
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                const int n_live = __builtin_popcount(m);
+                if (n_live & 1) { issue(rawA, wA); consume(rawA, wA); }
+                if (n_live >= 2) {
+                    issue(rawA, wA);
+                    for (int i = 2; i < n_live - 1; i += 2) {
+                        issue(rawB, wB);
+                        consume(rawA, wA);
+                        issue(rawA, wA);
+                        consume(rawB, wB);
+                    }
+                    issue(rawB, wB);
+                    consume(rawA, wA);
+                    consume(rawB, wB);
+                }
+            }
+
+            // ---- LDS-resident levels on the matrix cores: batches of 8 samples per query
+            for (int b8 = 0; 8 * b8 < n_l; ++b8) {
+                // A: this lane's 8 weights = samples r0, r0 + 1 (rank among the chunk's LDS samples) x 4 corners
+                s16x8 A;
+                {
+                    const int r0 = 8 * b8 + 2 * akb;
+                    const bool on = (D == 64) || a_part < 2;
+                    uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
+                    const unsigned char *qrec = wrec + a_q * G::QSTRIDE + 16 + 8 * (a_part & 1);
+                    if (on && r0 < n_l) a0 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 1 - r0) * 32);
+                    if (on && r0 + 1 < n_l) a1 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 2 - r0) * 32);
+                    const uint4 aw = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                    A = __builtin_bit_cast(s16x8, aw);
+                }
+#pragma unroll
+                for (int j = 0; j < QPW; ++j) {
+                    // B rows of query j: this lane supplies 8 bytes of corner `be` of samples 2 * bG, 2 * bG + 1
+                    const unsigned char *ad[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r = 8 * b8 + 2 * bG + t;
+                        uint32_t off = 0u;                                               // the zero row
+                        if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + j * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * be);
+                        ad[t] = img + off + 8 * bc;
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        s16x8 Bv;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ad[t] + 32 * g));
+                            Bv[4 * t] = v[0]; Bv[4 * t + 1] = v[1]; Bv[4 * t + 2] = v[2]; Bv[4 * t + 3] = v[3];
+                        }
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 Tv = M::run(A, Bv, zero);
+                        if (D == 128) {
+                            // rows 4j (hi), 4j + 1 (lo) sit in the lanes of query j; column n = lane & 15 is channel 8n + g
+                            const float v = Tv[0] + Tv[1];
+                            if (qi == j) acc[g] += v;
+                        } else {
+                            // D == 64: row quad r = j / 2 spans the lanes of queries 2r and 2r + 1; columns 0..7 are
+                            // accumulator g of lig = n, columns 8..15 accumulator g + 4 of lig = n - 8
+                            const float v = (j & 1) ? Tv[2] + Tv[3] : Tv[0] + Tv[1];
+                            const float vr = dpp_move<0x128>(v);                         // row_ror:8 : lane n <- lane n ^ 8
+                            if (qi == j) {
+                                if (j & 1) { acc[g] += vr; acc[g + 4] += v; }
+                                else { acc[g] += v; acc[g + 4] += vr; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const int q = q0 + qi;
+        if (q < d.Nq) {
+            T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
+            *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launcher
+template <typename T, int D>
+static hipError_t launch_mma(const void *value, const int64_t *shapes, const int64_t *start,
+                             const void *loc, const void *attn, void *out, Dims d, hipStream_t st)
+{
+    typedef MmaGeom<D> G;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_mma<T, D>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    if (once != hipSuccess) return once;
+    static const int env_kb = getenv("MMFS_FWD_MMA_LDS_KB") ? atoi(getenv("MMFS_FWD_MMA_LDS_KB")) : 0;      // tuning / debugging
+    const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(G::IMG0 + 1024, env_kb * 1024)) : kLdsTotal;
+    // queries per workgroup: the image fill (up to IMG_BUDGET bytes through the texture path) is paid per workgroup,
+    // so runs are long; but the grid should still be a few workgroups per CU for the tail
+    int q_per_wg = 256;
+    static const int env_q = getenv("MMFS_FWD_MMA_QPW") ? atoi(getenv("MMFS_FWD_MMA_QPW")) : 0;
+    if (env_q > 0) q_per_wg = env_q;
+    const int unit = kMmaWaves * G::QPW;
+    q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
+    d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
+    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((msda_fwd_mma<T, D>), dim3((unsigned)blocks), dim3(kMmaThreads), lds_total, st,
+                       (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d, q_per_wg,
+                       lds_total - G::IMG0);
+    return hipGetLastError();
+}
+
+bool fwd_mma_supported(int dtype, const Dims &d)
+{
+    if (dtype != 1 && dtype != 2) return false;
+    if (d.D != 128 && d.D != 64) return false;
+    if (d.L > kMmaMaxLevels || d.K <= 0) return false;
+    return (int64_t)d.S * d.H * d.D * 2 <= kMaxSlabBytes;
+}
+
+bool fwd_mma_applies(int dtype, const Dims &d)
+{
+    static const char *algo = getenv("MMFS_FWD_ALGO");                 // "vec": never; "mma": whenever the shape allows
+    if (algo && algo[0] == 'v') return false;
+    if (!fwd_mma_supported(dtype, d)) return false;
+    if (algo && algo[0] == 'm') return true;
+    // the image is filled once per workgroup: worth it from a few hundred queries per (b, h) on
+    return d.Nq >= 256;
+}
+
+hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                       const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st)
+{
+    if (dtype == 1) {
+        if (d.D == 128) return launch_mma<half_t, 128>(value, shapes, start, loc, attn, out, d, st);
+        return launch_mma<half_t, 64>(value, shapes, start, loc, attn, out, d, st);
+    }
+    if (d.D == 128) return launch_mma<bf16_t, 128>(value, shapes, start, loc, attn, out, d, st);
+    return launch_mma<bf16_t, 64>(value, shapes, start, loc, attn, out, d, st);
+}
+
+}  // namespace mmfs

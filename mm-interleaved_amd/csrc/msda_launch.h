@@ -9,8 +9,17 @@
 namespace mmfs {
 
 // dtype codes are enum mmfs_dtype of include/mmfs_msda.h
+// algo: 0 the library chooses, 1 row gather (msda_fwd.hip), 2 LDS-resident levels (msda_fwd_mma.hip; the
+// caller has checked fwd_mma_supported)
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
-                   const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
+                   const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st, int algo = 0);
+
+// Second formulation of the forward for 16-bit storage, D in {64, 128}: small levels resident in LDS and sampled by
+// the matrix cores, large levels by row gather.                                                   [msda_fwd_mma.hip]
+bool fwd_mma_supported(int dtype, const Dims &d);        // the shape allows it
+bool fwd_mma_applies(int dtype, const Dims &d);          // ... and it is expected to pay (the default routing)
+hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                       const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
 
 // Location / attention-weight gradients (always) and, when scatter is true, grad_value
 // accumulated with global float atomics into the fp32 (fp64 for dtype 3) buffer gv_acc,

@@ -52,6 +52,13 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.mmfs_msda_forward(0, *null, -1, 1, 1, 1, 1, 1, 1, None) == -2      # dims
     assert lib.mmfs_msda_forward(0, *null, 1, 1, 1, 1, 1, 1, 1, None) == -3       # null
     assert lib.mmfs_msda_forward(0, *null, 0, 1, 1, 1, 1, 1, 1, None) == 0        # empty batch
+    # the LDS-resident formulation exists for 16-bit storage and heads of 64 / 128 channels only
+    lib.mmfs_msda_forward_flags.restype = ctypes.c_int
+    lib.mmfs_msda_forward_flags.argtypes = [ctypes.c_int] + [vp] * 6 + [i64] * 7 + [ctypes.c_uint, vp]
+    fake = [ctypes.c_void_p(4096)] * 6                                             # aligned, never dereferenced
+    assert lib.mmfs_msda_forward_flags(0, *fake, 1, 64, 1, 128, 1, 1, 1, 2, None) == -5     # fp32
+    assert lib.mmfs_msda_forward_flags(2, *fake, 1, 64, 1, 32, 1, 1, 1, 2, None) == -5      # D = 32
+    assert lib.mmfs_msda_forward_flags(2, *fake, 1, 64, 1, 128, 65, 1, 1, 2, None) == -5    # L > 64
     assert b"dtype" in lib.mmfs_msda_status_string(-1)
     assert lib.mmfs_msda_status_string(-99) is not None
 

@@ -509,3 +509,86 @@ def test_lazy_zero_attention_only_changes_entries_nobody_reads(dtype):
         big = torch.zeros_like(zero)
         big[:, :, :, [0, 3]] = True
         assert float(lazy[2][zero & big].abs().max()) == 0.0 and float(lazy[1][zero & big].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The forward's second formulation (csrc/msda_fwd_mma.hip): levels that fit in LDS live there and are
+# sampled by the matrix cores, the others by row gather.  The default routing takes it from 256 queries per
+# (b, h) slab on; here it is forced (mmfs_msda_forward_flags, MMFS_FWD_LDS_LEVELS) on shapes of every kind.
+LDS_CASES = [
+    # B, H, D, Nq, P, shapes                                           what it exercises
+    (1, 8, 128, 64, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),         # the north-star pyramid: two levels resident, K = 16
+    (2, 3, 128, 333, 4, [(16, 16), (8, 8), (20, 20), (5, 7)]),          # every level resident (two product batches), ragged run
+    (2, 16, 64, 200, 8, [(64, 64), (32, 32), (16, 16), (8, 8)]),        # SD geometry, D = 64 (8 queries per wave), K = 32: two chunks
+    (1, 16, 64, 300, 8, [(32, 32), (16, 16), (8, 8)] * 4),              # LLM n = 4: K = 96; the 8x8 levels and ONE 16x16 level fit
+    (1, 2, 128, 70, 3, [(9, 5), (40, 40), (3, 3), (1, 1), (2, 9)]),     # K = 15: a ragged chunk; non-square and degenerate levels
+    (1, 2, 64, 40, 2, [(3, 3)] * 60),                                   # L = 60, K = 120: eight chunks, everything resident
+    (1, 4, 128, 50, 4, [(70, 70), (50, 50)]),                           # nothing fits: pure row gather inside the new kernel
+    (3, 8, 128, 1, 4, [(16, 16), (8, 8)]),                              # one query (decode)
+    (1, 2, 64, 5000, 4, [(24, 24), (12, 12), (6, 6)]),                  # many runs per (b, h): 20 workgroups per slab
+]
+
+
+def run_fwd(x, dtype, algo):
+    import MultiScaleDeformableAttention as MSDA
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
+    old = MSDA._fwd_algo
+    MSDA._fwd_algo = algo
+    try:
+        out = MSDA.ms_deform_attn_forward(dev(x["value"]), dev(x["shapes"]), dev(x["start"]), dev(x["loc"]), dev(x["attn"]), 1)
+        torch.cuda.synchronize()
+    finally:
+        MSDA._fwd_algo = old
+    return out.double().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", LDS_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in LDS_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lds_levels_forward_matches_oracle(case, dtype):
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=21, loc_range=(-0.15, 1.15), dtype=dtype)
+    x["loc"][0, 0, 0, 0, 0, 0] = float("nan")            # non-finite locations contribute nothing
+    x["loc"][0, Nq // 2, 1 % H, -1, 0, 1] = float("inf")
+    x["attn"][0, Nq - 1, 0, -1] = 0.0                     # zero weights read nothing
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    got = run_fwd(x, dtype, "lds")
+    scale = max(1.0, float(np.abs(want).max()))
+    assert max_abs(got, want) <= TOL[dtype] * scale, f"{case[:5]}: {max_abs(got, want):.3e}"
+    # and against the row-gather kernel: the same fp32 products, sums in another order, weights of the
+    # resident levels carried as hi + lo 16-bit parts (>= 16 significant bits)
+    ref = run_fwd(x, dtype, "gather")
+    assert max_abs(got, ref) <= 0.5 * TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_lds_levels_forward_non_finite_rows_stay_with_their_queries(D):
+    """A product on the matrix cores multiplies every row of its weight operand with every value row it is handed.
+    The kernel gives each query a product of its own, so a non-finite value row reaches the queries that sample
+    it and no other (cuh:58-81); corners outside the map and zero weights point at a row of zeros."""
+    sh, start = level_tables([(4, 4), (2, 2)])
+    H, Nq = 2, 24
+    value = torch.ones(1, 20, H, D, dtype=torch.float64)
+    value[0, 5, 0] = float("inf")                         # pixel (1, 1) of level 0, head 0
+    value[0, 16, 1] = float("nan")                        # pixel (0, 0) of level 1, head 1
+    loc = torch.full((1, Nq, H, 2, 2, 2), 0.875, dtype=torch.float64)        # level 0: pixels (2..3, 2..3); level 1: (1, 1) + outside
+    attn = torch.full((1, Nq, H, 2, 2), 0.25, dtype=torch.float64)
+    loc[0, 3, 0, 0, 0] = torch.tensor([0.375, 0.375])     # query 3, head 0 touches pixel (1, 1) of level 0
+    loc[0, 7, 1, 1, 1] = torch.tensor([0.25, 0.25])       # query 7, head 1 touches pixel (0, 0) of level 1
+    loc[0, 9, 0, 0, 1] = torch.tensor([0.375, 0.375]); attn[0, 9, 0, 0, 1] = 0.0      # zero weight: reads nothing
+    x = dict(value=value, shapes=sh, start=start, loc=loc, attn=attn)
+    got = run_fwd(x, torch.bfloat16, "lds").reshape(Nq, H, D)
+    bad = ~np.isfinite(got).all(-1)
+    want_bad = np.zeros((Nq, H), dtype=bool)
+    want_bad[3, 0] = True; want_bad[7, 1] = True
+    assert (bad == want_bad).all(), np.argwhere(bad != want_bad)
+    assert np.allclose(got[~want_bad], got[0, 0, 0])
+
+
+def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
+    """From 256 queries per (b, h) slab on, 16-bit heads of 64 / 128 channels take the LDS-resident formulation
+    (and the autograd function's outputs and gradients still match the oracle on such a shape)."""
+    x = make_inputs(1, 4, 128, 300, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    a, g = run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "lds")
+    assert max_abs(a, g) == 0.0
+    assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0        # (a different summation order: not bit-equal)
+    check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "auto-routed")
