@@ -3,7 +3,9 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N = 1: plain process.  N > 1: launched by torch.distributed.run, one rank per GPU
-  (RCCL).  W untimed warm-up steps, then exactly K timed steps bracketed by
+  (RCCL) -- by the driver, or by bench.py itself when it finds no WORLD_SIZE (it re-executes under
+  torch.distributed.run on 127.0.0.1; fewer visible GPUs than N is an error, never a silent 1-rank run).
+  W untimed warm-up steps, then exactly K timed steps bracketed by
   barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE
   JSON line.
 
@@ -68,6 +70,10 @@ WORKLOADS = {
     # sample the 16^2 ViT map); 5 of each per ViT forward
     "enc_injector": dict(B=32, Nq=256, H=16, D=32, P=4, shapes=[(32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
     "enc_extractor": dict(B=32, Nq=1344, H=16, D=32, P=4, shapes=[(16, 16)], n=1, dtype="bf16"),
+    # the only workload the reference itself ever timed: ops/tests/speed_test.py:67-88 (bs 32, two levels
+    # 16^2 / 8^2, 128 queries, 64 points per level, 8 heads of 128 channels; fp16, then fp32 via --dtype f32;
+    # its loss is .sum(): --grad ones)
+    "ref_speed_test": dict(B=32, Nq=128, H=8, D=128, P=64, shapes=[(16, 16), (8, 8)], n=1, dtype="f16"),
 }
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
@@ -180,6 +186,33 @@ def cpu_baseline(budget_s=12.0):
                       f"{all_threads} threads and {runs[1][2]} with 1 thread after warm-up"}
 
 
+class ExchangeOverlap:
+    """the feature all-gather overlapped with the op.  issue() launches the RCCL all-gather of this
+    rank's image block on a side stream (after the caller's stream has reached this point), join() makes the
+    caller's stream wait for it -- the bank build that consumes it belongs to the NEXT module call."""
+
+    def __init__(self, device, rank, world):
+        from mmfs_amd import bank
+        self.bank = bank
+        B_local, n, hw, C = 4, 4, 1344, 1024
+        self.n_img = world * B_local * n
+        per_rank = bank.images_per_rank(self.n_img, world)
+        g = torch.Generator(device=device).manual_seed(100 + rank)
+        self.mine = torch.randn(per_rank, hw, C, device=device, generator=g).to(torch.bfloat16)
+        self.side = torch.cuda.Stream(device=device)
+        self.device = device
+        self.out = None
+
+    def issue(self):
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.out = self.bank.all_gather_image_features(self.mine, self.n_img)
+
+    def join(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 def exchange_step(device, rank, world, dist, steps=20):
     """The path's one exchange step at BASELINE config 5's geometry: 4 context images per sequence, LLM
     pyramid (32^2, 16^2, 8^2 -> 1344 tokens) x C = 1024 bf16 = 2.75 MB per image; every rank encodes a
@@ -217,6 +250,35 @@ def exchange_step(device, rank, world, dist, steps=20):
             "bank_us": round(float(t[1]) * 1e3, 1)}
 
 
+def launch_command(argv, gpus, port=None):
+    """The command that starts ``bench.py`` as ``gpus`` ranks of one node, one per GPU over RCCL: what the driver
+    runs for N > 1, and what ``python bench.py --gpus N`` re-executes itself as when nobody did
+    (reference bootstrap: mm_interleaved/utils/misc.py:292-337).  Rendezvous on 127.0.0.1 (the container's
+    hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """--gpus N > 1 without a launcher around it: fail loudly when the node has fewer GPUs, else re-execute under
+    torch.distributed.run and return its exit status.  Never degrades to one rank."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < gpus:
+        print(f"bench.py: --gpus {gpus} but this node shows {have} GPU(s); refusing to run fewer ranks than asked",
+              file=sys.stderr, flush=True)
+        return 2
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return subprocess.run(launch_command(argv, gpus), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,9 +300,23 @@ def main():
     ap.add_argument("--loc-dist", default="uniform", choices=["uniform", "centre"],
                     help="sampling locations: uniform over each level (the contract workload) or clustered "
                          "around one reference point (what the LLM path produces)")
+    ap.add_argument("--fresh-levels", action="store_true",
+                    help="the literal drop-in: spatial_shapes / level_start_index rebuilt as NEW device tensors on every "
+                         "call, as the reference's callers do (modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41) -- the shim "
+                         "has never seen them, the backward checks the table on the device and has no hybrid routing")
+    ap.add_argument("--grad", default="randn", choices=["randn", "ones"],
+                    help="grad_output: N(0,1) or ones (the reference's speed test backpropagates .sum())")
+    ap.add_argument("--exchange-in-step", action="store_true",
+                    help="N > 1: the feature all-gather of BASELINE config 5 is issued on a side stream inside every "
+                         "timed step, overlapping the op (SURVEY 8e); default: timed after the main region")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {args.gpus}, or unset WORLD_SIZE and let bench.py launch its own ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
@@ -251,7 +327,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import MultiScaleDeformableAttention as MSDA
     from mmfs_amd.functions import MSDeformAttnFunction
@@ -268,10 +343,28 @@ def main():
     from mmfs_amd.levels import make_level_tables
     shapes, start, _ = make_level_tables(w["shapes"], w["n"], device)
     value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
+    if args.grad == "ones":
+        grad = torch.ones_like(grad)
+    host_shapes = torch.tensor(w["shapes"] * w["n"], dtype=torch.long)
+
+    overlap = None
+    if args.exchange_in_step and dist is not None:
+        overlap = ExchangeOverlap(device, rank, world)
 
     def step():
-        out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
-        return torch.autograd.grad(out, (value, loc, attn), grad)
+        if overlap is not None:
+            overlap.issue()                     # the all-gather rides a side stream under the op
+        if args.fresh_levels:
+            # what the reference's callers do per call: two new device tensors, nothing registered
+            sh = host_shapes.to(device)
+            st = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+            out = MSDeformAttnFunction.apply(value, sh, st, loc, attn, 1)
+        else:
+            out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
+        res = torch.autograd.grad(out, (value, loc, attn), grad)
+        if overlap is not None:
+            overlap.join()
+        return res
 
     def fence():
         torch.cuda.synchronize()
@@ -369,6 +462,9 @@ def main():
                          "traffic_from": traffic_from,
                          "algorithmic_bytes": ab[dom], "mean_us": round(mean_ms[dom] * 1e3, 2)},
             "kernels_mean_us": {k: round(v * 1e3, 2) for k, v in mean_ms.items()},
+            # event brackets cost a few us each and span a stage's helper launches: their sum may exceed the clean step
+            "event_overhead_us": round(sum(mean_ms.values()) * 1e3 - elapsed / args.steps * 1e6, 2),
+            "levels": "fresh per call, unregistered (reference call pattern)" if args.fresh_levels else "make_level_tables (built once, known to the shim)",
             # whole step against the roofline: algorithmic bytes of forward + backward / the clean step time
             "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -377,10 +473,21 @@ def main():
             res["cpu_baseline"] = cpu_baseline()
     ex = None
     if dist is not None:
+        # every rank says whether it can enter the collectives BEFORE any of them does: a rank that fails
+        # inside its own set-up must not leave the others waiting in an all-gather
+        ok = torch.ones((), dtype=torch.int32, device=device)
         try:
-            ex = exchange_step(device, rank, world, dist)
-        except Exception as e:                      # the headline number does not depend on this step
+            from mmfs_amd import bank as _bank      # noqa: F401
+        except Exception as e:
+            ok.zero_()
             ex = {"error": f"{type(e).__name__}: {e}"}
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            ex = exchange_step(device, rank, world, dist)          # a failure inside a collective propagates: no hang
+            if overlap is not None:
+                ex["in_step"] = "all-gather issued on a side stream in every timed step (its time is inside ms_per_step)"
+        elif ex is None:
+            ex = {"error": "another rank could not set the exchange up"}
     if rank == 0:
         if ex is not None:
             res["exchange"] = ex

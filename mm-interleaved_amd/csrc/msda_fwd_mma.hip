@@ -128,6 +128,22 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 }  // namespace
 
+// Development aid (tools/exp_build.sh fprof "-DMMFS_PROFILE_FWD"; tools/fwd_prof.py): shader clocks per phase of a
+// wave, summed over the waves of a workgroup slot, read back with mmfs_debug_fwd_profile().
+#ifdef MMFS_PROFILE_FWD
+constexpr int kFProfSlots = 4096;
+__device__ unsigned long long g_fwd_prof[kFProfSlots * 8];
+#define FPROF_DECL unsigned long long fprof_c = __builtin_readcyclecounter(), fprof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FPROF(i) do { const unsigned long long tn = __builtin_readcyclecounter(); fprof_t[i] += tn - fprof_c; fprof_c = tn; } while (0)
+#define FPROF_COUNT(i, v) do { fprof_t[i] += (unsigned long long)(v); } while (0)
+#define FPROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_fwd_prof[(blockIdx.x % kFProfSlots) * 8 + i_], fprof_t[i_]); } while (0)
+#else
+#define FPROF_DECL do {} while (0)
+#define FPROF(i) do {} while (0)
+#define FPROF_COUNT(i, v) do {} while (0)
+#define FPROF_FLUSH() do {} while (0)
+#endif
+
 template <typename T, int D>
 __global__ void __launch_bounds__(kMmaThreads)
 msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -146,6 +162,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    FPROF_DECL;
     // workgroup -> (b, h, run of queries); h from the block index: a head's slab stays in one XCD's L2
     const int bid = blockIdx.x;
     const int h = bid % d.H;
@@ -207,6 +224,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     }
     __syncthreads();
 
+    FPROF(0);                                                             // table + fill (incl. waiting for the slowest wave)
     // ---- from here on every wave works on its own
     unsigned char *wrec = smem + G::TAB_BYTES + wave * G::WSCR;         // records: [QPW][kChunk] x 32 bytes
     const int qi = lane / LPI, lig = lane % LPI;                          // row-gather role: query of the wave, 16-byte vector
@@ -219,13 +237,43 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int a_part = (D == 128) ? (am & 3) : (am & 1);                  // 0: hi, 1: lo, (D == 128) 2, 3: zero rows
     const int bG = lane >> 4, be = (lane >> 2) & 3, bc = lane & 3;        // B operand: K block, corner (row of the read), 8-byte piece
 
+    // ---- a wave's work is a sequence of steps: (group of QPW queries) x (chunk of kChunk samples per query).
+    // The locations / weights of step s + 1 are requested while step s gathers, so a step opens with
+    // arithmetic, not with a global round trip.
     const int q_wg1 = min(d.Nq, q_wg0 + q_per_wg);
-    for (int q0 = q_wg0 + wave * QPW; q0 < q_wg1; q0 += kMmaWaves * QPW) {
-        float acc[VEC];
+    const int n_chunks = (d.K + kChunk - 1) / kChunk;
+    const int q_first = q_wg0 + wave * QPW;
+    const int n_groups = q_first < q_wg1 ? (q_wg1 - q_first + kMmaWaves * QPW - 1) / (kMmaWaves * QPW) : 0;
+    const int n_steps = n_groups * n_chunks;
+    constexpr int PS = QPW / 4;                                           // staging passes (one sample per lane each)
+    // (kept as the RAW words: converting them would make the wave wait for the loads on the spot)
+    uint32_t pf_w0[PS], pf_w1[PS], pf_a[PS];
+    auto prefetch = [&](int step) {
+        const int q0 = q_first + (step / n_chunks) * (kMmaWaves * QPW);
+        const int k = (step % n_chunks) * kChunk + kk;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int ps = 0; ps < PS; ++ps) {
+            const int q = q0 + ps * 4 + (lane >> 4);
+            pf_w0[ps] = pf_w1[ps] = pf_a[ps] = 0u;
+            if (step < n_steps && k < d.K && q < d.Nq) {
+                const int64_t s = (((int64_t)b * d.Nq + q) * d.H + h) * d.K + k;
+                const uint16_t *lw = reinterpret_cast<const uint16_t *>(loc) + 2 * s;
+                if (pair_ok) pf_w0[ps] = *reinterpret_cast<const uint32_t *>(lw);
+                else { pf_w0[ps] = lw[0]; pf_w1[ps] = lw[1]; }
+                pf_a[ps] = reinterpret_cast<const uint16_t *>(attn)[s];
+            }
+        }
+    };
+    prefetch(0);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
-        for (int k0 = 0; k0 < d.K; k0 += kChunk) {
+    for (int step = 0; step < n_steps; ++step) {
+        const int q0 = q_first + (step / n_chunks) * (kMmaWaves * QPW);
+        const int chunk = step % n_chunks;
+        const int k0 = chunk * kChunk;
+        {
             // ---- the chunk's samples by kind (the same for every query: the level decides)
             const int k = k0 + kk;
             const bool k_ok = k < d.K;
@@ -240,20 +288,21 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             // records: row-gather samples from the bottom (index = rank among them), LDS samples from the top
             const int ridx = in_lds ? kChunk - 1 - __builtin_popcount(lmask & below) : __builtin_popcount(gmask & below);
 
-            wave_sync();                                                  // the previous chunk's records are consumed
-            // ---- stage: one sample per lane, QPW / 4 passes
+            wave_sync();                                                  // the previous step's records are consumed
+            // ---- stage: one sample per lane, QPW / 4 passes (the sample's words arrived during the previous step)
             uint32_t live = 0u;                                           // row-gather samples (by kk) that weigh something for some query
 #pragma unroll
-            for (int ps = 0; ps < QPW / 4; ++ps) {
+            for (int ps = 0; ps < PS; ++ps) {
                 const int sq = ps * 4 + (lane >> 4);                      // query of the wave this lane stages
                 const int q = q0 + sq;
                 uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
                 bool weighs = false;
                 if (k_ok && q < d.Nq) {
-                    const int64_t s = (((int64_t)b * d.Nq + q) * d.H + h) * d.K + k;
-                    float lx, ly;
-                    load_xy(loc, s, pair_ok, lx, ly);
-                    const float a = to_f32(attn[s]);
+                    // (opaque to the compiler HERE, so that the decode below cannot move up to the loads)
+                    asm volatile("" : "+v"(pf_w0[ps]), "+v"(pf_w1[ps]), "+v"(pf_a[ps]));
+                    const uint32_t xb = pair_ok ? (pf_w0[ps] & 0xffffu) : pf_w0[ps], yb = pair_ok ? (pf_w0[ps] >> 16) : pf_w1[ps];
+                    const float lx = to_f32(__builtin_bit_cast(T, (uint16_t)xb)), ly = to_f32(__builtin_bit_cast(T, (uint16_t)yb));
+                    const float a = to_f32(__builtin_bit_cast(T, (uint16_t)pf_a[ps]));
                     const float y = ly * (float)Hl - 0.5f, x = lx * (float)Wl - 0.5f;
                     // strict comparisons: NaN fails, exactly -1 / Hl / Wl fail (cuh:291)
                     const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)Hl) && (x < (float)Wl);
@@ -299,26 +348,94 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 live |= (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
             }
             wave_sync();
+            FPROF(1);                                                     // stage
 
-            // ---- row gather of the large levels: counted, software-pipelined walk over the live samples
+            // ---- LDS-resident levels on the matrix cores: batches of 8 samples per query
+            auto mma_phase = [&]() {
+                for (int b8 = 0; 8 * b8 < n_l; ++b8) {
+                    // A: this lane's 8 weights = samples r0, r0 + 1 (rank among the chunk's LDS samples) x 4 corners
+                    s16x8 A;
+                    {
+                        const int r0 = 8 * b8 + 2 * akb;
+                        const bool on = (D == 64) || a_part < 2;
+                        uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
+                        const unsigned char *qrec = wrec + a_q * G::QSTRIDE + 16 + 8 * (a_part & 1);
+                        if (on && r0 < n_l) a0 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 1 - r0) * 32);
+                        if (on && r0 + 1 < n_l) a1 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 2 - r0) * 32);
+                        const uint4 aw = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        A = __builtin_bit_cast(s16x8, aw);
+                    }
+#pragma unroll 1
+                    for (int j = 0; j < QPW; ++j) {
+                        // B rows of query j: this lane supplies 8 bytes of corner `be` of samples 2 * bG, 2 * bG + 1
+                        const unsigned char *ad[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int r = 8 * b8 + 2 * bG + t;
+                            uint32_t off = 0u;                                               // the zero row
+                            if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + j * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * be);
+                            ad[t] = img + off + 8 * bc;
+                        }
+                        const bool mine = qi == j;
+                        // four products at a time (independent: they pipeline), then their sums
+#pragma unroll
+                        for (int g0 = 0; g0 < NG; g0 += 4) {
+                            f32x4 Tv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                s16x8 Bv;
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ad[t] + 32 * (g0 + u)));
+                                    Bv[4 * t] = v[0]; Bv[4 * t + 1] = v[1]; Bv[4 * t + 2] = v[2]; Bv[4 * t + 3] = v[3];
+                                }
+                                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                                Tv[u] = M::run(A, Bv, zero);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int g = g0 + u;
+                                if (D == 128) {
+                                    // rows 4j (hi), 4j + 1 (lo) sit in the lanes of query j; column n = lane & 15 is channel 8n + g
+                                    const float v = Tv[u][0] + Tv[u][1];
+                                    acc[g] += mine ? v : 0.f;
+                                    // (rows 2, 3 of the quad are unused, but their registers must stay the product's own:
+                                    // overlapped with the next product's result, the products wait for each other)
+                                    asm volatile("" :: "v"(Tv[u][2]), "v"(Tv[u][3]));
+                                } else {
+                                    // D == 64: row quad r = j / 2 spans the lanes of queries 2r and 2r + 1; columns 0..7 are
+                                    // accumulator g of lig = n, columns 8..15 accumulator g + 4 of lig = n - 8
+                                    const bool odd = j & 1;
+                                    const float v = odd ? Tv[u][2] + Tv[u][3] : Tv[u][0] + Tv[u][1];
+                                    const float vr = dpp_move<0x128>(v);                     // row_ror:8 : lane n <- lane n ^ 8
+                                    acc[g] += mine ? (odd ? vr : v) : 0.f;
+                                    acc[g + 4] += mine ? (odd ? v : vr) : 0.f;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+
+            // ---- row gather of the large levels: counted, software-pipelined walk over the live samples, with the
+            // next step's sample words requested and the matrix-core phase run while the first rows are in flight
             {
                 unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
                 const unsigned gm = (unsigned)__builtin_amdgcn_readfirstlane((int)gmask);
                 const uint4 *recs = reinterpret_cast<const uint4 *>(wrec + qi * G::QSTRIDE);
-                uint4 rawA[4], rawB[4], wA, wB;
-                auto issue = [&](uint4 (&raw)[4], uint4 &ww) {
+                auto issue = [&](uint4 (&raw)[4], int &gi) {
                     const int kq = __builtin_ctz(m);
                     m &= m - 1u;
-                    const int gi = __builtin_popcount(gm & ((1u << kq) - 1u));
+                    gi = __builtin_popcount(gm & ((1u << kq) - 1u));
                     const uint4 rr = recs[2 * gi];
-                    ww = recs[2 * gi + 1];
                     raw[0] = buffer_load16(rsrc, rr.x + lane_off);
                     raw[1] = buffer_load16(rsrc, rr.y + lane_off);
                     raw[2] = buffer_load16(rsrc, rr.z + lane_off);
                     raw[3] = buffer_load16(rsrc, rr.w + lane_off);
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                auto consume = [&](const uint4 (&raw)[4], const uint4 &ww) {
+                auto consume = [&](const uint4 (&raw)[4], int gi) {
+                    const uint4 ww = recs[2 * gi + 1];                    // (the weights wait in LDS, not in registers)
                     const float w4[4] = {__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w)};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -332,80 +449,61 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 const int n_live = __builtin_popcount(m);
-                if (n_live & 1) { issue(rawA, wA); consume(rawA, wA); }
-                if (n_live >= 2) {
-                    issue(rawA, wA);
-                    for (int i = 2; i < n_live - 1; i += 2) {
-                        issue(rawB, wB);
-                        consume(rawA, wA);
-                        issue(rawA, wA);
-                        consume(rawB, wB);
+                if (n_live >= 4 && (n_live & 3) == 0) {
+                    uint4 r0[4], r1[4], r2[4], r3[4];
+                    int g0, g1, g2, g3;
+                    issue(r0, g0); issue(r1, g1); issue(r2, g2); issue(r3, g3);
+                    prefetch(step + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    FPROF(2);                                             // first issues + next step's requests
+                    mma_phase();
+                    __builtin_amdgcn_sched_barrier(0);
+                    FPROF(3);                                             // matrix-core phase
+                    for (int i = 4; i < n_live; i += 4) {
+                        consume(r0, g0); issue(r0, g0);
+                        consume(r1, g1); issue(r1, g1);
+                        consume(r2, g2); issue(r2, g2);
+                        consume(r3, g3); issue(r3, g3);
                     }
-                    issue(rawB, wB);
-                    consume(rawA, wA);
-                    consume(rawB, wB);
-                }
-            }
-
-            // ---- LDS-resident levels on the matrix cores: batches of 8 samples per query
-            for (int b8 = 0; 8 * b8 < n_l; ++b8) {
-                // A: this lane's 8 weights = samples r0, r0 + 1 (rank among the chunk's LDS samples) x 4 corners
-                s16x8 A;
-                {
-                    const int r0 = 8 * b8 + 2 * akb;
-                    const bool on = (D == 64) || a_part < 2;
-                    uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
-                    const unsigned char *qrec = wrec + a_q * G::QSTRIDE + 16 + 8 * (a_part & 1);
-                    if (on && r0 < n_l) a0 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 1 - r0) * 32);
-                    if (on && r0 + 1 < n_l) a1 = *reinterpret_cast<const uint2 *>(qrec + (kChunk - 2 - r0) * 32);
-                    const uint4 aw = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                    A = __builtin_bit_cast(s16x8, aw);
-                }
-#pragma unroll
-                for (int j = 0; j < QPW; ++j) {
-                    // B rows of query j: this lane supplies 8 bytes of corner `be` of samples 2 * bG, 2 * bG + 1
-                    const unsigned char *ad[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int r = 8 * b8 + 2 * bG + t;
-                        uint32_t off = 0u;                                               // the zero row
-                        if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + j * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * be);
-                        ad[t] = img + off + 8 * bc;
-                    }
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        s16x8 Bv;
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ad[t] + 32 * g));
-                            Bv[4 * t] = v[0]; Bv[4 * t + 1] = v[1]; Bv[4 * t + 2] = v[2]; Bv[4 * t + 3] = v[3];
+                    consume(r0, g0); consume(r1, g1); consume(r2, g2); consume(r3, g3);
+                    FPROF(4);                                             // gather loop
+                } else {
+                    prefetch(step + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_phase();
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint4 rawA[4], rawB[4];
+                    int gA, gB;
+                    if (n_live & 1) { issue(rawA, gA); consume(rawA, gA); }
+                    if (n_live >= 2) {
+                        issue(rawA, gA);
+                        for (int i = 2; i < n_live - 1; i += 2) {
+                            issue(rawB, gB);
+                            consume(rawA, gA);
+                            issue(rawA, gA);
+                            consume(rawB, gB);
                         }
-                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        const f32x4 Tv = M::run(A, Bv, zero);
-                        if (D == 128) {
-                            // rows 4j (hi), 4j + 1 (lo) sit in the lanes of query j; column n = lane & 15 is channel 8n + g
-                            const float v = Tv[0] + Tv[1];
-                            if (qi == j) acc[g] += v;
-                        } else {
-                            // D == 64: row quad r = j / 2 spans the lanes of queries 2r and 2r + 1; columns 0..7 are
-                            // accumulator g of lig = n, columns 8..15 accumulator g + 4 of lig = n - 8
-                            const float v = (j & 1) ? Tv[2] + Tv[3] : Tv[0] + Tv[1];
-                            const float vr = dpp_move<0x128>(v);                         // row_ror:8 : lane n <- lane n ^ 8
-                            if (qi == j) {
-                                if (j & 1) { acc[g] += vr; acc[g + 4] += v; }
-                                else { acc[g] += v; acc[g + 4] += vr; }
-                            }
-                        }
+                        issue(rawB, gB);
+                        consume(rawA, gA);
+                        consume(rawB, gB);
                     }
+                    FPROF(5);                                             // the general path, whole
                 }
             }
         }
-        const int q = q0 + qi;
-        if (q < d.Nq) {
-            T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
-            *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+        if (chunk == n_chunks - 1) {
+            const int q = q0 + qi;
+            if (q < d.Nq) {
+                T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
+                *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            FPROF(6);                                                     // store
         }
     }
+    FPROF_COUNT(7, n_steps);
+    FPROF_FLUSH();
 }
 
 // ---------------------------------------------------------------- launcher
@@ -465,3 +563,19 @@ hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, cons
 }
 
 }  // namespace mmfs
+
+#ifdef MMFS_PROFILE_FWD
+extern "C" int mmfs_debug_fwd_profile(unsigned long long *out, int reset)
+{
+    static unsigned long long host[mmfs::kFProfSlots * 8];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(mmfs::g_fwd_prof), sizeof(host));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int s = 0; s < mmfs::kFProfSlots; ++s)
+        for (int i = 0; i < 8; ++i) out[i] += host[s * 8 + i];
+    if (e == hipSuccess && reset) {
+        for (auto &v : host) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_fwd_prof), host, sizeof(host));
+    }
+    return (int)e;
+}
+#endif

@@ -581,7 +581,9 @@ def test_lds_levels_forward_non_finite_rows_stay_with_their_queries(D):
     want_bad = np.zeros((Nq, H), dtype=bool)
     want_bad[3, 0] = True; want_bad[7, 1] = True
     assert (bad == want_bad).all(), np.argwhere(bad != want_bad)
-    assert np.allclose(got[~want_bad], got[0, 0, 0])
+    same = ~want_bad
+    same[9, 0] = False                                     # (the query with the zeroed weight sums to less)
+    assert np.allclose(got[same], got[0, 0, 0]) and got[9, 0, 0] < got[0, 0, 0]
 
 
 def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
