@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 7   /* 7: + mmfs_msda_forward_flags (the forward's two formulations, selectable)
+#define MMFS_MSDA_ABI_VERSION 7   /* 7: + mmfs_msda_forward_flags (the forward's two formulations, selectable);
+                                   *    + mmfs_msda_backward_checked: a level table the device-side check cannot serve is
+                                   *      REPORTED through a status word, no device trap (MMFS_BWD_DEVICE_CHECKED_LEVELS
+                                   *      is refused by mmfs_msda_backward, which has nowhere to report)
                                    * 6: + mmfs_sample_forward (plan -> sampler in one kernel)
                                    * 5: + MMFS_BWD_DEVICE_CHECKED_LEVELS; the dense forward / grad_value products
                                    *    (mmfs_msda_forward_hybrid*, MMFS_BWD_DENSE_VALUE) are gone: measured slower than
@@ -128,9 +131,12 @@ int mmfs_msda_forward_flags(int dtype,
  * rebuild it on every call: modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41) and does not want to pay a
  * device->host copy per backward to find out whether MMFS_BWD_CANONICAL_LEVELS holds.  The sorted
  * backward is taken and the table is checked ON THE DEVICE: any table whose levels do not overlap is
- * served (rows that belong to no level are zero-filled, like the reference's zero-initialised output);
- * overlapping, out-of-range or >= 65536-wide levels make the launch fail loudly (device-side trap) --
- * a caller that builds such tables registers them on the host and gets the float-atomic path. */
+ * served (rows that belong to no level are zero-filled, like the reference's zero-initialised output).
+ * Overlapping, out-of-range or >= 65536-wide levels cannot be served by the sorted backward: the call then
+ * zero-fills grad_value (grad_loc / grad_attn are still exact) and ORs 1 into the caller's status word
+ * (mmfs_msda_backward_checked; the HIP context stays usable -- a caller that builds such tables registers them
+ * on the host and gets the float-atomic path, which serves any table as the reference does, cuh:128-155).
+ * Only mmfs_msda_backward_checked takes this flag. */
 #define MMFS_BWD_DEVICE_CHECKED_LEVELS 32u
 
 /*
@@ -169,6 +175,23 @@ int mmfs_msda_backward(int dtype,
                        void *workspace, int64_t workspace_bytes,
                        int64_t B, int64_t S, int64_t H, int64_t D,
                        int64_t L, int64_t Nq, int64_t P, unsigned flags, void *stream);
+
+/*
+ * The same backward for callers that pass MMFS_BWD_DEVICE_CHECKED_LEVELS: ``table_status`` points at an int32
+ * the device can write (device memory or mapped host memory), owned and zero-initialised by the caller.  When
+ * the device-side check finds a table the sorted backward cannot serve, the launch sequence completes without
+ * touching anything it should not, grad_value is all zeros, and bit 0 of *table_status is set (the reference
+ * would have accumulated overlapping levels with atomics: take MMFS_BWD_FORCE_ATOMIC, or no flag, for those).
+ * Without the flag ``table_status`` is ignored (may be NULL) and the call is mmfs_msda_backward.
+ */
+int mmfs_msda_backward_checked(int dtype,
+                               const void *value, const int64_t *shapes, const int64_t *start,
+                               const void *loc, const void *attn, const void *grad_out,
+                               void *grad_value, void *grad_loc, void *grad_attn,
+                               void *workspace, int64_t workspace_bytes,
+                               int64_t B, int64_t S, int64_t H, int64_t D,
+                               int64_t L, int64_t Nq, int64_t P, unsigned flags,
+                               int32_t *table_status, void *stream);
 
 /*
  * The two stages of the pixel-stationary backward as separate launches (what

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 __all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "register_level_tables", "library_path",
-           "build_info"]
+           "build_info", "check_level_table_status"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MMFS_MSDA_LIB", os.path.join(_HERE, "libmmfs_msda.so"))
@@ -55,6 +55,8 @@ _lib.mmfs_msda_forward_flags.restype = _int
 _lib.mmfs_msda_forward_flags.argtypes = [_int] + [_vp] * 6 + [_i64] * 7 + [ctypes.c_uint, _vp]
 _lib.mmfs_msda_backward.restype = _int
 _lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp]
+_lib.mmfs_msda_backward_checked.restype = _int
+_lib.mmfs_msda_backward_checked.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp, _vp]
 _lib.mmfs_msda_backward_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_taps.restype = _int
@@ -198,10 +200,46 @@ def _launch(name, device, fn, *args):
     return status
 
 
+# ---- level tables the shim has never seen are checked ON THE DEVICE by the backward (no device->host copy per
+# call).  A table the sorted backward cannot serve (overlapping / out-of-range / >= 65536-wide levels) is reported
+# through this word -- one int32 of pinned, device-visible host memory per device, written by the plan kernel -- and
+# raised as a RuntimeError by the next call into the shim (or by check_level_table_status()): no device trap, the
+# HIP context stays usable.  The call that found the table has returned zeros for grad_value by then.
+_status_words = {}
+_BAD_TABLE_MSG = ("ms_deform_attn_backward: an earlier call on this device was handed a level table with overlapping, "
+                  "out-of-range or >= 65536-wide levels that the shim had never seen; that call returned zeros for "
+                  "grad_value.  Register such tables (MultiScaleDeformableAttention.register_level_tables): they then "
+                  "take the float-atomic path, which serves any table as the reference does")
+
+
+def _status_word(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _status_words.get(idx)
+    if w is None:
+        t = torch.zeros(1, dtype=torch.int32).pin_memory()
+        w = _status_words[idx] = (t, t.numpy())
+    return w
+
+
+def check_level_table_status(device=None, synchronize=False):
+    """Raises RuntimeError if a backward on ``device`` (default: every device used so far) met a level table the
+    device-side check refused.  ``synchronize=True`` waits for the device first (a test's use; the op itself
+    only looks at what has already arrived)."""
+    if synchronize:
+        torch.cuda.synchronize(device)
+    words = _status_words.values() if device is None else [_status_word(torch.device(device))]
+    for _, flag in words:
+        if flag[0]:
+            flag[0] = 0
+            raise RuntimeError(_BAD_TABLE_MSG)
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                            im2col_step):
     """Reference: ms_deform_attn_cuda_forward, src/cuda/ms_deform_attn_cuda.cu:21-81."""
     _require(isinstance(value, torch.Tensor) and value.is_cuda, "Not implemented on the CPU")
+    if _status_words:
+        check_level_table_status()
     _validate([("value", value), ("spatial_shapes", spatial_shapes),
                ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                ("attn_weight", attn_weight)], value)
@@ -355,6 +393,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     never reads grad_attn_weight where attn_weight is exactly 0 (MMFS's masked softmax multiplies it
     by the weight), so those entries may come back as 0 without their value rows being read."""
     _require(isinstance(value, torch.Tensor) and value.is_cuda, "Not implemented on the CPU")
+    if _status_words:
+        check_level_table_status()
     _validate([("value", value), ("spatial_shapes", spatial_shapes),
                ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                ("attn_weight", attn_weight), ("grad_output", grad_output)], value)
@@ -395,7 +435,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
             flags |= _BWD_DENSE_TAPS
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
-            key = (code, dims, flags, hs, hst)            # (the host copies live as long as their table tensor)
+            # (keyed by the table's CONTENT: a freed host copy's address can come back with another table)
+            key = (code, dims, flags, info[1].tobytes(), info[2].tobytes())
             hyb_bytes = _ws_cache.get(key)
             if hyb_bytes is None:
                 if len(_ws_cache) > 4096:
@@ -432,6 +473,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             key = (code, dims, flags)
             ws_bytes = _ws_cache.get(key)
             if ws_bytes is None:
+                if len(_ws_cache) > 4096:
+                    _ws_cache.clear()
                 ws_bytes = _ws_cache[key] = _lib.mmfs_msda_backward_workspace_bytes(code, *dims, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes else None
         ws_ptr = ws.data_ptr() if ws is not None else None
@@ -462,11 +505,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             # the library's own sequence: taps + sort + reduce when the level table is canonical and
             # the head width has a vector path, else (odd head width, fp64, gapped or overlapping
             # levels) float-atomic accumulation (needs an fp32 scratch for 16-bit storage)
-            status = _launch("msda_bwd_atomic", value.device, _lib.mmfs_msda_backward, code,
+            word = _status_word(value.device)[0].data_ptr() if (flags & _BWD_DEVICE_CHECKED_LEVELS) else None
+            status = _launch("msda_bwd_atomic", value.device, _lib.mmfs_msda_backward_checked, code,
                              value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                              sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                              grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                             ws_ptr, ws_bytes, *dims, flags, stream)
+                             ws_ptr, ws_bytes, *dims, flags, word, stream)
         _check(status, "ms_deform_attn_backward")
     if loc_dtype != dt:
         grad_loc = grad_loc.to(loc_dtype)

@@ -108,6 +108,7 @@ struct PlanArgs {
     TileHeader *th;
     uint32_t tile_cap_extra, tile_cap_partials;
     const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
+    int32_t *status;                   // where a table the sorted backward cannot serve is reported (device-accessible; may be null)
 };
 
 // The plan: one workgroup's job.  A lane per level for everything that divides (the 64-bit divisions of one
@@ -187,7 +188,10 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     // grad_value row to belong to at most one level: checked here.  Rows that belong to NO level (a
     // table with gaps; canonical tables have none) are zero-filled by zero_uncovered_rows.  Overlapping
     // levels -- the reference would add both levels' gradients into the shared rows -- cannot be served
-    // by this path: loud, device-side failure (callers that know their table take the atomic path).
+    // by this path.  No trap (that would take the whole HIP context down, asynchronously): the plan is emptied --
+    // no tiles, no blocks, no level owns a row, so the sort and the reduce find nothing to do and the zero-fill
+    // pass clears every grad_value row -- and the fact is reported through PlanArgs::status (a word the caller
+    // owns; the Python shim raises at its next call) and CellHeader::pad[2].
     for (int l = tid; l < L && l < kMaxLevels; l += nthr) {
         const LevelRow r = rows[l];
         lv[l] = r;
@@ -215,13 +219,20 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         if (bad) atomicOr(&bad_s, 1);
     }
     __syncthreads();
+    const bool bad = bad_s != 0;
+    if (bad)
+        for (int l = tid; l < L && l < kMaxLevels; l += nthr) {         // no level owns a row: every row is zero-filled
+            lv[l].Hl = lv[l].Wl = 0; lv[l].nbx = lv[l].nby = lv[l].nbx4 = lv[l].nby4 = 0;
+        }
     if (tid == 0) {
-        const bool bad = bad_s != 0;
         hdr->pad[0] = (!bad && covered_all) ? 1 : 0;         // canonical in the sense that matters: every row has exactly one owner
+        hdr->pad[2] = bad ? 1 : 0;
         if (bad) {
-            printf("mmfs_msda backward: level table has overlapping / out-of-range / oversized levels; "
-                   "the sorted backward cannot serve it (register the table on the host to take the atomic path)\n");
-            __builtin_trap();
+            hdr->n_tiles = 0; hdr->n_blocks = 0; hdr->n_cells = 0; hdr->n_blocks4 = 0; hdr->pad[1] = 0;
+            hdr->loc_src = hdr->attn_src = nullptr;
+            if (pa.status != nullptr)            // (system scope: the word may be mapped host memory)
+                __hip_atomic_store(pa.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
         }
     }
 }
@@ -562,7 +573,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
     const bool in_place = hdr->loc_src != nullptr;
     if (in_place) {
-        if (!kept) __builtin_trap();
+        if (!kept) return;          // (a header that does not belong to this launch: nothing is sorted, nothing trapped)
         loc = reinterpret_cast<const T *>(hdr->loc_src); attn = reinterpret_cast<const T *>(hdr->attn_src);
     }
 
@@ -1219,6 +1230,7 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
     pa.cap_slots = sc.cap_slots; pa.cap_entries = sc.cap_entries; pa.cap_partials = sc.cap_partials;
     pa.th = sc.th; pa.tile_cap_extra = sc.tile_cap_extra; pa.tile_cap_partials = sc.tile_cap_partials;
     pa.loc_src = pa.attn_src = nullptr;
+    pa.status = d.table_status;
     return pa;
 }
 

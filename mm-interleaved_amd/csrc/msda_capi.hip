@@ -34,6 +34,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->q_tiles = 0;
     d->lazy_attn = 0;
     d->blocks4 = 0;
+    d->table_status = nullptr;
     return MMFS_OK;
 }
 
@@ -127,11 +128,26 @@ int mmfs_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
                        int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
                        unsigned flags, void *stream)
 {
+    // a table nobody has looked at needs somewhere to report what the device finds
+    if (flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) return MMFS_E_UNSUPPORTED;
+    return mmfs_msda_backward_checked(dtype, value, shapes, start, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                                      workspace, workspace_bytes, B, S, H, D, L, Nq, P, flags, nullptr, stream);
+}
+
+int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                               const void *loc, const void *attn, const void *grad_out,
+                               void *grad_value, void *grad_loc, void *grad_attn,
+                               void *workspace, int64_t workspace_bytes,
+                               int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
+                               unsigned flags, int32_t *table_status, void *stream)
+{
     const int es = elem_size(dtype);
     if (!es) return MMFS_E_DTYPE;
     mmfs::Dims d;
     const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
     if (rc) return rc;
+    if ((flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) && !table_status) return MMFS_E_NULLPTR;
+    d.table_status = (flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) ? table_status : nullptr;
     d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_samples = B * Nq * H * L * P;

@@ -18,6 +18,7 @@ struct Dims {
     int q_tiles;    // ceil(Nq / queries-per-block), filled by the launcher
     int lazy_attn;  // backward: grad_attn / grad_loc of samples whose attention is exactly 0 may be written as 0
     int blocks4;    // backward: 4x4 pixel blocks of all levels when the caller knows the level table on the host (else 0)
+    int32_t *table_status;   // backward, level table checked on the device: where the plan reports a table it cannot serve (or null)
 };
 
 // ---------------------------------------------------------------- storage types

@@ -248,6 +248,10 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     constexpr int PS = QPW / 4;                                           // staging passes (one sample per lane each)
     // (kept as the RAW words: converting them would make the wave wait for the loads on the spot)
     uint32_t pf_w0[PS], pf_w1[PS], pf_a[PS];
+    // (addresses: one 64-bit base per workgroup, 32-bit sample offsets per lane -- fwd_mma_supported bounds them)
+    const uint16_t *loc_wg = reinterpret_cast<const uint16_t *>(loc) + 2 * (((int64_t)b * d.Nq * d.H + h) * d.K);
+    const uint16_t *attn_wg = reinterpret_cast<const uint16_t *>(attn) + (((int64_t)b * d.Nq * d.H + h) * d.K);
+    const uint32_t q_stride = (uint32_t)d.H * (uint32_t)d.K;              // samples between consecutive queries of this head
     auto prefetch = [&](int step) {
         const int q0 = q_first + (step / n_chunks) * (kMmaWaves * QPW);
         const int k = (step % n_chunks) * kChunk + kk;
@@ -256,11 +260,11 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const int q = q0 + ps * 4 + (lane >> 4);
             pf_w0[ps] = pf_w1[ps] = pf_a[ps] = 0u;
             if (step < n_steps && k < d.K && q < d.Nq) {
-                const int64_t s = (((int64_t)b * d.Nq + q) * d.H + h) * d.K + k;
-                const uint16_t *lw = reinterpret_cast<const uint16_t *>(loc) + 2 * s;
+                const uint32_t s = (uint32_t)q * q_stride + (uint32_t)k;
+                const uint16_t *lw = loc_wg + 2 * (size_t)s;
                 if (pair_ok) pf_w0[ps] = *reinterpret_cast<const uint32_t *>(lw);
                 else { pf_w0[ps] = lw[0]; pf_w1[ps] = lw[1]; }
-                pf_a[ps] = reinterpret_cast<const uint16_t *>(attn)[s];
+                pf_a[ps] = attn_wg[s];
             }
         }
     };
@@ -377,7 +381,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                             ad[t] = img + off + 8 * bc;
                         }
                         const bool mine = qi == j;
-                        // four products at a time (independent: they pipeline), then their sums
+                        // four products at a time (independent: they pipeline), then their sums (in the lanes of query j only)
 #pragma unroll
                         for (int g0 = 0; g0 < NG; g0 += 4) {
                             f32x4 Tv[4];
@@ -397,8 +401,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                                 const int g = g0 + u;
                                 if (D == 128) {
                                     // rows 4j (hi), 4j + 1 (lo) sit in the lanes of query j; column n = lane & 15 is channel 8n + g
-                                    const float v = Tv[u][0] + Tv[u][1];
-                                    acc[g] += mine ? v : 0.f;
+                                    if (mine) acc[g] += Tv[u][0] + Tv[u][1];
                                     // (rows 2, 3 of the quad are unused, but their registers must stay the product's own:
                                     // overlapped with the next product's result, the products wait for each other)
                                     asm volatile("" :: "v"(Tv[u][2]), "v"(Tv[u][3]));
@@ -538,6 +541,7 @@ bool fwd_mma_supported(int dtype, const Dims &d)
     if (dtype != 1 && dtype != 2) return false;
     if (d.D != 128 && d.D != 64) return false;
     if (d.L > kMmaMaxLevels || d.K <= 0) return false;
+    if ((int64_t)d.Nq * d.H * d.K >= (1LL << 30)) return false;            // 32-bit sample offsets inside a (b, h) slab
     return (int64_t)d.S * d.H * d.D * 2 <= kMaxSlabBytes;
 }
 
