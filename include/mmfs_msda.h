@@ -99,7 +99,8 @@ int mmfs_msda_forward(int dtype,
  *   LDS levels   (csrc/msda_fwd_mma.hip)  16-bit storage, D in {64, 128}, L <= 64: the levels of the pyramid
  *                that fit in the CU's LDS (smallest first, decided on the device from the table) are copied
  *                there once per workgroup and sampled by the matrix cores, the others by row gather.
- * flags = 0 picks LDS levels when the shape allows it and a (b, h) slab has at least 256 queries.
+ * flags = 0 picks LDS levels for heads of 128 channels when a (b, h) slab has at least 256 queries (heads of
+ * 64 channels measured no faster that way and stay on the row gather unless MMFS_FWD_LDS_LEVELS asks).
  * MMFS_FWD_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED.
  */
 #define MMFS_FWD_ROW_GATHER 1u

@@ -551,8 +551,11 @@ bool fwd_mma_applies(int dtype, const Dims &d)
     if (algo && algo[0] == 'v') return false;
     if (!fwd_mma_supported(dtype, d)) return false;
     if (algo && algo[0] == 'm') return true;
-    // the image is filled once per workgroup: worth it from a few hundred queries per (b, h) on
-    return d.Nq >= 256;
+    // the image is filled once per workgroup: worth it from a few hundred queries per (b, h) on.  Heads of 64
+    // channels (the decoders' real geometry: 128-byte rows, 8 queries per wave) measured no faster than the
+    // row-gather kernel (profiles/r03_experiments.md, r03c: SD block 364 vs 345 us, LLM 4 images 250 vs 248):
+    // they stay on msda_fwd_vec unless asked for (MMFS_FWD_LDS_LEVELS / MMFS_FWD_ALGO=mma)
+    return d.D == 128 && d.Nq >= 256;
 }
 
 hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

@@ -12,6 +12,7 @@ Used by every ``cross_attention_frequency``-th decoder layer
 scope.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from ..levels import make_level_tables
@@ -82,13 +83,97 @@ class LlamaMMFSAttention(nn.Module):
         self.norm1 = MMFSRMSNorm(config.hidden_size, eps=eps)
         self.norm2 = MMFSRMSNorm(self.vision_hidden_size, eps=eps)
 
-    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None):
+    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None):
         """hidden_states [B, Lq, hidden]; vision_hidden_states [B, n, sum hw, image_embed_dim];
-        cross_attention_mask [B, Lq', n] (float, 1 = visible) -> [B, Lq, hidden]."""
+        cross_attention_mask [B, Lq', n] (float, 1 = visible) -> [B, Lq, hidden].
+        ``value`` (an addition): this layer's ``value_proj(norm2(vision_hidden_states))`` [B, n, sum hw, d_inner] as
+        a ``LlamaMMFSSchedule`` projected it for all layers at once; the bank is then only looked at for its shape."""
         hidden_states = self.norm1(hidden_states)
-        vision_hidden_states = self.norm2(vision_hidden_states)
+        if value is None:
+            vision_hidden_states = self.norm2(vision_hidden_states)
         ref, shapes, start = deform_inputs(hidden_states, vision_hidden_states, self.spatial_shapes)
         out = self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                         input_spatial_shapes=shapes, input_level_start_index=start,
-                        input_padding_mask=None, attention_mask=cross_attention_mask)
+                        input_padding_mask=None, attention_mask=cross_attention_mask, value=value)
         return out * self.gate.tanh()
+
+
+class ProjectedBank:
+    """``value_proj_k(norm2_k(bank))`` of every MMFS layer of a decoder for one feature bank: ``values[k]`` is
+    layer k's [B, n, sum hw, d_inner] (contiguous).  Made by ``LlamaMMFSSchedule.project``."""
+
+    def __init__(self, values, bank, source=None, weights=None):
+        self.values, self.bank = values, bank
+        self.source, self.weights = source, weights      # identity cache: (tensor, version), parameter signature
+
+    def matches(self, bank, weights):
+        return (self.source is not None and bank is self.source[0] and bank._version == self.source[1]
+                and weights == self.weights)
+
+
+class LlamaMMFSSchedule:
+    """The MMFS layers of a decoder, organised once (SURVEY 8f N3's idea on the LLM side).
+
+    Every ``cross_attention_frequency``-th decoder layer owns a ``LlamaMMFSAttention`` (8 of 32 at 7B, 10 of 40
+    at 13B: modeling_llama_mmfs.py:581-583) and ALL of them RMS-normalise and ``value_proj`` the SAME feature bank
+    (:352-353; ops/modules/mmfs.py:165); while generating, the bank does not even change between decode steps
+    (mm_interleaved.py:598-664, utils/causal_lm_cascade.py:139-153).  Same mathematics:
+
+      * one normalisation: RMS statistics do not depend on the layer, only the gain does, and it folds into the
+        projection: ``value_proj_k(g_k * xhat) = (W_k diag g_k) xhat + b_k``;
+      * one batched GEMM ``[tokens, d_value] x [n_layers, d_value, d_inner]`` for all layers' projections (each
+        layer's result contiguous);
+      * outside autograd the projections are kept for as long as the caller passes the same, unmodified bank
+        tensor and the parameters that went in do not move (identity + version counters): a decode step then
+        runs no bank-sized kernel at all.
+
+    ``schedule = LlamaMMFSSchedule(layers)``; per forward of the decoder ``bank = schedule.project(features)``
+    and layer k is called as ``layers[k](hidden, features, mask, value=bank.values[k])``.
+    Differentiable: gradients reach every ``W_k``, ``b_k``, ``g_k`` and the features."""
+
+    cache_projected_bank = True
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        assert self.layers and all(isinstance(l, LlamaMMFSAttention) for l in self.layers)
+        self._projected = None
+
+    def can_fuse(self):
+        n0, v0 = self.layers[0].norm2, self.layers[0].attn.value_proj
+        return all(l.norm2.weight.shape == n0.weight.shape and l.norm2.variance_epsilon == n0.variance_epsilon
+                   and l.attn.value_proj.weight.shape == v0.weight.shape
+                   and (l.attn.value_proj.bias is None) == (v0.bias is None) for l in self.layers)
+
+    def _weights(self):
+        return tuple((p.data_ptr(), p._version) for l in self.layers
+                     for p in (l.norm2.weight, l.attn.value_proj.weight, l.attn.value_proj.bias) if p is not None)
+
+    def _project(self, bank):
+        norm = self.layers[0].norm2
+        var = bank.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        xhat = bank * torch.rsqrt(var + norm.variance_epsilon)
+        if norm.weight.dtype in (torch.float16, torch.bfloat16):
+            xhat = xhat.to(norm.weight.dtype)
+        # [n_layers, d_value, d_inner]: W_k^T with the gain folded into its rows
+        wt = torch.stack([(l.attn.value_proj.weight * l.norm2.weight).t() for l in self.layers])
+        y = torch.matmul(xhat.reshape(1, -1, xhat.shape[-1]).to(wt.dtype), wt)         # [n_layers, tokens, d_inner]
+        if self.layers[0].attn.value_proj.bias is not None:
+            y = y + torch.stack([l.attn.value_proj.bias for l in self.layers])[:, None, :]
+        return [y[k].view(*bank.shape[:-1], -1) for k in range(len(self.layers))]
+
+    def project(self, vision_hidden_states):
+        """[B, n, sum hw, image_embed_dim] -> ``ProjectedBank`` (kept across calls outside autograd)."""
+        if not self.can_fuse():         # the reference's schedule, layer by layer
+            return ProjectedBank([l.attn.value_proj(l.norm2(vision_hidden_states)) for l in self.layers],
+                                 vision_hidden_states)
+        keep = self.cache_projected_bank and not torch.is_grad_enabled()
+        sig = self._weights()
+        if keep and self._projected is not None and self._projected.matches(vision_hidden_states, sig):
+            return self._projected
+        proj = ProjectedBank(self._project(vision_hidden_states), vision_hidden_states,
+                             (vision_hidden_states, vision_hidden_states._version), sig)
+        self._projected = proj if keep else None
+        return proj
+
+    def clear_cache(self):
+        self._projected = None

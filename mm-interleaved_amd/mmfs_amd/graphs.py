@@ -12,6 +12,7 @@ allocates nothing, and never synchronises (tests/test_modules_gpu.py checks the 
 """
 import torch
 
+from .blocks.llama_mmfs import LlamaMMFSSchedule, ProjectedBank
 from .blocks.sd_mmfs import MMFSNet, ProjectedFeatures
 
 
@@ -46,5 +47,48 @@ class GraphedMMFSNet:
         assert len(down_block_res_samples) == len(self._res)
         self._sample.copy_(sample)
         torch._foreach_copy_(self._res, list(down_block_res_samples))
+        self.graph.replay()
+        return self._out
+
+
+class GraphedLlamaMMFSStack:
+    """HIP-graph replay of a decoder's MMFS layers for ONE shape of the token stream -- the decode step of a
+    generation loop (one new token per sequence, the bank and the mask fixed: mm_interleaved.py:598-664), where the
+    8-10 layers are ~850 small launches that the host issues several times more slowly than the GPU runs them.
+
+    ``g = GraphedLlamaMMFSStack(layers, hidden, features, mask)`` projects the bank once (LlamaMMFSSchedule), records
+    ``for k: h = h + layers[k](h, features, mask, value=bank.values[k])`` over a static input buffer and
+    ``g(hidden)`` replays it.  The dense LLaMA layers that sit between the MMFS layers in the real decoder are out
+    of scope here (a caller that graphs its whole decode step captures these layers with the rest: the op and the
+    modules are capture-safe as they are -- no device->host copy, current stream, allocator workspaces).
+    Inference only; the result lives in a buffer owned by the graph."""
+
+    def __init__(self, layers, hidden, vision_hidden_states, cross_attention_mask, warmup=2):
+        assert hidden.is_cuda
+        self.layers = list(layers)
+        with torch.no_grad():
+            bank = vision_hidden_states if isinstance(vision_hidden_states, ProjectedBank) \
+                else LlamaMMFSSchedule(self.layers).project(vision_hidden_states)
+            self._bank, self._mask = bank, cross_attention_mask.clone()
+            self._hidden = hidden.clone()
+            side = torch.cuda.Stream(device=hidden.device)
+            side.wait_stream(torch.cuda.current_stream(hidden.device))
+            with torch.cuda.stream(side):          # first calls fill the caches (level tables)
+                for _ in range(warmup):
+                    self._run()
+            torch.cuda.current_stream(hidden.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._out = self._run()
+
+    def _run(self):
+        h = self._hidden
+        for k, layer in enumerate(self.layers):
+            h = h + layer(h, self._bank.bank, self._mask, value=self._bank.values[k])
+        return h
+
+    @torch.no_grad()
+    def __call__(self, hidden):
+        self._hidden.copy_(hidden)
         self.graph.replay()
         return self._out

@@ -376,3 +376,76 @@ def test_bank_from_levels_equals_pack_then_gather():
     got = bank.gather_bank(levels, src)
     assert torch.equal(got[0], bank.pack_image_levels(levels)[5]) and float(got[1].abs().max()) == 0.0
     assert float(got[3].abs().max()) == 0.0          # past the last image: an empty slot, not a clamp
+
+
+def _llama_stack(n_layers, seed=0):
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    cfg = types.SimpleNamespace(hidden_size=64, num_attention_heads=4, rms_norm_eps=1e-6,
+                                max_position_embeddings=64, image_embed_dim=32, spatial_shapes=[8, 4, 2])
+    g = torch.Generator().manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        layers = [LlamaMMFSAttention(cfg, layer_idx=4 * i).double() for i in range(n_layers)]
+    with torch.no_grad():
+        for l in layers:                                    # nothing at its (zero / one) initial value
+            for p in l.parameters():
+                if p.requires_grad:
+                    p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.3 + (1.0 if p.dim() == 1 and p.numel() > 1 else 0.0))
+    return layers
+
+
+def test_llama_schedule_equals_the_references_layer_by_layer(oracle_op):
+    """The decoder's MMFS layers all normalise and project the SAME bank (modeling_llama_mmfs.py:352-353, 581-583):
+    one RMS pass with the gains folded into the projections and one batched GEMM (LlamaMMFSSchedule) give the
+    outputs and EVERY gradient of the reference's schedule -- norm2 + value_proj inside each layer."""
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    layers = _llama_stack(3)
+    g = torch.Generator().manual_seed(1)
+    B, Lq, n, hw = 2, 5, 2, 64 + 16 + 4
+    hidden = torch.randn(B, Lq, 64, generator=g, dtype=torch.float64)
+    feats = torch.randn(B, n, hw, 32, generator=g, dtype=torch.float64)
+    mask = torch.tensor([[[1, 1]] * Lq, [[1, 0]] * Lq], dtype=torch.float32)
+    go = torch.randn(B, Lq, 64, generator=g, dtype=torch.float64)
+
+    def run(fused):
+        for l in layers:
+            l.zero_grad()
+        h0 = hidden.clone().requires_grad_(True); f0 = feats.clone().requires_grad_(True)
+        bank = LlamaMMFSSchedule(layers).project(f0) if fused else None
+        h = h0
+        for k, l in enumerate(layers):
+            h = h + (l(h, f0, mask, value=bank.values[k]) if fused else l(h, f0, mask))
+        h.backward(go)
+        return h.detach(), h0.grad, f0.grad, {n_: p.grad.clone() for l in layers for n_, p in l.named_parameters() if p.grad is not None}
+
+    ref, fus = run(False), run(True)
+    close(fus[0], ref[0].numpy(), 1e-10)
+    close(fus[1], ref[1].numpy(), 1e-10)
+    # (the gradient w.r.t. the bank passes through the norm's fp32 statistics -- the reference computes them in
+    # fp32 whatever the input type, modeling_llama_mmfs.py:61-63 -- once here, once per layer there: fp32 rounding)
+    close(fus[2], ref[2].numpy(), 1e-6)
+    assert ref[3].keys() == fus[3].keys() and len(ref[3]) >= 12
+    for k in ref[3]:
+        close(fus[3][k], ref[3][k].numpy(), 1e-9)
+
+
+def test_llama_schedule_keeps_the_projected_bank_only_while_nothing_moves():
+    """Outside autograd (generation: the bank is constant across decode steps, mm_interleaved.py:598-664) the
+    projections are kept for the same, unmodified bank tensor and parameters; anything else recomputes."""
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    layers = _llama_stack(2, seed=3)
+    sched = LlamaMMFSSchedule(layers)
+    feats = torch.randn(1, 1, 84, 32, dtype=torch.float64)
+    with torch.no_grad():
+        a = sched.project(feats)
+        assert sched.project(feats) is a                                   # same tensor, same version: kept
+        feats.mul_(2.0)
+        b = sched.project(feats)
+        assert b is not a                                                  # modified in place: recomputed
+        layers[1].norm2.weight.add_(0.1)
+        c = sched.project(feats)
+        assert c is not b and not torch.equal(c.values[1], b.values[1]) and torch.equal(c.values[0], b.values[0])
+        assert sched.project(feats.clone()) is not c                       # another tensor object
+    d = sched.project(feats)                                               # with autograd: never kept
+    assert d is not c and sched._projected is None
+    for k, l in enumerate(layers):
+        assert torch.allclose(d.values[k], l.attn.value_proj(l.norm2(feats)), atol=1e-12)

@@ -146,6 +146,56 @@ def test_mmfs_16bit_on_gpu(name, dtype, tol, ftol, qtol):
     assert e_out <= tol and e_f <= ftol and e_q <= qtol
 
 
+@pytest.mark.parametrize("name", P48_CASES + ["mmfs_llm_mask3d", "mmfs_sd_mask2d"])
+@pytest.mark.parametrize("dtype,qtol,ftol", [(torch.float16, 1e-2, 6e-3), (torch.bfloat16, 4e-2, 4e-2)])
+def test_mmfs_16bit_gradients_against_fp64_on_the_same_cells(name, dtype, qtol, ftol, monkeypatch):
+    """What the bars of test_mmfs_16bit_on_gpu cannot catch: grad_query there is compared with a
+    reference whose fp64 locations fall into OTHER pixel cells than the module's 16-bit ones, so 0.25 / 0.5 only
+    exclude a wrong sign.  Here the comparison is against the same module in fp64 on the CPU (oracle op, the very
+    parameters and inputs the 16-bit run rounded) that samples at the 16-bit run's OWN locations -- the tensor the
+    device module handed to the op is captured and put in the fp64 forward's place, straight-through for the
+    gradient -- so both differentiate the same bilinear cells and what is left is rounding: 1e-2 / 4e-2 norm-wise."""
+    import mmfs_amd.modules.mmfs as mm
+    from mmfs_amd.modules import MMFS
+    from oracle.msda_oracle import OracleMSDAFunction
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    real = mm.MSDeformAttnFunction
+    seen = {}
+
+    class Capture:
+        @staticmethod
+        def apply(value, shapes, start, loc, attn, *rest):
+            seen["loc"] = loc.detach().double().cpu()
+            return real.apply(value, shapes, start, loc, attn, *rest)
+
+    monkeypatch.setattr(mm, "MSDeformAttnFunction", Capture)
+    m16, out16, q16, f16 = run_mmfs(z, dtype)
+    assert "loc" in seen
+
+    class SameCells:
+        @staticmethod
+        def apply(value, shapes, start, loc, attn, *rest):
+            assert loc.shape == seen["loc"].shape
+            loc_st = loc + (seen["loc"] - loc).detach()        # the 16-bit run's locations, the fp64 run's gradient path
+            return OracleMSDAFunction.apply(value, shapes, start, loc_st, attn, *rest[:1])
+
+    monkeypatch.setattr(mm, "MSDeformAttnFunction", SameCells)
+    rt = lambda a: torch.from_numpy(np.asarray(a)).to(dtype).double()            # what the device run saw
+    with contextlib.redirect_stdout(io.StringIO()):
+        m64 = MMFS(**cfg).double()
+    m64.load_state_dict({k: v.detach().double().cpu() for k, v in m16.state_dict().items()}, strict=False)
+    q = rt(z["query"]).requires_grad_(True)
+    f = rt(z["feat"]).requires_grad_(True)
+    mask = torch.from_numpy(np.asarray(z["attention_mask"])).float()
+    out = m64(q, rt(z["reference_points"]), f, torch.from_numpy(z["spatial_shapes"]), torch.from_numpy(z["level_start_index"]), None, mask)
+    out.backward(rt(z["grad_out"]))
+    nrm = lambda a, b: float(torch.linalg.norm(a.double().cpu() - b) / max(float(torch.linalg.norm(b)), 1e-30))
+    e_q, e_f, e_o = nrm(q16.grad, q.grad), nrm(f16.grad, f.grad), nrm(out16.detach(), out.detach())
+    print(f"MODULE16-SAMECELLS {name} {str(dtype)[6:]} out {e_o:.2e} grad_query {e_q:.2e} grad_feat {e_f:.2e}")
+    assert e_q <= qtol and e_f <= ftol and e_o <= ftol
+
+
 @pytest.mark.parametrize("name", ["enc_injector", "enc_extractor", "enc_boxes_padded"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 def test_encoder_ms_deform_attn_on_gpu(name, dtype, tol):

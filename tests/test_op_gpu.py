@@ -456,6 +456,14 @@ def test_full_size_properties(name, cfg, dtype):
     _, gl, ga = msda_oracle.backward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"], x["grad"])
     assert max_abs(a.grad[:1, qs].double().cpu().numpy(), ga) <= TOL[dtype] * max(1.0, np.abs(ga).max())
     assert max_abs(l.grad[:1, qs].double().cpu().numpy(), gl) <= TOL[dtype] * max(1.0, np.abs(gl).max())
+    # (3b) grad_value of one whole head of sample 0 -- every level's map, fed by ALL of the sample's queries --
+    # agrees with the CPU oracle (the Euler identity above only holds the sum)
+    h0 = 3 % H
+    x1 = dict(value=value[:1, :, h0:h0 + 1].double().cpu(), shapes=sh.cpu(), start=start.cpu(),
+              loc=loc[:1, :, h0:h0 + 1].double().cpu(), attn=attn[:1, :, h0:h0 + 1].double().cpu(),
+              grad=grad[:1, :, h0 * D:(h0 + 1) * D].double().cpu())
+    gv1, _, _ = msda_oracle.backward(x1["value"], x1["shapes"], x1["start"], x1["loc"], x1["attn"], x1["grad"])
+    assert max_abs(v.grad[:1, :, h0:h0 + 1].double().cpu().numpy(), gv1) <= TOL[dtype] * max(1.0, np.abs(gv1).max())
     # (4) determinism of the forward (no atomics there)
     out2 = MSDeformAttnFunction.apply(value, sh, start, loc, attn, 1)
     assert torch.equal(out2, out.detach())

@@ -86,7 +86,8 @@ def op_bytes(B, Nq, H, D, Leff, P, S, e=2, backward=False):
 
 
 def cfg3():
-    from mmfs_amd.blocks import LlamaMMFSAttention
+    from mmfs_amd.blocks import LlamaMMFSAttention, LlamaMMFSSchedule
+    from mmfs_amd.graphs import GraphedLlamaMMFSStack
     cfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, rms_norm_eps=1e-6,
                                 max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
     torch.manual_seed(0)
@@ -116,7 +117,34 @@ def cfg3():
                 x = x + l(x, feats, mask)
             x.backward(torch.ones_like(x))
 
-        for label, fn, bwd in (("forward", fwd, False), ("forward+backward", train, True)):
+        sched = LlamaMMFSSchedule(layers)
+
+        def fwd_sched(keep):
+            # one RMS pass + one batched projection for all 8 layers; keep: the bank does not change between calls
+            # (decode steps of a generation loop) and the projections are reused
+            with torch.no_grad():
+                if not keep:
+                    sched.clear_cache()
+                bank = sched.project(feats)
+                h = hidden
+                for k, l in enumerate(layers):
+                    h = h + l(h, feats, mask, value=bank.values[k])
+                return h
+
+        def train_sched():
+            h = hidden.clone().requires_grad_(True)
+            bank = sched.project(feats)
+            x = h
+            for k, l in enumerate(layers):
+                x = x + l(x, feats, mask, value=bank.values[k])
+            x.backward(torch.ones_like(x))
+
+        graphed = GraphedLlamaMMFSStack(layers, hidden, feats, mask)
+        cases = [("forward", fwd, False), ("forward, shared normalisation + batched value projection", lambda: fwd_sched(False), False),
+                 ("forward, projected bank kept across calls (decode / generation)", lambda: fwd_sched(True), False),
+                 ("forward, projected bank kept, HIP-graph replay", lambda: graphed(hidden), False),
+                 ("forward+backward", train, True), ("forward+backward, shared normalisation + batched value projection", train_sched, True)]
+        for label, fn, bwd in cases:
             if bwd and Lq == 1:
                 continue
             ms = timed(fn)
