@@ -139,6 +139,15 @@ int mmfs_msda_forward_flags(int dtype,
  * on the host and gets the float-atomic path, which serves any table as the reference does, cuh:128-155).
  * Only mmfs_msda_backward_checked takes this flag. */
 #define MMFS_BWD_DEVICE_CHECKED_LEVELS 32u
+/* grad_loc / grad_attn have two formulations (tests, measurements; default: the library chooses):
+ *   row gather   csrc/msda_bwd.hip, plus -- mmfs_msda_backward_hybrid only -- levels of <= 256 pixels as a DENSE
+ *                matrix-core product over all their pixels (csrc/msda_dense.hip);
+ *   LDS levels   csrc/msda_taps_mma.hip: one kernel for all levels, 16-bit storage, D = 128, L <= 64; the levels that
+ *                fit in the CU's LDS (decided on the device) are contracted on the matrix cores from GATHERED rows,
+ *                the others by row gather.  Default from 256 queries per (b, h) slab on.
+ * MMFS_BWD_TAPS_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
+#define MMFS_BWD_TAPS_ROW_GATHER 64u
+#define MMFS_BWD_TAPS_LDS_LEVELS 128u
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.

@@ -273,7 +273,14 @@ _BWD_FORCE_ATOMIC = 2
 _BWD_DENSE_TAPS = 4
 _BWD_LAZY_ZERO_ATTN = 16
 _BWD_DEVICE_CHECKED_LEVELS = 32
+_BWD_TAPS_ROW_GATHER = 64
+_BWD_TAPS_LDS_LEVELS = 128
 _E_UNSUPPORTED = -5
+
+# tests / measurements: which formulation computes grad_loc / grad_attn (include/mmfs_msda.h):
+# "auto" | "gather" (csrc/msda_bwd.hip + msda_dense.hip) | "lds" (csrc/msda_taps_mma.hip; unsupported shapes raise)
+_taps_algo = "auto"
+_TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS}
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
@@ -411,7 +418,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     dt = value.dtype
     code = _DTYPE_CODE[dt]
     dims = (B, S, H, D, L, Nq, P)
-    flags = _BWD_LAZY_ZERO_ATTN if lazy_zero_attn else 0
+    flags = (_BWD_LAZY_ZERO_ATTN if lazy_zero_attn else 0) | _TAPS_FLAGS[_taps_algo]
     info = None
     if _bwd_algo == "atomic":
         flags |= _BWD_FORCE_ATOMIC

@@ -35,6 +35,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->lazy_attn = 0;
     d->blocks4 = 0;
     d->table_status = nullptr;
+    d->taps_algo = 0;
     return MMFS_OK;
 }
 
@@ -149,6 +150,8 @@ int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shap
     if ((flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) && !table_status) return MMFS_E_NULLPTR;
     d.table_status = (flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) ? table_status : nullptr;
     d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
+    d.taps_algo = (flags & MMFS_BWD_TAPS_LDS_LEVELS) ? 2 : (flags & MMFS_BWD_TAPS_ROW_GATHER) ? 1 : 0;
+    if (d.taps_algo == 2 && !(mmfs::taps_mma_supported(dtype, d) && use_tiled(dtype, d, flags))) return MMFS_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_samples = B * Nq * H * L * P;
     const int64_t n_value = B * S * H * D;
@@ -358,6 +361,8 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     if (rc) return rc;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
     d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
+    d.taps_algo = (flags & MMFS_BWD_TAPS_LDS_LEVELS) ? 2 : (flags & MMFS_BWD_TAPS_ROW_GATHER) ? 1 : 0;
+    if (d.taps_algo == 2 && !mmfs::taps_mma_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
     if (host_shapes) {          // exact grid for the matrix-core grad_value reduce (else a bound is launched)
         int64_t nb4 = 0;
         for (int64_t l = 0; l < L; ++l)
@@ -380,10 +385,15 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     hipError_t e = hipSuccess;
     // (every level dense -- e.g. the ViT-Adapter extractor's single 16x16 map -- leaves the row-gather
     // kernel nothing to write: not launched)
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && !(dense_taps && plan.fine_taps.n == 0))
+    // (one kernel for every level where the LDS-resident formulation applies: the "fine" stage then does all the
+    // levels and the "coarse" stage has nothing left)
+    const bool fused_taps = mmfs::taps_mma_applies(dtype, d);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && fused_taps)
+        e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn, d, false, st, nullptr);
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && !fused_taps && !(dense_taps && plan.fine_taps.n == 0))
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
                                 d, false, st, dense_taps ? &plan.fine_taps : nullptr);
-    if (e == hipSuccess && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
+    if (e == hipSuccess && dense_taps && !fused_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
         e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
     // (the plan rides in the prepare launch only when this very call also sorts; the hybrid path needs
     // MMFS_BWD_CANONICAL_LEVELS, so every grad_value row has an owner and no zero-fill pass is due)

@@ -19,6 +19,7 @@ struct Dims {
     int lazy_attn;  // backward: grad_attn / grad_loc of samples whose attention is exactly 0 may be written as 0
     int blocks4;    // backward: 4x4 pixel blocks of all levels when the caller knows the level table on the host (else 0)
     int32_t *table_status;   // backward, level table checked on the device: where the plan reports a table it cannot serve (or null)
+    int taps_algo;  // backward, grad_loc / grad_attn: 0 the library chooses, 1 row gather (+ dense small levels), 2 LDS-resident levels
 };
 
 // ---------------------------------------------------------------- storage types

@@ -38,95 +38,13 @@
 // that its y-neighbours are 64 bytes apart: the four corners of a sample never collide.
 //
 // fp32 storage, other head widths, L > 64 and small query counts stay on msda_fwd_vec (msda_fwd.hip).
-#include "msda_device.h"
+#include "msda_mma_common.h"
 #include "msda_launch.h"
 #include <cstdlib>
 
 namespace mmfs {
 
-namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kMmaWaves = 16;                 // waves per workgroup (one workgroup per CU: the LDS image is shared)
-constexpr int kMmaThreads = kMmaWaves * 64;
-constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
-constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
-constexpr int kLdsTotal = 160 * 1024;         // LDS of a CU (MI355X_MICROARCH.md)
-constexpr int kTabInts = 6;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes
-
-template <typename T> struct FwdMma;
-template <> struct FwdMma<bf16_t> {
-    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-    // fp32 weight -> leading 16 bits, rounded remainder (the difference is exact)
-    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
-        const uint32_t h = __float_as_uint(w) & 0xffff0000u;
-        hi = h >> 16;
-        lo = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(w - __uint_as_float(h)));
-    }
-};
-template <> struct FwdMma<half_t> {
-    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
-        const float c = w != w ? w : fminf(fmaxf(w, -65504.f), 65504.f);
-        const _Float16 h = (_Float16)c;
-        const _Float16 l = (_Float16)(c - (float)h);
-        hi = (uint32_t)__builtin_bit_cast(uint16_t, h);
-        lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
-    }
-};
-
-// Geometry of the kernel for a head of D channels of 2 bytes.
-template <int D> struct MmaGeom {
-    static constexpr int RB = D * 2;                  // bytes of a pixel row of one head
-    static constexpr int LPI = RB / 16;               // lanes per query in the row-gather layout (16-byte vectors)
-    static constexpr int QPW = 64 / LPI;              // queries a wave works on at a time
-    static constexpr int NG = D / 16;                 // column groups = products per (query, batch of 8 samples)
-    static constexpr int RP = RB + 32;                // pitch of a pixel row in the LDS image
-    static constexpr int QSTRIDE = (2 * kChunk + 1) * 16;       // bytes between the record rows of two queries (+16: banks)
-    static constexpr int WSCR = QPW * QSTRIDE;        // wave-private record bytes
-    static constexpr int TAB_BYTES = ((kMmaMaxLevels * kTabInts * 4 + 64) + 255) & ~255;
-    static constexpr int IMG0 = (TAB_BYTES + kMmaWaves * WSCR + 255) & ~255;    // image offset in the dynamic LDS (256-aligned)
-    static constexpr int IMG_BUDGET = kLdsTotal - IMG0;                           // zero row + resident levels
-    // position (in halfwords) of channel 8 * lig + i inside the LDS image of a pixel row
-    static __device__ __forceinline__ int img_pos(int lig, int i) {
-        if (D == 128) return i * 16 + lig;                                        // [g = i][n = lig]
-        return i < 4 ? i * 16 + lig : (i - 4) * 16 + lig + 8;                     // D == 64: [g = i % 4][n = lig + 8 * (i / 4)]
-    }
-};
-
-// bytes between two lines of a W-pixel-wide level: y-neighbours 64 bytes apart modulo the 256-byte bank row
-template <int D> __host__ __device__ __forceinline__ int line_pitch(int W)
-{
-    const int raw = W * MmaGeom<D>::RP;
-    return raw + ((64 - raw % 256) & 255);
-}
-
-__device__ __forceinline__ void wave_sync()
-{
-    // same wave writes and reads: LDS keeps program order; the fences keep the compiler from moving
-    // the accesses of OTHER lanes' data across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-}  // namespace
+using namespace mma;
 
 // Development aid (tools/exp_build.sh fprof "-DMMFS_PROFILE_FWD"; tools/fwd_prof.py): shader clocks per phase of a
 // wave, summed over the waves of a workgroup slot, read back with mmfs_debug_fwd_profile().
@@ -176,53 +94,8 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
 
-    // ---- level table; which levels live in LDS: smallest first (ties: lower index), while they fit
-    for (int l = tid; l < L; l += kMmaThreads) {
-        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-        tab[kTabInts * l] = Hl; tab[kTabInts * l + 1] = Wl; tab[kTabInts * l + 2] = (int)start[l];
-        int bytes = (Hl > 0 && Wl > 0) ? 1 << 24 : 0;                     // "never fits"; an empty level takes no room
-        int lp = 0;
-        if (Hl > 0 && Wl > 0 && Hl <= 1024 && Wl <= 1024) {
-            lp = line_pitch<D>(Wl);
-            const int64_t bb = (int64_t)Hl * lp;
-            if (bb < (1 << 24)) bytes = (int)bb;
-        }
-        tab[kTabInts * l + 4] = lp; tab[kTabInts * l + 5] = bytes;
-    }
-    __syncthreads();
-    for (int l = tid; l < L; l += kMmaThreads) {
-        const int px = tab[kTabInts * l] * tab[kTabInts * l + 1], bytes = tab[kTabInts * l + 5];
-        int cum = 0;
-        for (int l2 = 0; l2 < L; ++l2) {
-            const int px2 = tab[kTabInts * l2] * tab[kTabInts * l2 + 1];
-            if (px2 < px || (px2 == px && l2 <= l)) cum += tab[kTabInts * l2 + 5];
-        }
-        // (cum includes this level; the zero row sits in front of the first level)
-        tab[kTabInts * l + 3] = (cum + G::RP <= img_budget && px > 0) ? G::RP + cum - bytes : -1;
-    }
-    // the zero row
-    if (tid < G::RP / 4) reinterpret_cast<uint32_t *>(img)[tid] = 0u;
-    __syncthreads();
-
-    // ---- fill: resident levels global -> LDS, channel-permuted (16-bit writes: once per workgroup)
-    for (int l = 0; l < L; ++l) {
-        const int base = tab[kTabInts * l + 3];
-        if (base < 0) continue;
-        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
-        const int units = Hl * Wl * LPI;
-        for (int u = tid; u < units; u += kMmaThreads) {
-            const int p = u / LPI, lig = u % LPI;
-            const int y = p / Wl, x = p - y * Wl;
-            const uint32_t goff = (uint32_t)(st + p) < (uint32_t)d.S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
-            const uint4 raw = buffer_load16(rsrc, goff);
-            uint16_t *dst = reinterpret_cast<uint16_t *>(img + base + y * lp + x * G::RP);
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                dst[G::img_pos(lig, i)] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-        }
-    }
-    __syncthreads();
+    build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
+    fill_image<D, true>(tab, img, rsrc, row_bytes, L, d.S, tid);          // channel-permuted (header)
 
     FPROF(0);                                                             // table + fill (incl. waiting for the slowest wave)
     // ---- from here on every wave works on its own

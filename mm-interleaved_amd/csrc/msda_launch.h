@@ -29,6 +29,13 @@ hipError_t backward_taps(int dtype, const void *value, const int64_t *shapes, co
                          void *gv_acc, void *grad_loc, void *grad_attn, const Dims &d, bool scatter,
                          hipStream_t st, const LevelSel *sel = nullptr);
 bool bwd_has_vector_path(int dtype, const Dims &d);
+// One kernel for all levels, 16-bit storage, D = 128: the levels that fit in LDS contracted on the matrix cores, the
+// others by row gather (replaces msda_bwd_vec + msda_taps_coarse where it applies).             [msda_taps_mma.hip]
+bool taps_mma_supported(int dtype, const Dims &d);
+bool taps_mma_applies(int dtype, const Dims &d);        // supported, expected to pay, and d.taps_algo does not say otherwise
+hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                             const void *loc, const void *attn, const void *grad_out, void *grad_loc, void *grad_attn,
+                             const Dims &d, hipStream_t st);
 
 // grad_value by pixel-stationary tiles: no atomics, no fp32 buffer, every element of
 // grad_value (storage dtype) written exactly once.     [msda_bwd_value.hip]

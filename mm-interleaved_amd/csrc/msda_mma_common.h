@@ -1,0 +1,163 @@
+// msda_mma_common.h -- what the two "LDS-resident levels" kernels share (msda_fwd_mma.hip: forward;
+// msda_taps_mma.hip: grad_loc / grad_attn): the small levels of a (batch, head) slab copied into LDS once per
+// 1024-lane workgroup and sampled by v_mfma_f32_16x16x32 from there, the large levels by row gather.
+//   * geometry of the LDS image (row pitch D*e + 32 bytes, line pitch padded so that a sample's four corners
+//     sit in four different 32-byte bank slots), the level table kept in LDS and the rule that decides on
+//     the device which levels are resident (smallest first, while they fit);
+//   * the image fill (channel-permuted for the forward, whose products' columns must land in the row-gather
+//     accumulators; natural order for the taps kernel, whose products contract over the channels);
+//   * wave-level synchronisation for wave-private LDS records.
+#pragma once
+#include "msda_device.h"
+
+namespace mmfs {
+namespace mma {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMmaWaves = 16;                 // waves per workgroup (one workgroup per CU: the LDS image is shared)
+constexpr int kMmaThreads = kMmaWaves * 64;
+constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
+constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
+constexpr int kLdsTotal = 160 * 1024;         // LDS of a CU (MI355X_MICROARCH.md)
+constexpr int kTabInts = 6;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes
+
+template <typename T> struct FwdMma;
+template <> struct FwdMma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    // fp32 weight -> leading 16 bits, rounded remainder (the difference is exact)
+    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
+        const uint32_t h = __float_as_uint(w) & 0xffff0000u;
+        hi = h >> 16;
+        lo = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(w - __uint_as_float(h)));
+    }
+};
+template <> struct FwdMma<half_t> {
+    static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float w, uint32_t &hi, uint32_t &lo) {
+        const float c = w != w ? w : fminf(fmaxf(w, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        const _Float16 l = (_Float16)(c - (float)h);
+        hi = (uint32_t)__builtin_bit_cast(uint16_t, h);
+        lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
+    }
+};
+
+// Geometry for a head of D channels of 2 bytes; EXTRA: wave-private scratch bytes besides the sample records.
+template <int D, int EXTRA = 0> struct MmaGeom {
+    static constexpr int RB = D * 2;                  // bytes of a pixel row of one head
+    static constexpr int LPI = RB / 16;               // lanes per query in the row-gather layout (16-byte vectors)
+    static constexpr int QPW = 64 / LPI;              // queries a wave works on at a time
+    static constexpr int NG = D / 16;                 // 16-channel column groups of a row
+    static constexpr int RP = RB + 32;                // pitch of a pixel row in the LDS image
+    static constexpr int QSTRIDE = (2 * kChunk + 1) * 16;       // bytes between the record rows of two queries (+16: banks)
+    static constexpr int REC_BYTES = QPW * QSTRIDE;   // wave-private sample records
+    static constexpr int WSCR = REC_BYTES + EXTRA;    // wave-private bytes
+    static constexpr int TAB_BYTES = ((kMmaMaxLevels * kTabInts * 4 + 64) + 255) & ~255;
+    static constexpr int IMG0 = (TAB_BYTES + kMmaWaves * WSCR + 255) & ~255;    // image offset in the dynamic LDS (256-aligned)
+    // position (in halfwords) of channel 8 * lig + i inside the channel-PERMUTED image of a pixel row
+    static __device__ __forceinline__ int img_pos(int lig, int i) {
+        if (D == 128) return i * 16 + lig;                                        // [g = i][n = lig]
+        return i < 4 ? i * 16 + lig : (i - 4) * 16 + lig + 8;                     // D == 64: [g = i % 4][n = lig + 8 * (i / 4)]
+    }
+};
+
+// bytes between two lines of a W-pixel-wide level: y-neighbours 64 bytes apart modulo the 256-byte bank row
+template <int D> __host__ __device__ __forceinline__ int line_pitch(int W)
+{
+    const int raw = W * MmaGeom<D>::RP;
+    return raw + ((64 - raw % 256) & 255);
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    // same wave writes and reads: LDS keeps program order; the fences keep the compiler from moving
+    // the accesses of OTHER lanes' data across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// Level table -> LDS, and which levels live in the image: smallest first (ties: lower index), while they fit
+// behind the zero row.  Call from every thread of the workgroup; ends with a barrier.
+template <int D>
+__device__ __forceinline__ void build_level_table(int *tab, unsigned char *img, const int64_t *__restrict__ shapes,
+                                                  const int64_t *__restrict__ start, int L, int tid, int img_budget)
+{
+    constexpr int RP = MmaGeom<D>::RP;
+    for (int l = tid; l < L; l += kMmaThreads) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        tab[kTabInts * l] = Hl; tab[kTabInts * l + 1] = Wl; tab[kTabInts * l + 2] = (int)start[l];
+        int bytes = (Hl > 0 && Wl > 0) ? 1 << 24 : 0;                     // "never fits"; an empty level takes no room
+        int lp = 0;
+        if (Hl > 0 && Wl > 0 && Hl <= 1024 && Wl <= 1024) {
+            lp = line_pitch<D>(Wl);
+            const int64_t bb = (int64_t)Hl * lp;
+            if (bb < (1 << 24)) bytes = (int)bb;
+        }
+        tab[kTabInts * l + 4] = lp; tab[kTabInts * l + 5] = bytes;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += kMmaThreads) {
+        const int px = tab[kTabInts * l] * tab[kTabInts * l + 1], bytes = tab[kTabInts * l + 5];
+        int cum = 0;
+        for (int l2 = 0; l2 < L; ++l2) {
+            const int px2 = tab[kTabInts * l2] * tab[kTabInts * l2 + 1];
+            if (px2 < px || (px2 == px && l2 <= l)) cum += tab[kTabInts * l2 + 5];
+        }
+        // (cum includes this level; the zero row sits in front of the first level)
+        tab[kTabInts * l + 3] = (cum + RP <= img_budget && px > 0) ? RP + cum - bytes : -1;
+    }
+    if (tid < RP / 4) reinterpret_cast<uint32_t *>(img)[tid] = 0u;        // the zero row
+    __syncthreads();
+}
+
+// Resident levels global -> LDS (once per workgroup).  PERMUTE: channel-permuted (16-bit writes); else natural
+// order (one 16-byte write per lane).  Ends with a barrier.
+template <int D, bool PERMUTE>
+__device__ __forceinline__ void fill_image(const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
+                                           uint32_t row_bytes, int L, int S, int tid)
+{
+    typedef MmaGeom<D> G;
+    for (int l = 0; l < L; ++l) {
+        const int base = tab[kTabInts * l + 3];
+        if (base < 0) continue;
+        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
+        const int units = Hl * Wl * G::LPI;
+        for (int u = tid; u < units; u += kMmaThreads) {
+            const int p = u / G::LPI, lig = u % G::LPI;
+            const int y = p / Wl, x = p - y * Wl;
+            const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
+            const uint4 raw = buffer_load16(rsrc, goff);
+            unsigned char *row = img + base + y * lp + x * G::RP;
+            if (PERMUTE) {
+                uint16_t *dst = reinterpret_cast<uint16_t *>(row);
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    dst[G::img_pos(lig, i)] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+            } else {
+                *reinterpret_cast<uint4 *>(row + lig * 16) = raw;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace mma
+}  // namespace mmfs

@@ -167,3 +167,55 @@ def test_footprint_corners_never_share_a_bank_slot(D):
             offs = [x * g["RP"], (x + 1) * g["RP"], lp + x * g["RP"], lp + (x + 1) * g["RP"]]
             slots = {(o % 256) // 32 for o in offs}
             assert len(slots) == 4, (W, x, offs)
+
+
+def test_taps_wave_model_matches_dots():
+    """csrc/msda_taps_mma.hip: the gathered value rows of 4 samples x 4 corners of ONE query as the A operand
+    (a lane reads 16 bytes of its row out of the natural-order image), the wave's four grad_out rows as the B
+    operand (column n = query n mod 4), K chained over D / 32 steps.  Lane (column j, row quad s) must end up with
+    the four corner dots of sample s of query j."""
+    D, QPW, NKS = 128, 4, 4
+    g = geom(D)
+    RP = g["RP"]
+    rng = np.random.default_rng(7)
+    H, W = 5, 6
+    lp = line_pitch(D, W)
+    base = RP
+    img = np.zeros((base + H * lp) // 2 + 64)                       # halfword array, natural channel order
+    vals = rng.integers(-4, 5, size=(H, W, D)).astype(np.float64)
+    for y in range(H):
+        for x in range(W):
+            img[(base + y * lp + x * RP) // 2:(base + y * lp + x * RP) // 2 + D] = vals[y, x]
+    gout = rng.integers(-3, 4, size=(QPW, D)).astype(np.float64)   # gsh: [query][channel]
+    n_l = 7                                                         # a ragged tile: samples 4..6 in the second tile
+    rec_off = np.zeros((QPW, K_CHUNK, 4), dtype=np.int64)
+    want = np.zeros((QPW, n_l, 4))
+    for q in range(QPW):
+        for r in range(n_l):
+            y0 = int(rng.integers(-1, H)); x0 = int(rng.integers(-1, W))
+            for c in range(4):
+                yy, xx = y0 + (c >> 1), x0 + (c & 1)
+                if 0 <= yy < H and 0 <= xx < W:
+                    rec_off[q, K_CHUNK - 1 - r, c] = base + yy * lp + xx * RP
+                    want[q, r, c] = vals[yy, xx] @ gout[q]
+    got = np.full((QPW, n_l, 4), np.nan)
+    for t4 in range((n_l + 3) // 4):
+        for j in range(QPW):
+            acc = np.zeros((64, 4))
+            for ks in range(NKS):
+                A = np.zeros((64, 8)); B = np.zeros((64, 8))
+                for lane in range(64):
+                    am, akb = lane & 15, lane >> 4
+                    r = 4 * t4 + (am >> 2)
+                    off = rec_off[j, K_CHUNK - 1 - r, am & 3] if r < n_l else 0
+                    a0 = (off + 16 * akb + 64 * ks) // 2
+                    A[lane] = img[a0:a0 + 8]
+                    bn, bkb = lane & 15, lane >> 4
+                    b0 = (4 * ks + bkb) * 8
+                    B[lane] = gout[bn & (QPW - 1), b0:b0 + 8]
+                acc += mfma(A, B)
+            for lane in range(64):
+                rs = 4 * t4 + (lane >> 4)
+                if (lane & 15) == j and rs < n_l:
+                    got[j, rs] = acc[lane]
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)

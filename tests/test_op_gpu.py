@@ -679,3 +679,66 @@ def test_many_points_lds_forward(dtype):
     want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
     got = run_fwd(x, dtype, "lds")
     assert max_abs(got, want) <= TOL[dtype] * max(1.0, float(np.abs(want).max()))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# grad_loc / grad_attn, second formulation (csrc/msda_taps_mma.hip): one kernel for all levels, those that fit in
+# LDS contracted on the matrix cores from gathered rows, the others by row gather.  Default from 256 queries per
+# (b, h) slab on for heads of 128 channels; forced here (MMFS_BWD_TAPS_LDS_LEVELS) on shapes of every kind.
+TAPS_LDS_CASES = [
+    # B, H, D, Nq, P, shapes
+    (1, 8, 128, 64, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),         # the north-star pyramid: two levels resident, K = 16
+    (2, 3, 128, 333, 4, [(16, 16), (8, 8), (20, 20), (5, 7)]),          # every level resident: four tiles per query, ragged run
+    (1, 2, 128, 70, 3, [(9, 5), (40, 40), (3, 3), (1, 1), (2, 9)]),     # K = 15: ragged chunk, ragged last tile, degenerate levels
+    (1, 4, 128, 50, 4, [(70, 70), (50, 50)]),                           # nothing fits: pure row gather inside the new kernel
+    (3, 8, 128, 1, 4, [(16, 16), (8, 8)]),                              # one query
+    (1, 2, 128, 300, 8, [(32, 32), (16, 16), (8, 8)] * 2),              # K = 48: three chunks per query group
+    (2, 8, 128, 128, 64, [(16, 16), (8, 8)]),                           # the reference's speed-test shape: K = 128, all resident
+]
+
+
+@pytest.mark.parametrize("case", TAPS_LDS_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in TAPS_LDS_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("route", ["registered", "fresh"])
+def test_lds_levels_taps_match_oracle(case, dtype, route, monkeypatch):
+    import MultiScaleDeformableAttention as MSDA
+    monkeypatch.setattr(MSDA, "_taps_algo", "lds")
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=17, loc_range=(-0.15, 1.15), dtype=dtype)
+    x["loc"][0, 0, 0, 0, 0, 0] = float("nan")            # non-finite locations: zero gradients
+    x["loc"][0, Nq // 2, 1 % H, -1, 0, 1] = float("inf")
+    x["attn"][0, Nq - 1, 0, -1] = 0.0                     # zero weight: grad_attn is NOT zero, grad_loc is
+    log = []
+    monkeypatch.setattr(MSDA, "_event_log", log)
+    got = run_hip(x, dtype, use_autograd=False, register=(route == "registered"))
+    monkeypatch.setattr(MSDA, "_event_log", None)
+    assert not any("coarse" in n for n, _, _ in log), [n for n, _, _ in log]         # one kernel does every level
+    check(got, run_oracle(x), dtype, f"taps lds {route} {case[:5]}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lds_levels_taps_are_the_default_and_agree_with_the_row_gather(dtype, monkeypatch):
+    """From 256 queries per slab on, heads of 128 channels take the fused kernel; against the row gather + dense pair
+    the same dots come out in another summation order, the algebra after them is the same code."""
+    import MultiScaleDeformableAttention as MSDA
+    x = make_inputs(2, 4, 128, 300, 4, [(24, 24), (16, 16), (8, 8)], seed=19, loc_range=(-0.1, 1.1), dtype=dtype)
+    keep = (torch.rand(2, 300, 1, 3, 1, generator=torch.Generator().manual_seed(1)) < 0.6).double()
+    x["attn"] = (x["attn"] * keep).to(dtype).to(torch.float64)
+    res = {}
+    for algo in ("auto", "lds", "gather"):
+        monkeypatch.setattr(MSDA, "_taps_algo", algo)
+        res[algo] = run_hip(x, dtype, use_autograd=False, register=True)
+    for a, b in zip(res["auto"][2:], res["lds"][2:]):
+        assert max_abs(a, b) == 0.0                                                  # auto IS the fused kernel here
+    want = run_oracle(x)
+    for algo in ("lds", "gather"):
+        check(res[algo], want, dtype, algo)
+    # the lazy hint (MMFS's softmax never reads the gradients of a zero weight): zeros there, the rest bit-equal
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
+    args = [dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn")] + [dev(x["grad"]).reshape(2, 300, -1), 1]
+    monkeypatch.setattr(MSDA, "_taps_algo", "lds")
+    full = MSDA.ms_deform_attn_backward(*args)
+    lazy = MSDA.ms_deform_attn_backward(*args, lazy_zero_attn=True)
+    zero = args[4] == 0
+    assert zero.any() and torch.equal(lazy[2][~zero], full[2][~zero]) and torch.equal(lazy[1][~zero], full[1][~zero])
+    assert not lazy[2][zero].any() and not lazy[1][zero].any()
