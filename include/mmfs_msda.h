@@ -148,6 +148,10 @@ int mmfs_msda_forward_flags(int dtype,
  * MMFS_BWD_TAPS_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
 #define MMFS_BWD_TAPS_ROW_GATHER 64u
 #define MMFS_BWD_TAPS_LDS_LEVELS 128u
+/* 1 when, for these arguments, grad_loc / grad_attn of ALL levels come from the one LDS-levels kernel (the staged
+ * hybrid backward's MMFS_HYB_BWD_TAPS_COARSE stage then has nothing to launch), else 0.  Host-only. */
+int mmfs_msda_backward_taps_fused(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                  int64_t L, int64_t Nq, int64_t P, unsigned flags);
 
 /*
  * Scratch the backward needs for these arguments (0 when none).  Host-only computation.

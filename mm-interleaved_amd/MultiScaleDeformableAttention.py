@@ -57,6 +57,8 @@ _lib.mmfs_msda_backward.restype = _int
 _lib.mmfs_msda_backward.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp]
 _lib.mmfs_msda_backward_checked.restype = _int
 _lib.mmfs_msda_backward_checked.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp, _vp]
+_lib.mmfs_msda_backward_taps_fused.restype = _int
+_lib.mmfs_msda_backward_taps_fused.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_taps.restype = _int
@@ -456,8 +458,15 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                     grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr(), hyb_bytes,
                     *dims, flags)
+            fkey = ("fused", code, dims, flags)
+            fused = _ws_cache.get(fkey)
+            if fused is None:
+                fused = _ws_cache[fkey] = _lib.mmfs_msda_backward_taps_fused(code, *dims, flags)
+
             def run_stages(stages):
                 st = 0
+                if fused:               # one kernel does every level: the dense stage has nothing to launch
+                    stages = tuple(sb for sb in stages if sb[0] != "msda_bwd_taps_coarse")
                 if _event_log is None:
                     bits = sum(bit for _, bit in stages)
                     return _lib.mmfs_msda_backward_hybrid(*args, bits, _stream(value.device))

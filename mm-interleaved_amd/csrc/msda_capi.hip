@@ -111,6 +111,15 @@ static bool use_tiled(int dtype, const mmfs::Dims &d, unsigned flags)
     return (flags & MMFS_BWD_DEVICE_CHECKED_LEVELS) && mmfs::bwd_value_block_supported(dtype, d);
 }
 
+int mmfs_msda_backward_taps_fused(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                  int64_t L, int64_t Nq, int64_t P, unsigned flags)
+{
+    mmfs::Dims d;
+    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
+    d.taps_algo = (flags & MMFS_BWD_TAPS_LDS_LEVELS) ? 2 : (flags & MMFS_BWD_TAPS_ROW_GATHER) ? 1 : 0;
+    return mmfs::taps_mma_applies(dtype, d) ? 1 : 0;
+}
+
 int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
                                            int64_t L, int64_t Nq, int64_t P, unsigned flags)
 {

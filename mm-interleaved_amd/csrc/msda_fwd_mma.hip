@@ -66,7 +66,8 @@ template <typename T, int D>
 __global__ void __launch_bounds__(kMmaThreads)
 msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
              const int64_t *__restrict__ start, const T *__restrict__ loc,
-             const T *__restrict__ attn, T *__restrict__ out, const Dims d, const int q_per_wg, const int img_budget)
+             const T *__restrict__ attn, T *__restrict__ out, const Dims d, const int q_per_wg, const int img_budget,
+             const int n_runs)
 {
     typedef MmaGeom<D> G;
     typedef FwdMma<T> M;
@@ -81,20 +82,23 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     FPROF_DECL;
-    // workgroup -> (b, h, run of queries); h from the block index: a head's slab stays in one XCD's L2
-    const int bid = blockIdx.x;
-    const int h = bid % d.H;
-    const int tq = bid / d.H;
+    const int L = d.L;
+    const int64_t HD = (int64_t)d.H * d.D;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
+    // Persistent workgroups (one per CU: the image takes most of the LDS): workgroup w serves the runs
+    // w, w + grid, w + 2 grid, ... -- the order the dispatcher would have dealt them in (a head's slab stays in
+    // one XCD's L2: run -> (b, h, queries) with h = run mod H, and the grid is a multiple of 8), but every CU
+    // gets the SAME number of runs: dealt dynamically, 1024 runs on 256 CUs left some CUs a fifth run while
+    // others had three, and the kernel took five run-times instead of four (profiles/r03_experiments.md).
+    for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
+    const int h = run % d.H;
+    const int tq = run / d.H;
     const int q_wg0 = (tq % d.q_tiles) * q_per_wg;
     const int b = tq / d.q_tiles;
-    const int L = d.L;
-
-    const int64_t HD = (int64_t)d.H * d.D;
     const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
-
-    build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
+    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
     fill_image<D, true>(tab, img, rsrc, row_bytes, L, d.S, tid);          // channel-permuted (header)
 
     FPROF(0);                                                             // table + fill (incl. waiting for the slowest wave)
@@ -379,6 +383,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
     }
     FPROF_COUNT(7, n_steps);
+    }   // runs
     FPROF_FLUSH();
 }
 
@@ -401,11 +406,12 @@ static hipError_t launch_mma(const void *value, const int64_t *shapes, const int
     const int unit = kMmaWaves * G::QPW;
     q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
-    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_fwd_mma<T, D>), dim3((unsigned)blocks), dim3(kMmaThreads), lds_total, st,
+    const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
+    if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int grid = (int)std::min<int64_t>(runs, persistent_grid());
+    hipLaunchKernelGGL((msda_fwd_mma<T, D>), dim3((unsigned)grid), dim3(kMmaThreads), lds_total, st,
                        (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d, q_per_wg,
-                       lds_total - G::IMG0);
+                       lds_total - G::IMG0, (int)runs);
     return hipGetLastError();
 }
 

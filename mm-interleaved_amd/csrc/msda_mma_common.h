@@ -9,6 +9,7 @@
 //   * wave-level synchronisation for wave-private LDS records.
 #pragma once
 #include "msda_device.h"
+#include <cstdlib>
 
 namespace mmfs {
 namespace mma {
@@ -24,7 +25,8 @@ constexpr int kMmaThreads = kMmaWaves * 64;
 constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
 constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
 constexpr int kLdsTotal = 160 * 1024;         // LDS of a CU (MI355X_MICROARCH.md)
-constexpr int kTabInts = 6;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes
+constexpr int kTabInts = 7;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes, first fill unit
+constexpr int kFillBatch = 7;                 // fill units (16 bytes) a lane moves at most: 7 x 1024 x 16 B = 112 KiB >= any image
 
 template <typename T> struct FwdMma;
 template <> struct FwdMma<bf16_t> {
@@ -93,6 +95,19 @@ template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Workgroups of a persistent launch: one per CU of the current device (rounded down to a multiple of 8, the XCD
+// count, so that run -> XCD stays what the head -> XCD affinity expects); MMFS_MMA_GRID overrides (tuning).
+inline int persistent_grid()
+{
+    static const int n = [] {
+        if (const char *e = getenv("MMFS_MMA_GRID")) if (atoi(e) > 0) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus >= 8 ? cus / 8 * 8 : (cus > 0 ? cus : 256);
+    }();
+    return n;
+}
+
 // Level table -> LDS, and which levels live in the image: smallest first (ties: lower index), while they fit
 // behind the zero row.  Call from every thread of the workgroup; ends with a barrier.
 template <int D>
@@ -125,35 +140,85 @@ __device__ __forceinline__ void build_level_table(int *tab, unsigned char *img, 
     }
     if (tid < RP / 4) reinterpret_cast<uint32_t *>(img)[tid] = 0u;        // the zero row
     __syncthreads();
+    // fill units (one 16-byte piece of a pixel row each) of the resident levels, numbered level after level
+    for (int l = tid; l < L; l += kMmaThreads) {
+        int u0 = 0;
+        for (int l2 = 0; l2 < l; ++l2)
+            if (tab[kTabInts * l2 + 3] >= 0) u0 += tab[kTabInts * l2] * tab[kTabInts * l2 + 1] * MmaGeom<D>::LPI;
+        tab[kTabInts * l + 6] = u0;
+    }
+    __syncthreads();
 }
 
 // Resident levels global -> LDS (once per workgroup).  PERMUTE: channel-permuted (16-bit writes); else natural
-// order (one 16-byte write per lane).  Ends with a barrier.
+// order (one 16-byte write per lane).  Every lane first REQUESTS all its pieces, then writes them: one global
+// round trip per workgroup instead of one per piece (the loop form spent 9 k clocks on five dependent trips).
+// Ends with a barrier.
 template <int D, bool PERMUTE>
 __device__ __forceinline__ void fill_image(const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
                                            uint32_t row_bytes, int L, int S, int tid)
 {
     typedef MmaGeom<D> G;
-    for (int l = 0; l < L; ++l) {
-        const int base = tab[kTabInts * l + 3];
-        if (base < 0) continue;
-        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
-        const int units = Hl * Wl * G::LPI;
-        for (int u = tid; u < units; u += kMmaThreads) {
-            const int p = u / G::LPI, lig = u % G::LPI;
+    int total = 0;
+    for (int l = L - 1; l >= 0; --l)
+        if (tab[kTabInts * l + 3] >= 0) { total = tab[kTabInts * l + 6] + tab[kTabInts * l] * tab[kTabInts * l + 1] * G::LPI; break; }
+    uint4 raw[kFillBatch];
+    int dst[kFillBatch];
+#pragma unroll
+    for (int i = 0; i < kFillBatch; ++i) {
+        const int u = tid + i * kMmaThreads;
+        dst[i] = -1;
+        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (u < total) {
+            int l = 0;                                                    // the resident level this unit belongs to
+            for (int l2 = 1; l2 < L; ++l2)
+                if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) l = l2;
+            if (tab[kTabInts * l + 3] < 0) {                              // (level 0 not resident: the first resident one)
+                for (int l2 = L - 1; l2 >= 0; --l2)
+                    if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) { l = l2; break; }
+            }
+            const int Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
+            const int ul = u - tab[kTabInts * l + 6];
+            const int p = ul / G::LPI, lig = ul % G::LPI;
             const int y = p / Wl, x = p - y * Wl;
             const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
-            const uint4 raw = buffer_load16(rsrc, goff);
-            unsigned char *row = img + base + y * lp + x * G::RP;
-            if (PERMUTE) {
-                uint16_t *dst = reinterpret_cast<uint16_t *>(row);
-                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            raw[i] = buffer_load16(rsrc, goff);
+            dst[i] = tab[kTabInts * l + 3] + y * lp + x * G::RP + (PERMUTE ? 2 * lig : 16 * lig);
+        }
+    }
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    dst[G::img_pos(lig, i)] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-            } else {
-                *reinterpret_cast<uint4 *>(row + lig * 16) = raw;
-            }
+    for (int i = 0; i < kFillBatch; ++i) {
+        if (dst[i] < 0) continue;
+        if (PERMUTE) {
+            // channel 8 * lig + j -> halfword img_pos(lig, j): the lane's own column of eight 32-byte groups
+            uint16_t *row = reinterpret_cast<uint16_t *>(img + dst[i]);
+            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                row[G::img_pos(0, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+        } else {
+            *reinterpret_cast<uint4 *>(img + dst[i]) = raw[i];
+        }
+    }
+    // (images beyond kFillBatch x 16 KiB -- none fits the LDS next to the records today -- the slow way)
+    for (int u = tid + kFillBatch * kMmaThreads; u < total; u += kMmaThreads) {
+        int l = 0;
+        for (int l2 = 0; l2 < L; ++l2)
+            if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) l = l2;
+        const int Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
+        const int ul = u - tab[kTabInts * l + 6];
+        const int p = ul / G::LPI, lig = ul % G::LPI;
+        const int y = p / Wl, x = p - y * Wl;
+        const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
+        const uint4 r = buffer_load16(rsrc, goff);
+        unsigned char *rowp = img + tab[kTabInts * l + 3] + y * lp + x * G::RP;
+        if (PERMUTE) {
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                reinterpret_cast<uint16_t *>(rowp)[G::img_pos(lig, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+        } else {
+            *reinterpret_cast<uint4 *>(rowp + lig * 16) = r;
         }
     }
     __syncthreads();

@@ -36,7 +36,8 @@ template <typename T, int D>
 __global__ void __launch_bounds__(kMmaThreads)
 msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
               const T *__restrict__ loc, const T *__restrict__ attn, const T *__restrict__ grad_out,
-              T *__restrict__ grad_loc, T *__restrict__ grad_attn, const Dims d, const int q_per_wg, const int img_budget)
+              T *__restrict__ grad_loc, T *__restrict__ grad_attn, const Dims d, const int q_per_wg, const int img_budget,
+              const int n_runs)
 {
     constexpr int LPI = D * 2 / 16, QPW = 64 / LPI;
     constexpr int GSH = QPW * D * 2;                                      // the wave's grad_out rows (B operand source)
@@ -51,19 +52,19 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int bid = blockIdx.x;
-    const int h = bid % d.H;
-    const int tq = bid / d.H;
+    const int L = d.L;
+    const int64_t HD = (int64_t)d.H * d.D;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
+    // persistent workgroups, one per CU, runs dealt statically in dispatch order (msda_fwd_mma.hip)
+    for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
+    const int h = run % d.H;
+    const int tq = run / d.H;
     const int q_wg0 = (tq % d.q_tiles) * q_per_wg;
     const int b = tq / d.q_tiles;
-    const int L = d.L;
-
-    const int64_t HD = (int64_t)d.H * d.D;
     const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
-
-    build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
+    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
     fill_image<D, false>(tab, img, rsrc, row_bytes, L, d.S, tid);         // natural channel order
 
     // ---- from here on every wave works on its own
@@ -136,7 +137,10 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         {
             const int sq = lane >> 4;
             const int q = q0 + sq;
-            uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+            // (a row-gather sample that reads nothing must not read row 0 either when the wave walks its tap for
+            // another query: "outside" offsets, whose loads return zeros -> zero dots)
+            uint4 r0 = in_lds ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(kOobOffset, kOobOffset, kOobOffset, kOobOffset);
+            uint4 r1 = make_uint4(0u, 0u, 0u, 0u);
             bool reads = false;
             if (k_ok && q < d.Nq) {
                 asm volatile("" : "+v"(pf_w0), "+v"(pf_w1), "+v"(pf_a));
@@ -165,15 +169,17 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = ok[c] ? (uint32_t)row[c] * row_bytes : kOobOffset;
                         r0 = make_uint4(o[0], o[1], o[2], o[3]);
-                    }                                                     // else: four zero dots, already in r0
+                    }
                 }
             }
+            const unsigned long long bl = __builtin_amdgcn_ballot_w64(reads);
+            live = (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
+            // a tap no query of the wave reads is never walked: its records keep what is written here -- zero dots
+            if (!in_lds && !((live >> kk) & 1u)) r0 = make_uint4(0u, 0u, 0u, 0u);
             if (k_ok) {
                 uint4 *dst = reinterpret_cast<uint4 *>(wrec + sq * G::QSTRIDE + ridx * 32);
                 dst[0] = r0; dst[1] = r1;
             }
-            const unsigned long long bl = __builtin_amdgcn_ballot_w64(reads);
-            live = (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
         }
         wave_sync();
         if (chunk == 0) {
@@ -185,23 +191,32 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         // ---- LDS-resident levels on the matrix cores: tiles of 4 samples x 4 corners of one query
         auto mma_phase = [&]() {
             for (int t4 = 0; 4 * t4 < n_l; ++t4) {
+                const int r = 4 * t4 + (am >> 2);                         // rank of this row's sample among the chunk's LDS samples
+                const int rs = 4 * t4 + (lane >> 4);                      // ... and of the sample whose dots this lane's row quad holds
 #pragma unroll 1
-                for (int j = 0; j < QPW; ++j) {
-                    const int r = 4 * t4 + (am >> 2);                     // rank of this row's sample among the chunk's LDS samples
-                    uint32_t off = 0u;                                    // the zero row
-                    if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + j * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * (am & 3));
-                    const unsigned char *ap = img + off + 16 * akb;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < QPW; j += 2) {                        // two queries at a time: two independent product chains
+                    const unsigned char *ap[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        uint32_t off = 0u;                                // the zero row
+                        if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + (j + u) * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * (am & 3));
+                        ap[u] = img + off + 16 * akb;
+                    }
+                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        const s16x8 A = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4 *>(ap + 64 * ks));
-                        acc = M::run(A, Bf[ks], acc);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const s16x8 A = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4 *>(ap[u] + 64 * ks));
+                            acc[u] = M::run(A, Bf[ks], acc[u]);
+                        }
                     }
                     // column j, row quad s: the four corner dots of sample 4 * t4 + s of query j
-                    const int rs = 4 * t4 + (lane >> 4);
-                    if (bn == j && rs < n_l)
-                        *reinterpret_cast<uint4 *>(wrec + j * G::QSTRIDE + (kChunk - 1 - rs) * 32) =
-                            make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (bn == j + u && rs < n_l)
+                            *reinterpret_cast<uint4 *>(wrec + (j + u) * G::QSTRIDE + (kChunk - 1 - rs) * 32) =
+                                make_uint4(__float_as_uint(acc[u][0]), __float_as_uint(acc[u][1]), __float_as_uint(acc[u][2]), __float_as_uint(acc[u][3]));
                 }
             }
         };
@@ -291,6 +306,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
             }
         }
     }
+    }   // runs
 }
 
 // ---------------------------------------------------------------- launcher
@@ -308,11 +324,12 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
     const int unit = kMmaWaves * G::QPW;
     q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
-    const int64_t blocks = (int64_t)d.B * d.q_tiles * d.H;
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_taps_mma<T, D>), dim3((unsigned)blocks), dim3(kMmaThreads), kLdsTotal, st,
+    const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
+    if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int grid = (int)std::min<int64_t>(runs, persistent_grid());
+    hipLaunchKernelGGL((msda_taps_mma<T, D>), dim3((unsigned)grid), dim3(kMmaThreads), kLdsTotal, st,
                        (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga,
-                       d, q_per_wg, kLdsTotal - G::IMG0);
+                       d, q_per_wg, kLdsTotal - G::IMG0, (int)runs);
     return hipGetLastError();
 }
 
