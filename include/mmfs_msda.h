@@ -383,6 +383,22 @@ int mmfs_bank_scatter(int dtype, int n_levels, void *const *grad_level_ptrs, con
                       const int64_t *src_index, const void *grad_bank, int64_t n_img, int64_t C,
                       int64_t n_slots, void *stream);
 
+/*
+ * RMS normalisation of the LLM-side block (``LlamaRMSNorm``, mm_interleaved/models/decoders/modeling_llama_mmfs.py:53-70,
+ * applied at :352-353 to the token stream and to the feature bank), one pass each way instead of the reference's
+ * chain of seven framework kernels.  x, y, grad_y, grad_x: [rows, C] contiguous, ``weight`` [C], all of storage type
+ * ``dtype`` (MMFS_F32 / MMFS_F16 / MMFS_BF16), 16-byte aligned; ``rstd`` [rows] fp32 (forward: written when not
+ * NULL; backward: read).  y = weight * round(x * rsqrt(mean(x^2) + eps)), the rounding to the storage type between
+ * the two products exactly where the reference has its ``.to(weight.dtype)``.  Backward: ``grad_weight_f32`` [C] fp32
+ * is ACCUMULATED into (atomics): zero it first; cast it to the storage type afterwards.
+ * mmfs_rmsnorm_supported: C a multiple of the 16-byte vector and at most 1024 vectors (8192 channels of 16 bits).
+ */
+int mmfs_rmsnorm_supported(int dtype, int64_t C);
+int mmfs_rmsnorm_forward(int dtype, const void *x, const void *weight, void *y, float *rstd,
+                         int64_t rows, int64_t C, float eps, void *stream);
+int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
+                          void *grad_x, float *grad_weight_f32, int64_t rows, int64_t C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,10 +98,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int b = tq / d.q_tiles;
     const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
-    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
-    fill_image<D, true>(tab, img, rsrc, row_bytes, L, d.S, tid);          // channel-permuted (header)
 
-    FPROF(0);                                                             // table + fill (incl. waiting for the slowest wave)
     // ---- from here on every wave works on its own
     unsigned char *wrec = smem + G::TAB_BYTES + wave * G::WSCR;         // records: [QPW][kChunk] x 32 bytes
     const int qi = lane / LPI, lig = lane % LPI;                          // row-gather role: query of the wave, 16-byte vector
@@ -146,6 +143,13 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
     };
     prefetch(0);
+    // ---- the run's image (requested now, written once every wave has left the previous run)
+    FillRegs<D> fr;
+    fill_load<D, true>(fr, tab, rsrc, row_bytes, L, d.S, tid);            // (in flight while the slower waves finish the previous run)
+    FPROF(5);
+    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
+    fill_store<D, true>(fr, tab, img, rsrc, row_bytes, L, d.S, tid);      // channel-permuted (header)
+    FPROF(0);                                                             // barrier + image writes (incl. waiting for the slowest wave)
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;

@@ -150,54 +150,62 @@ __device__ __forceinline__ void build_level_table(int *tab, unsigned char *img, 
     __syncthreads();
 }
 
-// Resident levels global -> LDS (once per workgroup).  PERMUTE: channel-permuted (16-bit writes); else natural
-// order (one 16-byte write per lane).  Every lane first REQUESTS all its pieces, then writes them: one global
-// round trip per workgroup instead of one per piece (the loop form spent 9 k clocks on five dependent trips).
-// Ends with a barrier.
+// Resident levels global -> LDS (once per run of queries).  PERMUTE: channel-permuted (16-bit writes); else natural
+// order (one 16-byte write per lane).  Two halves: every lane first REQUESTS all its pieces (one global round trip
+// instead of one per piece: the loop form spent 9 k clocks on five dependent trips) -- before the barrier that ends
+// the previous run, so the trip hides behind the waves that are still working --, then writes them.
+template <int D>
+struct FillRegs { uint4 raw[kFillBatch]; int dst[kFillBatch]; int total; };
+
+// first half: request this lane's pieces (no LDS access: may run while other waves still read the old image)
 template <int D, bool PERMUTE>
-__device__ __forceinline__ void fill_image(const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
-                                           uint32_t row_bytes, int L, int S, int tid)
+__device__ __forceinline__ void fill_load(FillRegs<D> &f, const int *tab, __amdgpu_buffer_rsrc_t rsrc,
+                                          uint32_t row_bytes, int L, int S, int tid)
 {
     typedef MmaGeom<D> G;
     int total = 0;
     for (int l = L - 1; l >= 0; --l)
         if (tab[kTabInts * l + 3] >= 0) { total = tab[kTabInts * l + 6] + tab[kTabInts * l] * tab[kTabInts * l + 1] * G::LPI; break; }
-    uint4 raw[kFillBatch];
-    int dst[kFillBatch];
+    f.total = total;
 #pragma unroll
     for (int i = 0; i < kFillBatch; ++i) {
         const int u = tid + i * kMmaThreads;
-        dst[i] = -1;
-        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        f.dst[i] = -1;
+        f.raw[i] = make_uint4(0u, 0u, 0u, 0u);
         if (u < total) {
             int l = 0;                                                    // the resident level this unit belongs to
             for (int l2 = 1; l2 < L; ++l2)
                 if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) l = l2;
-            if (tab[kTabInts * l + 3] < 0) {                              // (level 0 not resident: the first resident one)
-                for (int l2 = L - 1; l2 >= 0; --l2)
-                    if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) { l = l2; break; }
-            }
             const int Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
             const int ul = u - tab[kTabInts * l + 6];
             const int p = ul / G::LPI, lig = ul % G::LPI;
             const int y = p / Wl, x = p - y * Wl;
             const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
-            raw[i] = buffer_load16(rsrc, goff);
-            dst[i] = tab[kTabInts * l + 3] + y * lp + x * G::RP + (PERMUTE ? 2 * lig : 16 * lig);
+            f.raw[i] = buffer_load16(rsrc, goff);
+            f.dst[i] = tab[kTabInts * l + 3] + y * lp + x * G::RP + (PERMUTE ? 2 * lig : 16 * lig);
         }
     }
+}
+
+// second half: write them (after a barrier: every wave is done with the old image); ends with a barrier
+template <int D, bool PERMUTE>
+__device__ __forceinline__ void fill_store(const FillRegs<D> &f, const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
+                                           uint32_t row_bytes, int L, int S, int tid)
+{
+    typedef MmaGeom<D> G;
+    const int total = f.total;
 #pragma unroll
     for (int i = 0; i < kFillBatch; ++i) {
-        if (dst[i] < 0) continue;
+        if (f.dst[i] < 0) continue;
         if (PERMUTE) {
             // channel 8 * lig + j -> halfword img_pos(lig, j): the lane's own column of eight 32-byte groups
-            uint16_t *row = reinterpret_cast<uint16_t *>(img + dst[i]);
-            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            uint16_t *row = reinterpret_cast<uint16_t *>(img + f.dst[i]);
+            const uint32_t w[4] = {f.raw[i].x, f.raw[i].y, f.raw[i].z, f.raw[i].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 row[G::img_pos(0, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
         } else {
-            *reinterpret_cast<uint4 *>(img + dst[i]) = raw[i];
+            *reinterpret_cast<uint4 *>(img + f.dst[i]) = f.raw[i];
         }
     }
     // (images beyond kFillBatch x 16 KiB -- none fits the LDS next to the records today -- the slow way)

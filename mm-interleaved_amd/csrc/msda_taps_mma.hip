@@ -64,8 +64,6 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     const int b = tq / d.q_tiles;
     const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
-    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
-    fill_image<D, false>(tab, img, rsrc, row_bytes, L, d.S, tid);         // natural channel order
 
     // ---- from here on every wave works on its own
     unsigned char *wrec = smem + G::TAB_BYTES + wave * G::WSCR;         // records: [QPW][kChunk] x 32 bytes
@@ -103,6 +101,11 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         }
     };
     prefetch(0);
+    // ---- the run's image (requested now, written once every wave has left the previous run)
+    FillRegs<D> fr;
+    fill_load<D, false>(fr, tab, rsrc, row_bytes, L, d.S, tid);           // (in flight while the slower waves finish the previous run)
+    if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
+    fill_store<D, false>(fr, tab, img, rsrc, row_bytes, L, d.S, tid);     // natural channel order
     uint4 graw = make_uint4(0u, 0u, 0u, 0u);                              // this lane's 16 bytes of its query's grad_out row
     s16x8 Bf[NKS];                                                        // B operand: the wave's queries, all of D
 

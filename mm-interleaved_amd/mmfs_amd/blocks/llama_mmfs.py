@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..functions.norm_func import RMSNormFunction, rmsnorm_supported
 from ..levels import make_level_tables
 from ..modules.mmfs import MMFS
 
@@ -28,7 +29,11 @@ class MMFSRMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(hidden_size))
         self.variance_epsilon = eps
 
+    fused = True          # one gfx950 kernel each way where it applies (csrc/mmfs_norm.hip); off: framework ops
+
     def forward(self, x):
+        if self.fused and rmsnorm_supported(x, self.weight):
+            return RMSNormFunction.apply(x, self.weight, self.variance_epsilon)
         var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
         x = x * torch.rsqrt(var + self.variance_epsilon)
         if self.weight.dtype in (torch.float16, torch.bfloat16):

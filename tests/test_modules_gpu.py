@@ -505,3 +505,84 @@ def test_fused_sampler_is_not_taken_when_a_gradient_is_wanted():
     finally:
         MSDA._event_log = None
     assert not any(n == "mmfs_sample_fwd" for n, _, _ in log)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape", [(4, 1, 4096), (2, 37, 4096), (3, 5, 1024), (1, 9, 72), (2, 3, 8192)])
+def test_rmsnorm_kernel_matches_the_reference_norm(dtype, tol, shape):
+    """csrc/mmfs_norm.hip against the reference's LlamaRMSNorm arithmetic (modeling_llama_mmfs.py:53-70) in fp64
+    on the rounded inputs, forward and both gradients; and against the framework-op evaluation of the same module
+    (same roundings: at most one unit in the last place apart, and nearly everywhere equal)."""
+    from mmfs_amd.blocks import MMFSRMSNorm
+    g = torch.Generator().manual_seed(shape[1])
+    C = shape[-1]
+    m = MMFSRMSNorm(C).to(DEV, dtype)
+    with torch.no_grad():
+        m.weight.copy_((torch.rand(C, generator=g) + 0.5).to(dtype))
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype).to(DEV).requires_grad_(True)
+    go = torch.randn(*shape, generator=g).to(dtype).to(DEV)
+    import MultiScaleDeformableAttention as MSDA
+    log = []
+    MSDA._event_log = log
+    try:
+        y = m(x)
+        y.backward(go)
+    finally:
+        MSDA._event_log = None
+    assert [n for n, _, _ in log] == ["mmfs_rmsnorm_fwd", "mmfs_rmsnorm_bwd"]
+    gx, gw = x.grad.clone(), m.weight.grad.clone()
+    # fp64 statement of the same function
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = m.weight.detach().double().cpu().requires_grad_(True)
+    y64 = w64 * (x64 * torch.rsqrt(x64.pow(2).mean(-1, keepdim=True) + m.variance_epsilon))
+    y64.backward(go.double().cpu())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(y.detach(), y64.detach()) <= tol and rel(gx, x64.grad) <= 2 * tol and rel(gw, w64.grad) <= 2 * tol
+    # the framework-op evaluation (what runs on the CPU and for unsupported shapes)
+    m.fused = False
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = m(x2)
+    y2.backward(go)
+    d = (y.detach().float() - y2.detach().float()).abs()
+    ulp = y2.detach().float().abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -22)
+    assert bool((d <= ulp + 1e-30).all()) and float((d > 0).float().mean()) < 0.02
+    assert rel(gx, x2.grad.double().cpu()) <= 2 * tol
+
+
+def test_llama_layer_with_the_fused_norm_and_schedule_matches_the_layerwise_path():
+    """LlamaMMFSAttention through every addition at once -- fused RMS norms, LlamaMMFSSchedule's shared projection,
+    fused plan + sampler -- against the same layers run the reference's way (framework norms, per-layer projection),
+    bf16 on the device: outputs within 16-bit rounding of each other."""
+    import types as _types
+    from mmfs_amd.blocks import LlamaMMFSAttention, LlamaMMFSSchedule, MMFSRMSNorm
+    cfg = _types.SimpleNamespace(hidden_size=512, num_attention_heads=8, rms_norm_eps=1e-6,
+                                 max_position_embeddings=64, image_embed_dim=128, spatial_shapes=[8, 4, 2])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        layers = [LlamaMMFSAttention(cfg, 4 * i).to(DEV, torch.bfloat16) for i in range(3)]
+    with torch.no_grad():
+        for l in layers:
+            l.gate.fill_(0.7)
+            l.attn.sampling_offsets.weight.normal_(0, 0.02)
+            l.norm2.weight.uniform_(0.5, 1.5)
+    B, Lq, n, hw = 2, 33, 2, 64 + 16 + 4
+    hidden = torch.randn(B, Lq, 512, device=DEV, dtype=torch.bfloat16)
+    feats = torch.randn(B, n, hw, 128, device=DEV, dtype=torch.bfloat16)
+    mask = torch.ones(B, Lq, n, device=DEV)
+    mask[1, :10, 1] = 0
+
+    def run(fused):
+        for l in layers:
+            for mod in l.modules():
+                if isinstance(mod, MMFSRMSNorm):
+                    mod.fused = fused
+        with torch.no_grad():
+            bank = LlamaMMFSSchedule(layers).project(feats) if fused else None
+            h = hidden
+            for k, l in enumerate(layers):
+                h = h + (l(h, feats, mask, value=bank.values[k]) if fused else l(h, feats, mask))
+        return h.float()
+
+    a, b = run(True), run(False)
+    assert float((a - b).abs().max() / b.abs().max()) <= 3e-2
+    assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 4e-3

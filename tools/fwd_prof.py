@@ -27,9 +27,11 @@ v = [x / n for x in buf]
 B, Nq, H = w["B"], w["Nq"], w["H"]
 steps = max(v[7], 1)
 print("%s: %.1f us per forward (instrumented); %d wave-steps per call" % (name, e0.elapsed_time(e1) / n * 1e3, v[7]))
-names = ["table + fill (per wave, whole kernel)", "stage", "first issues + next requests", "matrix-core phase", "gather loop",
-         "general path (whole)", "store"]
-print("  %-40s %10.0f clk per wave (x %d waves)" % (names[0], v[0] / (B * H * 16 * max(1, -(-Nq // 256))), B * H * 16 * -(-Nq // 256)))
-for i in range(1, 7):
-    print("  %-40s %10.0f clk per wave-step" % (names[i], v[i] / steps))
-print("  sum of the step phases %.0f clk per wave-step" % (sum(v[1:7]) / steps))
+names = ["barrier + image writes (per wave and run)", "stage", "first issues + next requests", "matrix-core phase", "gather loop",
+         "run setup + image requests (per wave and run; + the general gather path)", "store"]
+runs = B * H * 16 * max(1, -(-Nq // 256))
+for i in (5, 0):
+    print("  %-72s %10.0f clk per (wave, run)   (x %d)" % (names[i], v[i] / runs, runs))
+for i in (1, 2, 3, 4, 6):
+    print("  %-72s %10.0f clk per wave-step" % (names[i], v[i] / steps))
+print("  sum of the step phases %.0f clk per wave-step; all phases %.0f clk per (wave, run)" % (sum(v[j] for j in (1, 2, 3, 4, 6)) / steps, sum(v[:7]) / runs))
