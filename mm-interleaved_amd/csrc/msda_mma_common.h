@@ -95,15 +95,16 @@ template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// Workgroups of a persistent launch: one per CU of the current device (rounded down to a multiple of 8, the XCD
-// count, so that run -> XCD stays what the head -> XCD affinity expects); MMFS_MMA_GRID overrides (tuning).
-inline int persistent_grid()
+// Workgroups of a launch.  Default: one per run of queries (the dispatcher deals them; a CU holds one at a time).
+// MMFS_MMA_GRID=n makes the kernels PERSISTENT -- n workgroups (a multiple of 8, so that run -> XCD stays what the
+// head -> XCD affinity expects), runs dealt statically w, w + n, ...: measured slower (profiles/r03_experiments.md,
+// r03e: every wave waits at the barrier between two runs for the slowest wave of the previous one, 22 k clocks per
+// run against 9 k for the image fill of a fresh workgroup), kept as a tuning knob.
+inline int64_t persistent_grid()
 {
-    static const int n = [] {
-        if (const char *e = getenv("MMFS_MMA_GRID")) if (atoi(e) > 0) return atoi(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus >= 8 ? cus / 8 * 8 : (cus > 0 ? cus : 256);
+    static const int64_t n = [] {
+        if (const char *e = getenv("MMFS_MMA_GRID")) if (atoi(e) > 0) return (int64_t)atoi(e);
+        return (int64_t)0x7fffffff;
     }();
     return n;
 }

