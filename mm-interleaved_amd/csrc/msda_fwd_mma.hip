@@ -140,12 +140,9 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
     };
     prefetch(0);
-    // ---- the run's image (requested now, written once every wave has left the previous run)
-    FillRegs<D> fr;
-    fill_load<D, true>(fr, tab, rsrc, row_bytes, L, d.S, tid);            // (in flight while the slower waves finish the previous run)
-    FPROF(5);
+    // ---- the run's image
     if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
-    fill_store<D, true>(fr, tab, img, rsrc, row_bytes, L, d.S, tid);      // channel-permuted (header)
+    fill_image<D, true>(tab, img, rsrc, row_bytes, L, d.S, tid);          // channel-permuted (header)
     FPROF(0);                                                             // barrier + image writes (incl. waiting for the slowest wave)
     float acc[VEC];
 #pragma unroll

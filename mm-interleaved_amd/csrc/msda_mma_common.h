@@ -25,8 +25,7 @@ constexpr int kMmaThreads = kMmaWaves * 64;
 constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
 constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
 constexpr int kLdsTotal = 160 * 1024;         // LDS of a CU (MI355X_MICROARCH.md)
-constexpr int kTabInts = 7;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes, first fill unit
-constexpr int kFillBatch = 7;                 // fill units (16 bytes) a lane moves at most: 7 x 1024 x 16 B = 112 KiB >= any image
+constexpr int kTabInts = 6;                   // per level: H, W, start, image base (-1: not resident), line pitch, bytes
 
 template <typename T> struct FwdMma;
 template <> struct FwdMma<bf16_t> {
@@ -141,93 +140,57 @@ __device__ __forceinline__ void build_level_table(int *tab, unsigned char *img, 
     }
     if (tid < RP / 4) reinterpret_cast<uint32_t *>(img)[tid] = 0u;        // the zero row
     __syncthreads();
-    // fill units (one 16-byte piece of a pixel row each) of the resident levels, numbered level after level
-    for (int l = tid; l < L; l += kMmaThreads) {
-        int u0 = 0;
-        for (int l2 = 0; l2 < l; ++l2)
-            if (tab[kTabInts * l2 + 3] >= 0) u0 += tab[kTabInts * l2] * tab[kTabInts * l2 + 1] * MmaGeom<D>::LPI;
-        tab[kTabInts * l + 6] = u0;
-    }
-    __syncthreads();
 }
 
 // Resident levels global -> LDS (once per run of queries).  PERMUTE: channel-permuted (16-bit writes); else natural
-// order (one 16-byte write per lane).  Two halves: every lane first REQUESTS all its pieces (one global round trip
-// instead of one per piece: the loop form spent 9 k clocks on five dependent trips) -- before the barrier that ends
-// the previous run, so the trip hides behind the waves that are still working --, then writes them.
-template <int D>
-struct FillRegs { uint4 raw[kFillBatch]; int dst[kFillBatch]; int total; };
-
-// first half: request this lane's pieces (no LDS access: may run while other waves still read the old image)
+// order (one 16-byte write per lane).  Level after level, a lane's pieces of a level four at a time: requested
+// together, then written (the plain loop -- request, wait, write, next -- spent 9 k clocks on five dependent trips;
+// a version that batched ALL pieces of all levels behind a per-piece level search cost more in index arithmetic
+// than it saved: profiles/r03_experiments.md, r03g).  Ends with a barrier.
 template <int D, bool PERMUTE>
-__device__ __forceinline__ void fill_load(FillRegs<D> &f, const int *tab, __amdgpu_buffer_rsrc_t rsrc,
-                                          uint32_t row_bytes, int L, int S, int tid)
-{
-    typedef MmaGeom<D> G;
-    int total = 0;
-    for (int l = L - 1; l >= 0; --l)
-        if (tab[kTabInts * l + 3] >= 0) { total = tab[kTabInts * l + 6] + tab[kTabInts * l] * tab[kTabInts * l + 1] * G::LPI; break; }
-    f.total = total;
-#pragma unroll
-    for (int i = 0; i < kFillBatch; ++i) {
-        const int u = tid + i * kMmaThreads;
-        f.dst[i] = -1;
-        f.raw[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (u < total) {
-            int l = 0;                                                    // the resident level this unit belongs to
-            for (int l2 = 1; l2 < L; ++l2)
-                if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) l = l2;
-            const int Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
-            const int ul = u - tab[kTabInts * l + 6];
-            const int p = ul / G::LPI, lig = ul % G::LPI;
-            const int y = p / Wl, x = p - y * Wl;
-            const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
-            f.raw[i] = buffer_load16(rsrc, goff);
-            f.dst[i] = tab[kTabInts * l + 3] + y * lp + x * G::RP + (PERMUTE ? 2 * lig : 16 * lig);
-        }
-    }
-}
-
-// second half: write them (after a barrier: every wave is done with the old image); ends with a barrier
-template <int D, bool PERMUTE>
-__device__ __forceinline__ void fill_store(const FillRegs<D> &f, const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
+__device__ __forceinline__ void fill_image(const int *tab, unsigned char *img, __amdgpu_buffer_rsrc_t rsrc,
                                            uint32_t row_bytes, int L, int S, int tid)
 {
     typedef MmaGeom<D> G;
-    const int total = f.total;
+    constexpr int NB = 4;
+    for (int l = 0; l < L; ++l) {
+        const int base = tab[kTabInts * l + 3];
+        if (base < 0) continue;
+        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
+        const int units = Hl * Wl * G::LPI;
+        const float inv_w = 1.0f / (float)Wl;
+        for (int u0 = tid; u0 < units; u0 += NB * kMmaThreads) {
+            uint4 raw[NB];
+            int dst[NB];
 #pragma unroll
-    for (int i = 0; i < kFillBatch; ++i) {
-        if (f.dst[i] < 0) continue;
-        if (PERMUTE) {
-            // channel 8 * lig + j -> halfword img_pos(lig, j): the lane's own column of eight 32-byte groups
-            uint16_t *row = reinterpret_cast<uint16_t *>(img + f.dst[i]);
-            const uint32_t w[4] = {f.raw[i].x, f.raw[i].y, f.raw[i].z, f.raw[i].w};
+            for (int i = 0; i < NB; ++i) {
+                const int u = u0 + i * kMmaThreads;
+                dst[i] = -1;
+                raw[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (u < units) {
+                    const int p = u / G::LPI, lig = u % G::LPI;           // (LPI is a power of two)
+                    int y = (int)((float)p * inv_w);                       // p / Wl for p < 2^20: a float guess, corrected
+                    y -= (y * Wl > p); y += ((y + 1) * Wl <= p);
+                    const int x = p - y * Wl;
+                    const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
+                    raw[i] = buffer_load16(rsrc, goff);
+                    dst[i] = base + y * lp + x * G::RP + (PERMUTE ? 2 * lig : 16 * lig);
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                row[G::img_pos(0, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
-        } else {
-            *reinterpret_cast<uint4 *>(img + f.dst[i]) = f.raw[i];
-        }
-    }
-    // (images beyond kFillBatch x 16 KiB -- none fits the LDS next to the records today -- the slow way)
-    for (int u = tid + kFillBatch * kMmaThreads; u < total; u += kMmaThreads) {
-        int l = 0;
-        for (int l2 = 0; l2 < L; ++l2)
-            if (tab[kTabInts * l2 + 3] >= 0 && tab[kTabInts * l2 + 6] <= u) l = l2;
-        const int Wl = tab[kTabInts * l + 1], st = tab[kTabInts * l + 2], lp = tab[kTabInts * l + 4];
-        const int ul = u - tab[kTabInts * l + 6];
-        const int p = ul / G::LPI, lig = ul % G::LPI;
-        const int y = p / Wl, x = p - y * Wl;
-        const uint32_t goff = (uint32_t)(st + p) < (uint32_t)S ? (uint32_t)(st + p) * row_bytes + (uint32_t)lig * 16u : kOobOffset;
-        const uint4 r = buffer_load16(rsrc, goff);
-        unsigned char *rowp = img + tab[kTabInts * l + 3] + y * lp + x * G::RP;
-        if (PERMUTE) {
-            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            for (int i = 0; i < NB; ++i) {
+                if (dst[i] < 0) continue;
+                if (PERMUTE) {
+                    // channel 8 * lig + j -> halfword img_pos(lig, j): the lane's own column of the row's 32-byte groups
+                    uint16_t *row = reinterpret_cast<uint16_t *>(img + dst[i]);
+                    const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                reinterpret_cast<uint16_t *>(rowp)[G::img_pos(lig, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
-        } else {
-            *reinterpret_cast<uint4 *>(rowp + lig * 16) = r;
+                    for (int j = 0; j < 8; ++j)
+                        row[G::img_pos(0, j)] = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+                } else {
+                    *reinterpret_cast<uint4 *>(img + dst[i]) = raw[i];
+                }
+            }
         }
     }
     __syncthreads();

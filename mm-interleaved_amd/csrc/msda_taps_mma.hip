@@ -32,6 +32,11 @@ namespace mmfs {
 
 using namespace mma;
 
+#ifndef MMFS_TAPS_CHAINS
+#define MMFS_TAPS_CHAINS 2
+#endif
+constexpr int kChains = MMFS_TAPS_CHAINS;       // product chains in flight in the matrix-core phase (1, 2 or 4)
+
 template <typename T, int D>
 __global__ void __launch_bounds__(kMmaThreads)
 msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
@@ -101,11 +106,9 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         }
     };
     prefetch(0);
-    // ---- the run's image (requested now, written once every wave has left the previous run)
-    FillRegs<D> fr;
-    fill_load<D, false>(fr, tab, rsrc, row_bytes, L, d.S, tid);           // (in flight while the slower waves finish the previous run)
+    // ---- the run's image
     if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
-    fill_store<D, false>(fr, tab, img, rsrc, row_bytes, L, d.S, tid);     // natural channel order
+    fill_image<D, false>(tab, img, rsrc, row_bytes, L, d.S, tid);         // natural channel order
     uint4 graw = make_uint4(0u, 0u, 0u, 0u);                              // this lane's 16 bytes of its query's grad_out row
     s16x8 Bf[NKS];                                                        // B operand: the wave's queries, all of D
 
@@ -197,26 +200,28 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 const int r = 4 * t4 + (am >> 2);                         // rank of this row's sample among the chunk's LDS samples
                 const int rs = 4 * t4 + (lane >> 4);                      // ... and of the sample whose dots this lane's row quad holds
 #pragma unroll 1
-                for (int j = 0; j < QPW; j += 2) {                        // two queries at a time: two independent product chains
-                    const unsigned char *ap[2];
+                for (int j = 0; j < QPW; j += kChains) {                  // kChains queries at a time: independent product chains
+                    const unsigned char *ap[kChains];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < kChains; ++u) {
                         uint32_t off = 0u;                                // the zero row
                         if (r < n_l) off = *reinterpret_cast<const uint32_t *>(wrec + (j + u) * G::QSTRIDE + (kChunk - 1 - r) * 32 + 4 * (am & 3));
                         ap[u] = img + off + 16 * akb;
                     }
-                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    f32x4 acc[kChains];
+#pragma unroll
+                    for (int u = 0; u < kChains; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < kChains; ++u) {
                             const s16x8 A = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4 *>(ap[u] + 64 * ks));
                             acc[u] = M::run(A, Bf[ks], acc[u]);
                         }
                     }
                     // column j, row quad s: the four corner dots of sample 4 * t4 + s of query j
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < kChains; ++u)
                         if (bn == j + u && rs < n_l)
                             *reinterpret_cast<uint4 *>(wrec + (j + u) * G::QSTRIDE + (kChunk - 1 - rs) * 32) =
                                 make_uint4(__float_as_uint(acc[u][0]), __float_as_uint(acc[u][1]), __float_as_uint(acc[u][2]), __float_as_uint(acc[u][3]));

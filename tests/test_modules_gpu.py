@@ -515,6 +515,8 @@ def test_rmsnorm_kernel_matches_the_reference_norm(dtype, tol, shape):
     (same roundings in the same places; the statistics are summed in another order, so rsqrt may differ in its last
     bit: a unit or two in the last place of the output, and for 16-bit storage nearly everywhere equal)."""
     from mmfs_amd.blocks import MMFSRMSNorm
+    if dtype == torch.float32 and shape[-1] > 4096:
+        pytest.skip("a lane keeps at most 16 vectors of a row: 4096 fp32 channels (wider rows take the framework ops)")
     g = torch.Generator().manual_seed(shape[1])
     C = shape[-1]
     m = MMFSRMSNorm(C).to(DEV, dtype)
