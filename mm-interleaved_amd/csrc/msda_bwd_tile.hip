@@ -129,9 +129,17 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+// (experiments of round 3, profiles/r03_experiments.md r03i: -DMMFS_TILE_NT_RECS streams the records past the L2's
+// replacement order, -DMMFS_TILE_NT_STORE the finished grad_value rows: do the one-touch streams push the (b, h) slice
+// of grad_out -- read 26 times over -- out of the XCD's L2?)
+#ifdef MMFS_TILE_NT_RECS
+constexpr int kRecAux = 2;
+#else
+constexpr int kRecAux = 0;
+#endif
 __device__ __forceinline__ void dma4(const void *src, void *lds_dst)
 {
-    __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)lds_dst, 4, 0, kRecAux);
 }
 // 16 bytes per lane from rsrc + voffset to lds_dst + lane * 16; an offset past the descriptor's
 // extent moves nothing (or zeros): what a record past the end of a list asks for
@@ -389,7 +397,12 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
             if (y < Hl && x < Wl) {
                 T *o = grad_value + (((int64_t)it.b * d.S + td.lstart + y * Wl + x) * d.H + it.h) * d.D + chunk * 8;
+#ifdef MMFS_TILE_NT_STORE
+                __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(o)); __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(o) + 1);
+                __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(o) + 2); __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(o) + 3);
+#else
                 *reinterpret_cast<uint4 *>(o) = v;
+#endif
             }
         }
     }

@@ -33,7 +33,7 @@ namespace mmfs {
 using namespace mma;
 
 #ifndef MMFS_TAPS_CHAINS
-#define MMFS_TAPS_CHAINS 2
+#define MMFS_TAPS_CHAINS 1      // measured (r03h): 1: 144.7 us, 2: 152.4 us (the second chain's registers spill)
 #endif
 constexpr int kChains = MMFS_TAPS_CHAINS;       // product chains in flight in the matrix-core phase (1, 2 or 4)
 
