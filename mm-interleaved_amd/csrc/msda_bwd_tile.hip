@@ -397,9 +397,8 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             const int y = kTB * by + (p >> 2), x = kTB * bx + (p & 3);
             if (y < Hl && x < Wl) {
                 T *o = grad_value + (((int64_t)it.b * d.S + td.lstart + y * Wl + x) * d.H + it.h) * d.D + chunk * 8;
-#ifdef MMFS_TILE_NT_STORE
-                __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(o)); __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(o) + 1);
-                __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(o) + 2); __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(o) + 3);
+#ifndef MMFS_TILE_PLAIN_STORE
+                store16_stream(o, v);              // (grad_value is not read again in the step: r03i, 0.4604 -> 0.4431 ms)
 #else
                 *reinterpret_cast<uint4 *>(o) = v;
 #endif

@@ -174,6 +174,18 @@ __device__ __forceinline__ void store_xy(T *__restrict__ dst, int64_t s, bool pa
     }
 }
 
+// ---------------------------------------------------------------- streamed outputs
+// Results nobody reads again within the step (the forward's output, grad_value, grad_loc / grad_attn) leave with
+// the non-temporal hint: written normally they displaced the NEXT kernel's inputs from the memory-side cache --
+// with the hint on grad_value alone the forward that follows the backward ran 8.6 us faster
+// (profiles/r03_experiments.md, r03i).
+__device__ __forceinline__ void store16_stream(void *dst, const uint4 &v)
+{
+    uint32_t *o = reinterpret_cast<uint32_t *>(dst);
+    __builtin_nontemporal_store(v.x, o); __builtin_nontemporal_store(v.y, o + 1);
+    __builtin_nontemporal_store(v.z, o + 2); __builtin_nontemporal_store(v.w, o + 3);
+}
+
 // ---------------------------------------------------------------- buffer addressing
 // Row gathers go through a buffer descriptor (SRD) whose base is the workgroup's
 // (batch, head) slab: the per-lane address is a 32-bit byte offset, and an offset at or
