@@ -241,7 +241,7 @@ msda_bwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const float ga = (gy * gx) * d0 + (gy * fx) * d1 + (fy * gx) * d2 + (fy * fx) * d3;
             const float dw = gy * (d1 - d0) + fy * (d3 - d2);
             const float dh = gx * (d2 - d0) + fx * (d3 - d1);
-            grad_attn[s] = (T)ga;
+            store_stream(grad_attn + s, (T)ga);              // (final results of the step: non-temporal, msda_device.h)
             store_xy(grad_loc, s, pair_ok, (float)Wli * dw * a, (float)Hli * dh * a);
         }
     }

@@ -940,7 +940,7 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
                 const int y = kBH * by + px / kBW, x = kBW * bx + px % kBW;
                 if (y < lr.Hl && x < lr.Wl) {
                     T *o = grad_value + (((int64_t)b * d.S + lr.lstart + y * lr.Wl + x) * d.H + h) * d.D + lig * VEC;
-                    *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+                    store16_stream(o, V::pack(acc[px]));
                 }
             }
         }
@@ -1032,7 +1032,7 @@ msda_bwd_block_overflow(const T *__restrict__ grad_out, T *__restrict__ grad_val
                     const int y = kBH * os->by + px / kBW, x = kBW * os->bx + px % kBW;
                     if (y < os->Hl && x < os->Wl) {
                         T *o = grad_value + (((int64_t)b * d.S + os->lstart + y * os->Wl + x) * d.H + h) * d.D + lig * VEC;
-                        *reinterpret_cast<uint4 *>(o) = V::pack(acc[px]);
+                        store16_stream(o, V::pack(acc[px]));
                     }
                 }
             } else {

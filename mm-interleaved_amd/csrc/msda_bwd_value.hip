@@ -428,7 +428,7 @@ msda_bwd_value_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     }
     if (act) {
         T *o = grad_value + (((int64_t)b * d.S + pg) * d.H + h) * d.D + lig * VEC;
-        *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+        store16_stream(o, V::pack(acc));
     }
 }
 

@@ -187,9 +187,9 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
                 const float ga = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
                 const float dw = gy * (dot[1] - dot[0]) + fy * (dot[3] - dot[2]);
                 const float dh = gx * (dot[2] - dot[0]) + fx * (dot[3] - dot[1]);
-                grad_attn[s] = (T)ga;
-                grad_loc[2 * s] = (T)((float)p.Wl * dw * a);
-                grad_loc[2 * s + 1] = (T)((float)p.Hl * dh * a);
+                store_stream(grad_attn + s, (T)ga);
+                store_stream(grad_loc + 2 * s, (T)((float)p.Wl * dw * a));
+                store_stream(grad_loc + 2 * s + 1, (T)((float)p.Hl * dh * a));
             }
         }
     };

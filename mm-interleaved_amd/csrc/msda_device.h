@@ -157,6 +157,7 @@ __device__ __forceinline__ void load_xy(const T *__restrict__ loc, int64_t s, bo
     }
 }
 
+// (grad_loc is a final result of the step: non-temporal, see store16_stream)
 template <typename T>
 __device__ __forceinline__ void store_xy(T *__restrict__ dst, int64_t s, bool pair_ok, float x, float y)
 {
@@ -164,11 +165,12 @@ __device__ __forceinline__ void store_xy(T *__restrict__ dst, int64_t s, bool pa
     if (sizeof(T) == 2 && pair_ok) {
         uint32_t w;
         __builtin_memcpy(&w, p, 4);
-        *reinterpret_cast<uint32_t *>(dst + 2 * s) = w;
+        __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(dst + 2 * s));
     } else if (sizeof(T) == 4 && pair_ok) {
         uint2 w;
         __builtin_memcpy(&w, p, 8);
-        *reinterpret_cast<uint2 *>(dst + 2 * s) = w;
+        __builtin_nontemporal_store(w.x, reinterpret_cast<uint32_t *>(dst + 2 * s));
+        __builtin_nontemporal_store(w.y, reinterpret_cast<uint32_t *>(dst + 2 * s) + 1);
     } else {
         dst[2 * s] = p[0]; dst[2 * s + 1] = p[1];
     }
@@ -184,6 +186,15 @@ __device__ __forceinline__ void store16_stream(void *dst, const uint4 &v)
     uint32_t *o = reinterpret_cast<uint32_t *>(dst);
     __builtin_nontemporal_store(v.x, o); __builtin_nontemporal_store(v.y, o + 1);
     __builtin_nontemporal_store(v.z, o + 2); __builtin_nontemporal_store(v.w, o + 3);
+}
+
+// one element / an (x, y) pair of a streamed result (grad_attn, grad_loc)
+template <typename T>
+__device__ __forceinline__ void store_stream(T *dst, T v)
+{
+    if constexpr (sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(uint16_t, v), reinterpret_cast<uint16_t *>(dst));
+    else if constexpr (sizeof(T) == 4) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(dst));
+    else *dst = v;
 }
 
 // ---------------------------------------------------------------- buffer addressing

@@ -235,7 +235,7 @@ msda_fwd_vec(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     }
     if (q_ok) {
         T *o = out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + lig * VEC;
-        *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+        store16_stream(o, V::pack(acc));                 // (the output is not read again in the step: profiles/r03_experiments.md r03j)
     }
 }
 

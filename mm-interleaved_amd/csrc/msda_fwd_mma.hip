@@ -373,11 +373,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             const int q = q0 + qi;
             if (q < d.Nq) {
                 T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
-#ifdef MMFS_FWD_NT_OUT
-                store16_stream(o, V::pack(acc));
-#else
-                *reinterpret_cast<uint4 *>(o) = V::pack(acc);
-#endif
+                store16_stream(o, V::pack(acc));             // (the output is not read again in the step: r03j)
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;

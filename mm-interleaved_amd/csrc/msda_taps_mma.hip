@@ -309,19 +309,8 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 const float dw = gy * (d1 - d0) + fy * (d3 - d2);
                 const float dh = gx * (d2 - d0) + fx * (d3 - d1);
                 const uint32_t s = (uint32_t)q * q_stride + (uint32_t)k;
-#ifdef MMFS_TAPS_NT_OUT
-                {
-                    const T gav = (T)ga, gx = (T)((float)Wl * dw * a), gy = (T)((float)Hl * dh * a);
-                    __builtin_nontemporal_store(__builtin_bit_cast(uint16_t, gav), reinterpret_cast<uint16_t *>(ga_wg) + s);
-                    if (pair_ok)
-                        __builtin_nontemporal_store((uint32_t)__builtin_bit_cast(uint16_t, gx) | ((uint32_t)__builtin_bit_cast(uint16_t, gy) << 16),
-                                                    reinterpret_cast<uint32_t *>(gl_wg) + s);
-                    else store_xy(gl_wg, (int64_t)s, pair_ok, (float)Wl * dw * a, (float)Hl * dh * a);
-                }
-#else
-                ga_wg[s] = (T)ga;
+                store_stream(ga_wg + s, (T)ga);              // (final results of the step: non-temporal, msda_device.h)
                 store_xy(gl_wg, (int64_t)s, pair_ok, (float)Wl * dw * a, (float)Hl * dh * a);
-#endif
             }
         }
     }
