@@ -77,8 +77,20 @@ struct CellHeader {
     int n_tiles, n_blocks, n_cells, L;
     int n_blocks4, pad[3];              // 4x4 blocks of all levels (matrix-core reduce); pad[0]: every row has exactly one owner level;
                                         // pad[1]: levels cut into more than one sort tile (their seams' blocks are planned by the slice's last workgroup)
+    uint32_t stamp, reserved;           // what the plan was made for (header_stamp): a sort / reduce handed another call's workspace finds nothing to do
     const void *loc_src, *attn_src;     // the op's own loc / attn when the sort reads them in place (no re-pack), else null
 };
+
+// The dimensions a plan belongs to, folded into 32 bits (never 0).  The staged entry points let a caller run the sort
+// or the reduce on a workspace that was prepared by another call: the header then carries another
+// stamp -- or none -- and the kernels return without touching anything instead of following stale pointers.
+__device__ __host__ inline uint32_t header_stamp(const Dims &d)
+{
+    uint32_t h = 2166136261u;
+    const int v[7] = {d.B, d.S, d.H, d.D, d.L, d.Nq, d.P};
+    for (int i = 0; i < 7; ++i) { h ^= (uint32_t)v[i]; h *= 16777619u; }
+    return h ? h : 1u;
+}
 
 // workspace table: CellHeader | LevelRow[L] | CTile[cap]
 __device__ __host__ inline LevelRow *level_rows(CellHeader *h) { return reinterpret_cast<LevelRow *>(h + 1); }

@@ -109,6 +109,7 @@ struct PlanArgs {
     uint32_t tile_cap_extra, tile_cap_partials;
     const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
     int32_t *status;                   // where a table the sorted backward cannot serve is reported (device-accessible; may be null)
+    uint32_t stamp;                    // header_stamp of the call's dimensions
 };
 
 // The plan: one workgroup's job.  A lane per level for everything that divides (the 64-bit divisions of one
@@ -177,6 +178,7 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         }
         hdr->n_tiles = (int)min(n, (int64_t)cap); hdr->n_blocks = bbase; hdr->n_cells = cbase; hdr->L = L;
         hdr->n_blocks4 = bbase4; hdr->pad[1] = seamed; hdr->pad[2] = 0;
+        hdr->stamp = pa.stamp; hdr->reserved = 0u;
         hdr->loc_src = pa.loc_src; hdr->attn_src = pa.attn_src;
         covered_all = covered == (int64_t)S;
     }
@@ -552,7 +554,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     const int h = bid % d.H;
     const int t = (bid / d.H) % tp.tiles_bound;
     const int b = (bid / d.H) / tp.tiles_bound;
-    if (t >= hdr->n_tiles) return;
+    if (hdr->stamp != header_stamp(d) || t >= hdr->n_tiles) return;      // (a plan made for other dimensions: not ours)
     const CTile tl = tiles_of(hdr, d.L)[t];
     // (matrix-core reduce: the level's row, for the blocks this tile plans itself; asked for early)
     LevelRow lr = {};
@@ -790,7 +792,7 @@ msda_bwd_block_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value
     const int b = (bid / d.H) / chunks;
     const int tid = threadIdx.x;
     const int gid = tid / LPS, lig = tid % LPS;
-    const int n_blocks = hdr->n_blocks;              // virtual blocks: block x split
+    const int n_blocks = hdr->stamp == header_stamp(d) ? hdr->n_blocks : 0;              // virtual blocks: block x split
     if (chunk * GROUPS >= n_blocks) return;          // whole workgroup beyond the last block
     const LevelRow *grows = level_rows(hdr);
     for (int i = tid; i < min(d.L, kLdsLevels); i += kRThreads) lvs[i] = grows[i];
@@ -1231,6 +1233,7 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
     pa.th = sc.th; pa.tile_cap_extra = sc.tile_cap_extra; pa.tile_cap_partials = sc.tile_cap_partials;
     pa.loc_src = pa.attn_src = nullptr;
     pa.status = d.table_status;
+    pa.stamp = header_stamp(d);
     return pa;
 }
 

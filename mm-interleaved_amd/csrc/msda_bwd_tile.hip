@@ -427,7 +427,7 @@ msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
     int w = blockIdx.x;
     if (w < kQueueWgs) {
         const int ql = w % kTileLanes;
-        const uint32_t n = min(a.th->n_extra[ql], a.th->cap_extra);
+        const uint32_t n = a.hdr->stamp == header_stamp(d) ? min(a.th->n_extra[ql], a.th->cap_extra) : 0u;
         for (uint32_t i = (uint32_t)(w / kTileLanes); i < n; i += kQueueWgs / kTileLanes) {
             const TileItem ti = a.titems[(size_t)ql * a.th->cap_extra + i];
             if (ti.part == kVoidPart) continue;            // a reservation its block could not use
@@ -441,7 +441,7 @@ msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value,
         return;
     }
     w -= kQueueWgs;
-    const int nblk = a.hdr->n_blocks4;
+    const int nblk = a.hdr->stamp == header_stamp(d) ? a.hdr->n_blocks4 : 0;       // (a plan made for other dimensions: nothing to do)
     ItemArgs it;
     it.h = w % d.H;
     const int t = w / d.H;

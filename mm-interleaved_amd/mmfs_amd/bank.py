@@ -70,7 +70,9 @@ def llm_feature_bank(packed, num_image_per_seq, max_num_image):
     first = num.cumsum(0) - num                                          # [B]
     k = torch.arange(max_num_image, device=packed.device)
     valid = k[None, :] < num[:, None]                                    # [B, N]
-    src = (first[:, None] + k[None, :]).clamp_(max=max(packed.shape[0] - 1, 0))
+    if packed.shape[0] == 0:                      # a batch shard whose sequences show no image: an all-zero bank
+        return packed.new_zeros((num.shape[0], max_num_image) + tuple(packed.shape[1:])) + packed.sum() * 0
+    src = (first[:, None] + k[None, :]).clamp_(max=packed.shape[0] - 1)
     bank = packed.index_select(0, src.reshape(-1)).reshape(num.shape[0], max_num_image, *packed.shape[1:])
     return bank * valid[:, :, None, None].to(bank.dtype)
 
@@ -174,7 +176,8 @@ class AllGatherImageFeatures(torch.autograd.Function):
 def all_gather_image_features(local_packed, n_images_total, group=None):
     """local_packed [n_local, hw, C]: this rank's block of images (global ids rank * per_rank ...).
     Returns [n_images_total, hw, C] in global image order, identical on every rank.  Differentiable:
-    gradients w.r.t. the result flow back to the rank that holds each image (``AllGatherImageFeatures``)."""
+    gradients w.r.t. the result flow back to the rank that holds each image (``AllGatherImageFeatures``).
+    The backward is a collective: EVERY rank has to backpropagate through the result (``keep_in_graph``)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
@@ -184,6 +187,16 @@ def all_gather_image_features(local_packed, n_images_total, group=None):
         pad = local_packed.new_zeros((per_rank - local_packed.shape[0],) + tuple(local_packed.shape[1:]))
         local_packed = torch.cat((local_packed, pad), 0)
     return AllGatherImageFeatures.apply(local_packed, group)[:n_images_total]
+
+
+def keep_in_graph(loss, gathered):
+    """``loss`` with a zero-weight dependence on ``gathered`` (the result of ``all_gather_image_features``).
+
+    The gather's backward is a COLLECTIVE (reduce-scatter): autograd only runs it on ranks whose loss depends on the
+    gathered tensor, and a rank that skips it -- its sequences show no image, or its loss was filtered -- leaves the
+    others waiting.  Every rank must backpropagate through the result; where a rank's loss may not, wrap it:
+    ``loss = bank.keep_in_graph(loss, gathered)`` (``tests/test_distributed.py``: a rank without images)."""
+    return loss + gathered.sum() * 0
 
 
 def local_image_range(n_images_total, rank, world_size):

@@ -62,6 +62,44 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def _worker_idle_rank(rank, world, port, tmp):
+    """Rank 1's sequences show no image at all: its loss does not depend on the gathered tensor, and without
+    ``keep_in_graph`` it would never enter the gather's backward collective."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "mm-interleaved_amd")]
+    from mmfs_amd import bank
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1)
+        num = torch.tensor([2, 1, 0, 0])                         # sequences 2 and 3 (rank 1's shard) have no image
+        n_img = int(num.sum())
+        packed = torch.randn(n_img, 20, 6, generator=g)
+        i0, i1 = bank.local_image_range(n_img, rank, world)
+        mine = packed[i0:i1].clone().requires_grad_(True)
+        gathered = bank.all_gather_image_features(mine, n_img)
+        lo, hi = bank.shard_batch(num.numel(), rank, world)
+        first, cnt = int(num[:lo].sum()), int(num[lo:hi].sum())
+        assert (cnt == 0) == (rank == 1)
+        local = bank.llm_feature_bank(gathered[first:first + cnt], num[lo:hi], 2)
+        wts = torch.randn(num.numel(), 2, 20, 6, generator=g)
+        loss = (local * wts[lo:hi]).sum() + torch.zeros((), requires_grad=True).sum()
+        bank.keep_in_graph(loss, gathered).backward()            # (plain ``loss.backward()`` would hang rank 0 here)
+        ref = packed.clone().requires_grad_(True)
+        (bank.llm_feature_bank(ref, num, 2) * wts).sum().backward()
+        assert torch.allclose(mine.grad, ref.grad[i0:i1], rtol=0, atol=1e-6)
+        open(os.path.join(tmp, f"idle_ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_images_still_joins_the_backward_collective(tmp_path):
+    world = 2
+    mp.spawn(_worker_idle_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"idle_ok{r}").exists() for r in range(world))
+
+
 def test_feature_all_gather_and_batch_sharding_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
