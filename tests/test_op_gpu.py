@@ -742,3 +742,35 @@ def test_lds_levels_taps_are_the_default_and_agree_with_the_row_gather(dtype, mo
     zero = args[4] == 0
     assert zero.any() and torch.equal(lazy[2][~zero], full[2][~zero]) and torch.equal(lazy[1][~zero], full[1][~zero])
     assert not lazy[2][zero].any() and not lazy[1][zero].any()
+
+
+def test_staged_sort_and_reduce_on_a_foreign_workspace_do_nothing():
+    """``mmfs_msda_backward_hybrid`` lets a caller launch the pass stage by stage, and its sort / reduce
+    stages trust the plan in the workspace.  The plan stamps its header with the call's dimensions; a sort or a
+    reduce that finds another stamp (a workspace prepared for another shape, or by nobody) returns without
+    following the header's pointers -- no trap, no fault, the context stays usable."""
+    import numpy as np_
+    import MultiScaleDeformableAttention as MSDA
+    lib = MSDA._lib
+    x = make_inputs(2, 4, 64, 50, 4, [(12, 9), (6, 5), (3, 3)], seed=3, dtype=torch.bfloat16)
+    dev = lambda t: t.to(DEV, torch.bfloat16) if t.is_floating_point() else t.to(DEV)
+    v, l, a_ = dev(x["value"]), dev(x["loc"]), dev(x["attn"])
+    sh, st, go = dev(x["shapes"]), dev(x["start"]), dev(x["grad"]).reshape(2, 50, -1).contiguous()
+    hs = np_.ascontiguousarray(x["shapes"].numpy(), dtype=np_.int64); hst = np_.ascontiguousarray(x["start"].numpy(), dtype=np_.int64)
+    B, S, H, D, L, Nq, P = 2, int(x["value"].shape[1]), 4, 64, 3, 50, 4
+    flags = MSDA._BWD_CANONICAL_LEVELS | MSDA._BWD_DENSE_TAPS
+    nbytes = lib.mmfs_msda_backward_hybrid_workspace_bytes(2, hs.ctypes.data, hst.ctypes.data, B, S, H, D, L, Nq, P, flags)
+    assert nbytes > 0
+    SORT, REDUCE = 8, 16                                        # MMFS_HYB_BWD_VALUE_SORT, _REDUCE
+    for fill in (0, 0x5a):                                      # no plan at all / garbage
+        ws = torch.full((nbytes,), fill, dtype=torch.uint8, device=DEV)
+        gv = torch.full((B, S, H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        gl, ga = torch.empty_like(l), torch.empty_like(a_)
+        for stage in (SORT, REDUCE):
+            rc = lib.mmfs_msda_backward_hybrid(2, v.data_ptr(), sh.data_ptr(), st.data_ptr(), hs.ctypes.data, hst.ctypes.data,
+                                               l.data_ptr(), a_.data_ptr(), go.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                                               ws.data_ptr(), nbytes, B, S, H, D, L, Nq, P, flags, stage, MSDA._stream(gv.device))
+            assert rc == 0
+        torch.cuda.synchronize()
+        assert bool((gv == 7.0).all())                          # nothing was written
+    check(run_hip(x, torch.bfloat16, register=True), run_oracle(x), torch.bfloat16, "after staged calls on foreign workspaces")
