@@ -78,7 +78,7 @@ WORKLOADS = {
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
-def algorithmic_bytes(w, e):
+def algorithmic_bytes(w, e, lds_levels=()):
     """compulsory traffic, every distinct tensor element touched once."""
     B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
     Leff = len(w["shapes"]) * w["n"]
@@ -96,10 +96,15 @@ def algorithmic_bytes(w, e):
     pts_d = B * Nq * H * sum(dense) * P
     taps_dense = e * (B * Sd * C + 6 * pts_d + B * Nq * C)
     taps_fine = e * (B * (S - Sd) * C + 6 * (pts - pts_d) + B * Nq * C)
-    sort = e * 3 * pts                                  # loc, attn -> (scratch)
-    red = e * (B * S * C + B * Nq * C)                  # grad_out -> grad_value
+    # grad_value: the levels in ``lds_levels`` are sorted and reduced inside a workgroup (csrc/msda_gv_mma.hip: loc,
+    # attn, grad_out -> their grad_value rows), the others by the cell sort (loc, attn -> scratch) + tile reduce
+    Sl = sum(h * ww for i, (h, ww) in enumerate(w["shapes"] * w["n"]) if i in lds_levels)
+    pts_l = B * Nq * H * len(lds_levels) * P
+    sort = e * 3 * (pts - pts_l)
+    red = e * (B * (S - Sl) * C + B * Nq * C)           # grad_out -> grad_value
+    blocks = e * (B * Sl * C + B * Nq * C + 3 * pts_l)
     return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value_sort=sort,
-                msda_bwd_value_reduce=red, fwdbwd=fwd + bwd,
+                msda_bwd_value_reduce=red, msda_bwd_value_blocks=blocks, fwdbwd=fwd + bwd,
                 msda_bwd_taps_coarse=taps_dense, msda_bwd_taps_fine=taps_fine)
 
 
@@ -424,11 +429,14 @@ def main():
 
     if rank == 0:
         e = torch.empty((), dtype=DTYPES[w["dtype"]]).element_size()
-        ab = algorithmic_bytes(w, e)
         per_kernel = {}
         for name, a, b in log:
             per_kernel.setdefault(name, []).append(a.elapsed_time(b))     # ms
         mean_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+        lds_levels = ()
+        if "msda_bwd_value_blocks" in mean_ms:
+            lds_levels = tuple(MSDA.value_lds_levels(DTYPES[w["dtype"]], w["shapes"] * w["n"], w["B"], w["H"], w["D"], w["Nq"], w["P"]))
+        ab = algorithmic_bytes(w, e, lds_levels)
         if "msda_bwd_taps_coarse" in mean_ms:          # the gather kernel then covers the other levels only
             ab["msda_bwd_taps"] = ab["msda_bwd_taps_fine"]
         dom = max((k for k in mean_ms if k in ab), key=lambda k: mean_ms[k])

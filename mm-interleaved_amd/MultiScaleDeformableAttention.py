@@ -40,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 7
+_ABI_VERSION = 8
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -59,6 +59,10 @@ _lib.mmfs_msda_backward_checked.restype = _int
 _lib.mmfs_msda_backward_checked.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp, _vp]
 _lib.mmfs_msda_backward_taps_fused.restype = _int
 _lib.mmfs_msda_backward_taps_fused.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
+_lib.mmfs_msda_backward_value_lds_levels.restype = _int
+_lib.mmfs_msda_backward_value_lds_levels.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint]
+_lib.mmfs_msda_debug_value_plan.restype = _i64
+_lib.mmfs_msda_debug_value_plan.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint, _vp, _i64]
 _lib.mmfs_msda_backward_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_taps.restype = _int
@@ -277,12 +281,20 @@ _BWD_LAZY_ZERO_ATTN = 16
 _BWD_DEVICE_CHECKED_LEVELS = 32
 _BWD_TAPS_ROW_GATHER = 64
 _BWD_TAPS_LDS_LEVELS = 128
+_BWD_VALUE_SORTED_ONLY = 256
+_BWD_VALUE_LDS_BLOCKS = 512
 _E_UNSUPPORTED = -5
 
 # tests / measurements: which formulation computes grad_loc / grad_attn (include/mmfs_msda.h):
 # "auto" | "gather" (csrc/msda_bwd.hip + msda_dense.hip) | "lds" (csrc/msda_taps_mma.hip; unsupported shapes raise)
 _taps_algo = "auto"
 _TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS}
+
+# tests / measurements: which formulation computes grad_value of the small levels (include/mmfs_msda.h; only the hybrid
+# entry point -- a registered level table -- has the choice): "auto" | "sorted" (csrc/msda_bwd_block.hip +
+# msda_bwd_tile.hip for every level) | "lds" (csrc/msda_gv_mma.hip where a level qualifies; arguments without one raise)
+_value_algo = "auto"
+_VALUE_FLAGS = {"auto": 0, "sorted": _BWD_VALUE_SORTED_ONLY, "lds": _BWD_VALUE_LDS_BLOCKS}
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
@@ -334,8 +346,24 @@ class _fork:
 
 # stage bits of mmfs_msda_backward_hybrid (include/mmfs_msda.h)
 _HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
-                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16))
-_HYB_BWD_ALL = 31
+                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16), ("msda_bwd_value_blocks", 32))
+_HYB_BWD_ALL = 63
+
+
+def value_lds_levels(dtype, shapes, B, H, D, Nq, P, flags=0):
+    """Measurement / test helper: the levels (indices into ``shapes``, a list of (H_l, W_l) packed canonically)
+    whose grad_value the workgroup-local kernel (csrc/msda_gv_mma.hip) computes for these arguments on a
+    registered level table; the others stay with the cell sort + tile reduce."""
+    hs = np.ascontiguousarray(np.asarray(shapes, dtype=np.int64).reshape(-1, 2))
+    px = hs[:, 0] * hs[:, 1]
+    hst = np.ascontiguousarray(np.cumsum(px) - px)
+    size = _lib.mmfs_msda_debug_value_plan(_DTYPE_CODE[dtype], None, None, 0, 0, 0, 0, 0, 0, 0, 0, None, 0)
+    buf = (ctypes.c_uint8 * max(int(size), 32))()
+    _lib.mmfs_msda_debug_value_plan(_DTYPE_CODE[dtype], hs.ctypes.data, hst.ctypes.data, B, int(px.sum()), H, D, len(hs),
+                                    Nq, P, flags | _BWD_CANONICAL_LEVELS, ctypes.addressof(buf), len(buf))
+    head = np.frombuffer(buf, dtype=np.uint64, count=4)            # {n_levels, n_groups | wgs, ptiles}, skip[2]
+    mask = int(head[2]) | (int(head[3]) << 64)
+    return [l for l in range(len(hs)) if (mask >> l) & 1]
 
 
 def levels_are_canonical(spatial_shapes, level_start_index, S):
@@ -442,7 +470,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         status = _E_UNSUPPORTED
         hyb_bytes = 0
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
-            flags |= _BWD_DENSE_TAPS
+            flags |= _BWD_DENSE_TAPS | _VALUE_FLAGS[_value_algo]
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             # (keyed by the table's CONTENT: a freed host copy's address can come back with another table)
             key = (code, dims, flags, info[1].tobytes(), info[2].tobytes())
@@ -462,11 +490,21 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             fused = _ws_cache.get(fkey)
             if fused is None:
                 fused = _ws_cache[fkey] = _lib.mmfs_msda_backward_taps_fused(code, *dims, flags)
+            lkey = ("lds_levels", key)
+            lds_levels = _ws_cache.get(lkey)
+            if lds_levels is None:
+                lds_levels = _ws_cache[lkey] = _lib.mmfs_msda_backward_value_lds_levels(code, hs, hst, *dims, flags)
+            sorted_levels = int(((info[1][:, 0] > 0) & (info[1][:, 1] > 0)).sum()) - lds_levels
 
             def run_stages(stages):
                 st = 0
                 if fused:               # one kernel does every level: the dense stage has nothing to launch
                     stages = tuple(sb for sb in stages if sb[0] != "msda_bwd_taps_coarse")
+                if lds_levels == 0:     # grad_value: no level for the workgroup-local kernel / none left for the sort
+                    stages = tuple(sb for sb in stages if sb[0] != "msda_bwd_value_blocks")
+                if sorted_levels == 0:
+                    stages = tuple(sb for sb in stages if sb[0] not in ("msda_bwd_value_prepare", "msda_bwd_value_sort",
+                                                                        "msda_bwd_value_reduce"))
                 if _event_log is None:
                     bits = sum(bit for _, bit in stages)
                     return _lib.mmfs_msda_backward_hybrid(*args, bits, _stream(value.device))

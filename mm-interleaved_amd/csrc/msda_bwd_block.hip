@@ -110,6 +110,7 @@ struct PlanArgs {
     const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
     int32_t *status;                   // where a table the sorted backward cannot serve is reported (device-accessible; may be null)
     uint32_t stamp;                    // header_stamp of the call's dimensions
+    uint64_t skip[2];                  // bit l: another kernel writes level l's grad_value rows (msda_gv_mma.hip): no tiles, no blocks
 };
 
 // The plan: one workgroup's job.  A lane per level for everything that divides (the 64-bit divisions of one
@@ -148,7 +149,8 @@ __device__ void plan_cells_body(const PlanArgs &pa)
         r.nbx = (Wl + kBW - 1) / kBW; r.nby = (Hl + kBH - 1) / kBH; r.split = 1; r.cap = kCapRecords;
         r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
         r.band = 0;
-        const LevelTiling lt = level_tiling(Hl64, Wl64, nt_min);
+        LevelTiling lt = level_tiling(Hl64, Wl64, nt_min);
+        if ((pa.skip[(l >> 6) & 1] >> (l & 63)) & 1ull) lt.n = 0;       // served elsewhere: the level keeps its rows, owns no tile
         const int R = lt.R, C = lt.C, n = lt.n;
         if (n == 0) {
             r.nbx = r.nby = r.nbx4 = r.nby4 = 0;                   // (empty; or refused below: no tiles)
@@ -167,7 +169,8 @@ __device__ void plan_cells_body(const PlanArgs &pa)
             LevelRow &r = rows[l];
             r.cbase = cbase; r.bbase = bbase; r.bbase4 = bbase4;
             tile_base[l] = (int)min(n, (int64_t)cap);
-            if (tile_n[l] == 0) continue;                                // (empty, or refused below)
+            if ((pa.skip[(l >> 6) & 1] >> (l & 63)) & 1ull) covered += (int64_t)r.Hl * r.Wl;    // (its rows have an owner)
+            if (tile_n[l] == 0) continue;                                // (empty, served elsewhere, or refused below)
             bbase4 += r.nbx4 * r.nby4;
             n += tile_n[l];
             if (tile_n[l] > 1) ++seamed;
@@ -1234,6 +1237,7 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
     pa.loc_src = pa.attn_src = nullptr;
     pa.status = d.table_status;
     pa.stamp = header_stamp(d);
+    pa.skip[0] = d.gv_skip[0]; pa.skip[1] = d.gv_skip[1];
     return pa;
 }
 
