@@ -156,9 +156,11 @@ int mmfs_msda_forward_flags(int dtype,
  *                per 4x4 pixel block;
  *   LDS blocks   csrc/msda_gv_mma.hip, 16-bit storage, D in {64, 128}, >= 256 queries: the levels of at most 32 (D = 128)
  *                / 64 (D = 64) blocks of 4x4 pixels are sorted by block INSIDE a workgroup, chunk of queries by chunk of
- *                queries, next to the chunk's grad_out rows in LDS; the other levels stay sorted.  Default where it applies.
- * MMFS_BWD_VALUE_SORTED_ONLY keeps every level on the sorted path; MMFS_BWD_VALUE_LDS_BLOCKS on arguments for which
- * no level qualifies returns MMFS_E_UNSUPPORTED. */
+ *                queries, next to the chunk's grad_out rows in LDS; the other levels stay sorted.  OPT-IN: parity-green,
+ *                but measured slower than the sorted path on every shipped geometry.
+ * MMFS_BWD_VALUE_LDS_BLOCKS asks for it (on arguments for which no level qualifies: MMFS_E_UNSUPPORTED; environment
+ * MMFS_GV_ALGO=on asks for it wherever it applies); MMFS_BWD_VALUE_SORTED_ONLY keeps every level on the sorted path
+ * whatever the environment says. */
 #define MMFS_BWD_VALUE_SORTED_ONLY 256u
 #define MMFS_BWD_VALUE_LDS_BLOCKS 512u
 /* 1 when, for these arguments, grad_loc / grad_attn of ALL levels come from the one LDS-levels kernel (the staged

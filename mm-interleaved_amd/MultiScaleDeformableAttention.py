@@ -291,8 +291,9 @@ _taps_algo = "auto"
 _TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS}
 
 # tests / measurements: which formulation computes grad_value of the small levels (include/mmfs_msda.h; only the hybrid
-# entry point -- a registered level table -- has the choice): "auto" | "sorted" (csrc/msda_bwd_block.hip +
-# msda_bwd_tile.hip for every level) | "lds" (csrc/msda_gv_mma.hip where a level qualifies; arguments without one raise)
+# entry point -- a registered level table -- has the choice): "auto" (= sorted, unless MMFS_GV_ALGO=on) | "sorted"
+# (csrc/msda_bwd_block.hip + msda_bwd_tile.hip for every level) | "lds" (csrc/msda_gv_mma.hip where a level qualifies;
+# arguments without one raise).  The LDS formulation is parity-green and measured slower: opt-in
 _value_algo = "auto"
 _VALUE_FLAGS = {"auto": 0, "sorted": _BWD_VALUE_SORTED_ONLY, "lds": _BWD_VALUE_LDS_BLOCKS}
 

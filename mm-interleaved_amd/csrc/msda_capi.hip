@@ -5,6 +5,7 @@
 #include "msda_launch.h"
 #include "msda_gv_mma.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -344,7 +345,11 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
 static mmfs::gv::Table value_blocks_plan(int dtype, const mmfs::Dims &d, const int64_t *host_shapes,
                                          const int64_t *host_start, unsigned flags)
 {
-    if (flags & MMFS_BWD_VALUE_SORTED_ONLY) {
+    // opt-in (MMFS_BWD_VALUE_LDS_BLOCKS, or MMFS_GV_ALGO=on in the environment): measured slower than the sorted path on
+    // every shipped geometry (profiles/r03_experiments.md, r03m-r03o)
+    static const char *algo = getenv("MMFS_GV_ALGO");
+    const bool env_on = algo && algo[0] == 'o' && algo[1] == 'n';
+    if ((flags & MMFS_BWD_VALUE_SORTED_ONLY) || !((flags & MMFS_BWD_VALUE_LDS_BLOCKS) || env_on)) {
         mmfs::gv::Table t;
         memset(&t, 0, sizeof(t));
         return t;
@@ -366,8 +371,9 @@ int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    if (!((flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active)) return 0;
     const mmfs::gv::Table gvt = value_blocks_plan(dtype, d, host_shapes, host_start, flags);
+    // (something for this entry point to do: a level for the dense taps product, or one for the workgroup-local grad_value)
+    if (!((flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active) && gvt.n_groups == 0) return 0;
     return (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256 + mmfs::gv::workspace_bytes(gvt, d);
 }
 
@@ -425,7 +431,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     }
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
-    if (!dense_taps) return MMFS_E_UNSUPPORTED;
+    if (!dense_taps && gvt.n_groups == 0) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
         return MMFS_E_NULLPTR;
     if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||

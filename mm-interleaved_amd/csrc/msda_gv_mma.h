@@ -10,7 +10,9 @@
 //     range of queries; it walks the range in chunks of QC queries whose grad_out rows (QC x D x 2 bytes) it
 //     copies into LDS ONCE -- every sample of the chunk reads its row from there, 1.56 times on average;
 //   * the chunk's samples of the group's levels are binned by block in LDS (count, prefix, place: 4-byte records
-//     {sample, query}); a dense block's samples are dealt over 2^k "virtual blocks" so that the 16 waves carry
+//     {sample, query}), each list ordered so that eight consecutive records belong to queries of eight different
+//     residues modulo 8 while such queries last -- the rows a transposing LDS read touches together then sit in
+//     different banks; a dense block's samples are dealt over 2^k "virtual blocks" so that the 16 waves carry
 //     equal loads, and every virtual block is owned by one wave which keeps its 16 x D fp32 tile in registers
 //     across all chunks: no partial sums inside the workgroup until the end;
 //   * the product is the tile reduce's: grad_value[pixel, :] += W[pixel, record] * grad_out[query(record), :] on
@@ -34,7 +36,7 @@ constexpr int kMaxSegs = 4;               // levels per group
 constexpr int kMaxVb = 64;                // virtual blocks per group (16 waves x slots)
 constexpr int kTB = 4;                    // pixels per block side (= msda_bwd_tile.hip)
 constexpr int kLds = 160 * 1024;
-constexpr int kCtrl = 3072;               // counters, list bases, segment and virtual-block tables
+constexpr int kCtrl = 6144;               // counters (two sets of 64 x 8), list bases, segment and virtual-block tables
 constexpr int kATile = 2048;              // per wave: hi tile + lo tile, 16 pixels x 32 records x 2 bytes each
 constexpr int kRows0 = kCtrl + kWaves * kATile;
 constexpr int kMaxSamples = 2048;         // samples of a chunk (2 per lane kept between the two binning passes)

@@ -10,15 +10,17 @@
 //   per chunk of QC queries of one (b, h):
 //     rows    grad_out rows global -> LDS by DMA, 16-byte chunks XOR-swizzled by the row index (applied to the
 //             DMA's SOURCE address) so that a transposing read of rows with different low index bits is conflict-free;
-//     bin     every lane decodes up to 4 samples of the group's levels, finds the 1, 2 or 4 blocks whose pixels the
-//             sample's corners touch, and takes a rank in each block's list (LDS atomics); prefix over the <= 64
-//             lists; the lanes then write their 4-byte records {sample | query << 16};
+//     bin     every lane decodes up to 2 samples of the group's levels, finds the 1, 2 or 4 blocks whose pixels the
+//             sample's corners touch, and takes a rank in each block's list (LDS atomics, one counter per list and
+//             CLASS of query = index modulo 8); prefix over the <= 64 lists; the lanes then write their 4-byte
+//             records {sample | query << 16}, a list's classes merged round-robin: eight consecutive records have
+//             rows that a transposing read can fetch together without a bank conflict;
 //     product every wave walks the lists of the virtual blocks it owns, 32 records per step: the A operand
 //             (16 pixels x 32 records, hi and lo parts) is built in a wave-private LDS tile by 64 lanes = 16 records
 //             x 4 corners, the B operand (32 records x 16 channels) is read transposed from the records' rows;
 //   at the end the 2^k virtual blocks of a block are added up through LDS; a group cut into several query ranges
-//   leaves fp32 partial tiles and the range that finishes last adds them (agent-scope stores and loads, a drained
-//   arrival counter: the tile reduce's hand-off).
+//   leaves fp32 partial tiles and the range that finishes last adds them (written through, read past the caches, a
+//   drained arrival counter).
 //
 // Semantics inherited from the matrix-core formulation (as msda_bwd_tile.hip): a non-finite grad_out element
 // reaches all 16 pixels of the blocks its sample touches; samples of zero attention weight are not visited.
@@ -81,20 +83,13 @@ template <typename T> __device__ __forceinline__ Geo decode(uint32_t locw, uint3
     return g;
 }
 
+// Place p of a step's 32 records <-> column k of the product: bits 2 and 3 swapped (an involution).  One phase of a
+// transposing read serves the lanes of two 16-lane groups, columns 8 (2j + u) + 4 t + e for u = 0, 1, e = 0..3:
+// with the swap those are the EIGHT CONSECUTIVE places 16 j + 8 t .. + 7 of the list -- eight different classes.
+__device__ __host__ __forceinline__ int perm(int p) { return (p & 0x13) | ((p & 4) << 1) | ((p & 8) >> 1); }
+
 // segment table in LDS: 8 ints per segment
 enum { kSegH = 0, kSegW = 1, kSegNbx = 2, kSegV0 = 3, kSegLog2s = 4, kSegLevel = 5, kSegStart = 6, kSegRb0 = 7 };
-
-__device__ __forceinline__ void store_f32x2_agent(float *p, float a, float b)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
-                       ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void load_f32x2_agent(const float *p, float &a, float &b)
-{
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a = __uint_as_float((uint32_t)v); b = __uint_as_float((uint32_t)(v >> 32));
-}
 
 template <typename T, int D>
 __global__ void __launch_bounds__(kThreads)
@@ -126,8 +121,8 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
     const int c0 = (int)((int64_t)part * nchunks / qparts), c1 = (int)((int64_t)(part + 1) * nchunks / qparts);
 
     // ---- LDS
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);           // [64] records per virtual block (binning)
-    uint32_t *lbase = cnt + kMaxVb;                                // [64] first record of each list
+    uint32_t *cnt2 = reinterpret_cast<uint32_t *>(smem);          // [2][64][8] records per (virtual block, query class): one set per chunk parity
+    uint32_t *lbase = cnt2 + 2 * kMaxVb * 8;                       // [64] first record of each list
     uint32_t *nrec = lbase + kMaxVb;                               // [64] records of each list
     int *segtab = reinterpret_cast<int *>(nrec + kMaxVb);          // [kMaxSegs][8]
     int *vbd = segtab + kMaxSegs * 8;                              // [64][4] segment, block row, block column, part of the block
@@ -145,7 +140,7 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
         st[kSegH] = lv.Hl; st[kSegW] = lv.Wl; st[kSegNbx] = lv.nbx; st[kSegV0] = sg.v0; st[kSegLog2s] = sg.log2s;
         st[kSegLevel] = lv.level; st[kSegStart] = lv.lstart; st[kSegRb0] = sg.rb0;
     }
-    if (tid < kMaxVb) cnt[tid] = 0u;
+    cnt2[tid] = 0u;                                                // (2 x 64 x 8 = one word per lane)
     if (tid < RB / 4) reinterpret_cast<uint32_t *>(rows + QZ * RB)[tid] = 0u;
     __syncthreads();
     if (tid < nvb) {
@@ -190,7 +185,8 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
                 ? (uint32_t)(q0 + r) * HDB + (uint32_t)((cpos ^ (2 * swz<D>(r))) * 16) : kOobOffset;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(rows + (it * kThreads + wave * 64) * 16), 16, (int)off, 0, 0, 0);
         }
-        // ---- samples: decode, count
+        // ---- samples: decode, count.  A list is kept by CLASS of query (index modulo 8: the swizzle of its row)
+        uint32_t *cnt = cnt2 + (c & 1) * (kMaxVb * 8);
         uint32_t key[KS][4];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
@@ -224,7 +220,8 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
                 const int by = (j >> 1) ? yb : ya, bx = (j & 1) ? xb : xa;
                 if (((j >> 1) && yb == ya) || ((j & 1) && xb == xa)) continue;
                 const uint32_t v = (uint32_t)(v00 + ((by * nbx + bx) << l2));
-                key[k][j] = v | (atomicAdd(&cnt[v], 1u) << 8);
+                const uint32_t cl = (uint32_t)ql & 7u;
+                key[k][j] = v | (cl << 6) | (atomicAdd(&cnt[v * 8 + cl], 1u) << 9);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the rows have landed)
@@ -232,17 +229,24 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
         GPROF(1);
         // ---- prefix over the lists
         if (wave == 0) {
-            const uint32_t n = lane < nvb ? cnt[lane] : 0u;
+            uint32_t n = 0u;
+            if (lane < nvb) {
+                const uint4 a0 = reinterpret_cast<const uint4 *>(cnt)[lane * 2], a1 = reinterpret_cast<const uint4 *>(cnt)[lane * 2 + 1];
+                n = a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w;
+            }
             uint32_t incl = n;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t t = __shfl_up(incl, o, 64);
                 if (lane >= o) incl += t;
             }
-            lbase[lane] = incl - n; nrec[lane] = n; cnt[lane] = 0u;
+            lbase[lane] = incl - n; nrec[lane] = n;
         }
         __syncthreads();
-        // ---- place
+        // ---- place: the classes of a list are merged round-robin -- record r of class c goes behind the records
+        // (r', c') with r' < r, or r' == r and c' < c -- so that eight consecutive records are of eight different
+        // classes for as long as every class has records left
+        cnt2[((c + 1) & 1) * (kMaxVb * 8) + (tid & (kMaxVb * 8 - 1))] = 0u;      // (the other parity's counters: last read a chunk ago)
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sidx = k * kThreads + tid;
@@ -250,7 +254,13 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (key[k][j] == 0xffffffffu) continue;
-                recs[lbase[key[k][j] & 0xffu] + (key[k][j] >> 8)] = (uint32_t)sidx | ((uint32_t)ql << 16);
+                const uint32_t v = key[k][j] & 63u, cl = (key[k][j] >> 6) & 7u, r = key[k][j] >> 9;
+                const uint4 a0 = reinterpret_cast<const uint4 *>(cnt)[v * 2], a1 = reinterpret_cast<const uint4 *>(cnt)[v * 2 + 1];
+                const uint32_t cc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                uint32_t pos = lbase[v];
+#pragma unroll
+                for (uint32_t c2 = 0; c2 < 8; ++c2) pos += min(cc[c2], r + (c2 < cl ? 1u : 0u));
+                recs[pos] = (uint32_t)sidx | ((uint32_t)ql << 16);
             }
         }
         __syncthreads();
@@ -275,9 +285,10 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
                 wave_sync();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int k = 16 * t + wr;
-                    if (k < cs) {
-                        const uint32_t rec = list[p0 + k];
+                    const int pl = 16 * t + wr;                       // place in the step's 32 records
+                    const int k = perm(pl);                            // its column of the product
+                    if (pl < cs) {
+                        const uint32_t rec = list[p0 + pl];
                         const uint2 sw = reinterpret_cast<const uint2 *>(samp)[rec & 0xffffu];
                         const Geo ge = decode<T>(sw.x, sw.y, Hl, Wl);
                         const int yy = ge.y0 + wcy, xx = ge.x0 + wcx;
@@ -301,21 +312,18 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
                 int xs[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int k = 8 * bG + 4 * t + be;
-                    const int q = k < cs ? (int)(list[p0 + k] >> 16) : QZ;
+                    const int pl = perm(8 * bG + 4 * t + be);
+                    const int q = pl < cs ? (int)(list[p0 + pl] >> 16) : QZ;
                     ba[t] = rows + q * RB + 8 * bc;
                     xs[t] = swz<D>(q) << 5;
                 }
-                const bool upper = cs > 16;                       // (records 16..31 exist: lanes 32..63 have rows to read)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    s16x8 Bv = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (upper || lane < 32) {
+                    s16x8 Bv;
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ba[t] + ((nt << 5) ^ xs[t])));
-                            Bv[4 * t] = x[0]; Bv[4 * t + 1] = x[1]; Bv[4 * t + 2] = x[2]; Bv[4 * t + 3] = x[3];
-                        }
+                    for (int t = 0; t < 2; ++t) {
+                        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(ba[t] + ((nt << 5) ^ xs[t])));
+                        Bv[4 * t] = x[0]; Bv[4 * t + 1] = x[1]; Bv[4 * t + 2] = x[2]; Bv[4 * t + 3] = x[3];
                     }
                     acc[SL][nt] = M::run(Ah, Bv, acc[SL][nt]);
                     acc[SL][nt] = M::run(Al, Bv, acc[SL][nt]);
@@ -335,7 +343,11 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
     // ---- the virtual blocks of a block added up through LDS, slot by slot; rows stored (or partial tiles left)
     float *tl = reinterpret_cast<float *>(smem + kCtrl);          // [16 waves][16 pixels][D]
     const int64_t slab = (int64_t)b * d.H + h;
-    float *ptile = partials + (slab * tab.ptiles_per_slab + tab.g[g].pbase + (int64_t)part * nrb) * (kTB * kTB * D);
+    // partial tiles of the group's query ranges: [qparts][nrb][16][D] fp32 behind one descriptor; written through and read
+    // past the caches (sc0 sc1): the ranges of a group may run on different XCDs
+    constexpr int kCoherent = 1 | 16;
+    const __amdgpu_buffer_rsrc_t prs = make_slab_rsrc(partials + (slab * tab.ptiles_per_slab + tab.g[g].pbase) * (int64_t)(kTB * kTB * D),
+                                                      (int64_t)qparts * nrb * (kTB * kTB * D) * 4);
     auto put_rows = [&](int s, int rbl, int px, int c8, const float (&sum)[8]) {
         // block rbl of segment s, pixel px of the block, channels 8 c8 ..
         const int nbx = segtab[s * 8 + kSegNbx], Hl = segtab[s * 8 + kSegH], Wl = segtab[s * 8 + kSegW];
@@ -375,9 +387,11 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
             if (qparts == 1) {
                 put_rows(s, rbl, px, c8, sum);
             } else {
-                float *o = ptile + ((int64_t)(segtab[s * 8 + kSegRb0] + rbl) * (kTB * kTB) + px) * D + c8 * 8;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) store_f32x2_agent(o + 2 * i, sum[2 * i], sum[2 * i + 1]);
+                const uint32_t o = (uint32_t)((((part * nrb + segtab[s * 8 + kSegRb0] + rbl) * (kTB * kTB) + px) * D + c8 * 8) * 4);
+                const u32x4 w0 = {__float_as_uint(sum[0]), __float_as_uint(sum[1]), __float_as_uint(sum[2]), __float_as_uint(sum[3])};
+                const u32x4 w1 = {__float_as_uint(sum[4]), __float_as_uint(sum[5]), __float_as_uint(sum[6]), __float_as_uint(sum[7])};
+                __builtin_amdgcn_raw_buffer_store_b128(w0, prs, (int)o, 0, kCoherent);
+                __builtin_amdgcn_raw_buffer_store_b128(w1, prs, (int)o + 16, 0, kCoherent);
             }
         }
         __syncthreads();
@@ -394,18 +408,15 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
         }
         __syncthreads();
         if (*flag) {
-            const float *p0 = partials + (slab * tab.ptiles_per_slab + tab.g[g].pbase) * (int64_t)(kTB * kTB * D);
             for (int e = tid; e < nrb * 16 * LPR; e += kThreads) {
                 const int rbg = e / (16 * LPR), px = (e / LPR) & 15, c8 = e % LPR;
                 float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int pp = 0; pp < qparts; ++pp) {
-                    const float *src = p0 + (((int64_t)pp * nrb + rbg) * (kTB * kTB) + px) * D + c8 * 8;
+                    const uint32_t o = (uint32_t)((((pp * nrb + rbg) * (kTB * kTB) + px) * D + c8 * 8) * 4);
+                    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o, 0, kCoherent);
+                    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o + 16, 0, kCoherent);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float a, bb;
-                        load_f32x2_agent(src + 2 * i, a, bb);
-                        sum[2 * i] += a; sum[2 * i + 1] += bb;
-                    }
+                    for (int i = 0; i < 4; ++i) { sum[i] += __uint_as_float(w0[i]); sum[4 + i] += __uint_as_float(w1[i]); }
                 }
                 int s = 0;
                 while (s + 1 < nseg && segtab[(s + 1) * 8 + kSegRb0] <= rbg) ++s;
@@ -469,8 +480,6 @@ Table make_plan(int dtype, const Dims &d, const int64_t *hs, const int64_t *hst)
     Table t;
     memset(&t, 0, sizeof(t));
     if (!hs || !hst || !shape_supported(dtype, d)) return t;
-    static const char *algo = getenv("MMFS_GV_ALGO");              // "off": never; default: whenever a level qualifies
-    if (algo && (algo[0] == 'o' && algo[1] == 'f')) return t;
     if (d.Nq < env_int("MMFS_GV_MIN_NQ", 256)) return t;
     const int VB = d.D >= 128 ? Geom<128>::VB : Geom<64>::VB;
     const int RB = d.D * 2;
@@ -491,12 +500,14 @@ Table make_plan(int dtype, const Dims &d, const int64_t *hs, const int64_t *hst)
     if (cand.empty()) return t;
     const int64_t slabs = (int64_t)d.B * d.H;
     const double unit = (double)cand.size() * (double)slabs / (double)env_int("MMFS_GV_TARGET_WGS", 512);   // levels per workgroup
-    const int maxw = std::max(1, (int)(unit + 0.5));
-    // groups of levels, smallest first
+    // groups of levels, smallest first: as many levels as the virtual blocks allow while a chunk still holds 64 queries
+    // (the chunk's rows, barriers and prefix are shared by the levels of a group); MMFS_GV_MAX_SEGS=1: a level per group
+    const int max_segs = std::max(1, std::min(kMaxSegs, env_int("MMFS_GV_MAX_SEGS", kMaxSegs)));
     struct Tmp { std::vector<int> ci; int nb; };
     std::vector<Tmp> groups;
     for (int i = 0; i < (int)cand.size(); ++i) {
-        if (groups.empty() || (int)groups.back().ci.size() >= std::min(maxw, kMaxSegs) || groups.back().nb + cand[i].nb > VB)
+        if (groups.empty() || (int)groups.back().ci.size() >= max_segs || groups.back().nb + cand[i].nb > VB ||
+            ((int)groups.back().ci.size() + 1) * d.P * 64 > kMaxSamples)
             groups.push_back(Tmp{{}, 0});
         groups.back().ci.push_back(i);
         groups.back().nb += cand[i].nb;

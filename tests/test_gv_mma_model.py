@@ -22,7 +22,7 @@ from test_fwd_mma_model import mfma, tr_read
 LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mm-interleaved_amd", "libmmfs_msda.so")
 
 K_WAVES, K_THREADS, K_MAX_LEVELS, K_MAX_GROUPS, K_MAX_SEGS, K_TB = 16, 1024, 16, 32, 4, 4
-K_LDS, K_CTRL, K_ATILE = 160 * 1024, 3072, 2048
+K_LDS, K_CTRL, K_ATILE = 160 * 1024, 6144, 2048
 K_ROWS0 = K_CTRL + K_WAVES * K_ATILE
 K_MAX_SAMPLES, K_MAX_QC = 2048, 256
 
@@ -55,7 +55,7 @@ def load_lib():
     return lib
 
 
-def plan(shapes, B, H, D, Nq, P, flags=0, dtype=2):
+def plan(shapes, B, H, D, Nq, P, flags=512, dtype=2):          # 512: MMFS_BWD_VALUE_LDS_BLOCKS (the kernel is opt-in)
     lib = load_lib()
     hs = np.ascontiguousarray(np.array(shapes, dtype=np.int64).reshape(-1, 2))
     px = hs[:, 0] * hs[:, 1]
@@ -137,15 +137,36 @@ def test_plan_invariants(name):
         assert served == want
 
 
-def test_plan_is_off_when_asked():
+def test_plan_is_off_unless_asked_for():
     shapes, B, H, D, Nq, P = GEOMETRIES["north_star"]
-    t, _, _ = plan(shapes, B, H, D, Nq, P, flags=256)          # MMFS_BWD_VALUE_SORTED_ONLY
-    assert t.n_groups == 0 and t.skip[0] == 0
+    for flags in (0, 256, 256 | 512):                          # default; MMFS_BWD_VALUE_SORTED_ONLY; ... wins over LDS_BLOCKS
+        t, _, _ = plan(shapes, B, H, D, Nq, P, flags=flags)
+        assert t.n_groups == 0 and t.skip[0] == 0
 
 
 # ---------------------------------------------------------------------------------------------- the kernel's model
 def swz(D, r):
     return (r & 7) if D >= 128 else ((r >> 1) & 3)
+
+
+def perm(p):
+    return (p & 0x13) | ((p & 4) << 1) | ((p & 8) >> 1)
+
+
+def tr_read_conflicts(D, addr):
+    """Worst number of lanes of one 32-lane phase of a transposing read that hit the same 32-byte bank slot with
+    DIFFERENT rows (the model of the hardware behind the swizzle: 64 banks x 4 bytes = eight 32-byte slots)."""
+    worst = 1
+    for ph in range(2):
+        slots = {}
+        for lane in range(32 * ph, 32 * ph + 32):
+            a = int(addr[lane])
+            slots.setdefault((a % 256) // 32, set()).add(a // 32)
+        worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+
+
+stats = {"conflict_free_reads": 0}
 
 
 def run_workgroup(t, gi, part, D, Nq, P, samples, grad_out, out, partial_out):
@@ -187,6 +208,7 @@ def run_workgroup(t, gi, part, D, Nq, P, samples, grad_out, out, partial_out):
                 rows[i * 8:i * 8 + 8] = grad_out[q0 + r, src:src + 8]
         # ---- bin
         cnt = [0] * nvb
+        ccnt = np.zeros((nvb, 8), dtype=np.int64)
         keys = []
         samp = {}
         for sidx in range(NS):
@@ -210,12 +232,17 @@ def run_workgroup(t, gi, part, D, Nq, P, samples, grad_out, out, partial_out):
                     continue
                 v = v00 + ((by * st["nbx"] + bx) << st["l2"])
                 assert 0 <= v < nvb
-                keys.append((v, cnt[v], sidx, ql))
+                cl = ql & 7
+                keys.append((v, cl, int(ccnt[v, cl]), sidx, ql))
+                ccnt[v, cl] += 1
                 cnt[v] += 1
         lbase = np.concatenate([[0], np.cumsum(cnt)])[:-1]
-        recs = np.zeros(max(1, sum(cnt)), dtype=np.int64)
-        for v, rank, sidx, ql in keys:
-            recs[lbase[v] + rank] = sidx | (ql << 16)
+        recs = np.full(max(1, sum(cnt)), -1, dtype=np.int64)
+        for v, cl, r, sidx, ql in keys:
+            pos = lbase[v] + sum(min(int(ccnt[v, c2]), r + (1 if c2 < cl else 0)) for c2 in range(8))
+            assert recs[pos] == -1 and pos < lbase[v] + cnt[v]
+            recs[pos] = sidx | (ql << 16)
+        assert (recs[:sum(cnt)] >= 0).all()
         # ---- products
         for wave in range(K_WAVES):
             for SL in range(SLOTS):
@@ -232,10 +259,11 @@ def run_workgroup(t, gi, part, D, Nq, P, samples, grad_out, out, partial_out):
                     for tt in range(2):
                         for lane in range(64):
                             wr, wcy, wcx = lane >> 2, (lane >> 1) & 1, lane & 1
-                            k = 16 * tt + wr
-                            if k >= cs:
+                            pl = 16 * tt + wr
+                            k = perm(pl)
+                            if pl >= cs:
                                 continue
-                            rec = int(lst[p0 + k])
+                            rec = int(lst[p0 + pl])
                             y0, x0, fy, fx, a = samp[rec & 0xffff]
                             yy, xx = y0 + wcy, x0 + wcx
                             py, px = yy - by4, xx - bx4
@@ -258,18 +286,20 @@ def run_workgroup(t, gi, part, D, Nq, P, samples, grad_out, out, partial_out):
                         Al[lane] = atile[(1024 + a_off) // 2:(1024 + a_off) // 2 + 8]
                         bG, be, bc = lane >> 4, (lane >> 2) & 3, lane & 3
                         for tt in range(2):
-                            k = 8 * bG + 4 * tt + be
-                            q = int(lst[p0 + k]) >> 16 if k < cs else QZ
+                            pl = perm(8 * bG + 4 * tt + be)
+                            q = int(lst[p0 + pl]) >> 16 if pl < cs else QZ
                             ad[tt, lane] = q * RB + 8 * bc
                             xs[tt, lane] = swz(D, q) << 5
-                    upper = cs > 16
+                    # a step whose 32 places hold four full rounds of the eight classes reads without a bank conflict
+                    full = cs == 32 and all(sorted((int(lst[p0 + 8 * r8 + i]) >> 16) & 7 for i in range(8)) == list(range(8)) for r8 in range(4))
                     for nt in range(NT):
                         Bv = np.zeros((64, 8))
                         for tt in range(2):
-                            r = tr_read(rows, ad[tt] + ((nt << 5) ^ xs[tt]))
-                            Bv[:, 4 * tt:4 * tt + 4] = r
-                        if not upper:
-                            Bv[32:] = 0
+                            a = ad[tt] + ((nt << 5) ^ xs[tt])
+                            if full:
+                                assert tr_read_conflicts(D, a) == 1
+                                stats["conflict_free_reads"] += 1
+                            Bv[:, 4 * tt:4 * tt + 4] = tr_read(rows, a)
                         acc[wave, SL, nt] += mfma(Ah, Bv) + mfma(Al, Bv)
     # ---- epilogue
     for sl in range(SLOTS):
@@ -371,6 +401,6 @@ def test_workgroup_model_matches_scatter(case, target, monkeypatch):
                         out[seg[s]["level"]][y, x] += partial[:, rbg, px].sum(0)
         for si in range(g.nseg):
             served.add(t.lv[g.seg[si].lslot].level)
-    assert served
+    assert served and stats["conflict_free_reads"] > 0
     for l in served:
         np.testing.assert_allclose(out[l], want[l], rtol=0, atol=1e-9)
