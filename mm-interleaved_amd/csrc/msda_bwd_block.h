@@ -109,11 +109,10 @@ constexpr int kTB = 4;
 #define MMFS_TILE_CHUNK 1024
 #endif
 constexpr int kTileChunk = MMFS_TILE_CHUNK;
-constexpr int kTileLanes = 8;             // queue lanes of the extra work items (one per XCD, keyed by h % 8)
 
 struct TileHeader {
-    uint32_t n_extra[kTileLanes];         // queued extra items per lane
-    uint32_t n_partials, cap_extra, cap_partials, n_multi;
+    uint32_t spare0[8];
+    uint32_t n_partials, cap_extra, cap_partials, n_multi;       // cap_extra: queue places per (b, h) slice
     uint4 null_rec;                       // (spare)
     uint4 zero_row[32];                   // (spare)
 };
@@ -138,8 +137,10 @@ struct TileReduceArgs {
     int cell_stride;
     TileHeader *th;
     TileDesc *tdesc;                      // [B, H, blocks_bound]
-    TileItem *titems;                     // [kTileLanes, cap_extra]
+    TileItem *titems;                     // [B, H, cap_extra]: a slice's extra items are walked next to its blocks (one XCD, one L2: the
+                                          // slice's grad_out rows; a queue shared by the whole batch read 8 slices at once per XCD -- r03q)
     uint32_t *slice_done;                 // [B, H] sort workgroups of the slice that have finished (zeroed with the cursors)
+    uint32_t *n_extra;                    // [B, H] queued extra items of the slice (zeroed with the cursors)
     float *tpartials;                     // [cap_partials, kTB*kTB, D]
     int blocks_bound;
 };
@@ -147,28 +148,26 @@ constexpr uint32_t kVoidPart = 0xffffffffu;
 
 #ifdef __HIPCC__
 // A block's descriptor is complete but for its work items: from the length n of its list, the number of
-// items; the extra ones are queued (one queue lane per XCD, keyed by h like every other kernel's head ->
-// XCD affinity).
+// items; the extra ones are queued, slice by slice.
 __device__ inline void queue_block(const TileReduceArgs &a, const Dims &d, int64_t bh, int blk, TileDesc &td, int64_t n)
 {
     const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
     if (parts > 1) {
-        const int ql = (int)(bh % d.H) % kTileLanes;
         const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
-        const uint32_t eb = atomicAdd(&a.th->n_extra[ql], parts - 1);
+        const uint32_t eb = atomicAdd(&a.n_extra[bh], parts - 1);
         if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
             td.parts = parts; td.pbase = pb;
             for (uint32_t p = 1; p < parts; ++p) {
                 TileItem ti;
                 ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = p; ti.pidx = pb + p;
-                a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+                a.titems[(size_t)bh * a.th->cap_extra + eb + p - 1] = ti;
             }
         } else if (eb < a.th->cap_extra) {
             // reserved queue entries that cannot be used must read as "nothing to do"
             for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
                 TileItem ti;
                 ti.bh = (uint32_t)bh; ti.blk = (uint32_t)blk; ti.part = kVoidPart; ti.pidx = 0;
-                a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+                a.titems[(size_t)bh * a.th->cap_extra + eb + p - 1] = ti;
             }
         }
     }
@@ -246,14 +245,13 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
     if (parts > 1) {
         pd.blk = blk; pd.parts = parts;
         pd.pb = atomicAdd(&a.th->n_partials, parts);
-        pd.eb = atomicAdd(&a.th->n_extra[(int)(bh % d.H) % kTileLanes], parts - 1);
+        pd.eb = atomicAdd(&a.n_extra[bh], parts - 1);
     }
     return pd;
 }
 __device__ inline void plan_tile_finish(const TileReduceArgs &a, const Dims &d, int64_t bh, const PendingBlock &pd)
 {
     if (pd.blk < 0) return;
-    const int ql = (int)(bh % d.H) % kTileLanes;
     const uint32_t parts = pd.parts, pb = pd.pb, eb = pd.eb;
     if (pb + parts <= a.th->cap_partials && eb + parts - 1 <= a.th->cap_extra) {
         TileDesc *td = &a.tdesc[bh * a.blocks_bound + pd.blk];
@@ -261,14 +259,14 @@ __device__ inline void plan_tile_finish(const TileReduceArgs &a, const Dims &d, 
         for (uint32_t p = 1; p < parts; ++p) {
             TileItem ti;
             ti.bh = (uint32_t)bh; ti.blk = (uint32_t)pd.blk; ti.part = p; ti.pidx = pb + p;
-            a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+            a.titems[(size_t)bh * a.th->cap_extra + eb + p - 1] = ti;
         }
     } else if (eb < a.th->cap_extra) {
         // reserved queue entries that cannot be used must read as "nothing to do"
         for (uint32_t p = 1; p < parts && eb + p - 1 < a.th->cap_extra; ++p) {
             TileItem ti;
             ti.bh = (uint32_t)bh; ti.blk = (uint32_t)pd.blk; ti.part = kVoidPart; ti.pidx = 0;
-            a.titems[(size_t)ql * a.th->cap_extra + eb + p - 1] = ti;
+            a.titems[(size_t)bh * a.th->cap_extra + eb + p - 1] = ti;
         }
     }
 }
@@ -328,7 +326,7 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
 // 16-bit storage, D in {32, 64, 128}; MMFS_VALUE_ALGO=block keeps the vector-ALU reduce
 bool tile_reduce_supported(int dtype, const Dims &d);
 hipError_t tile_reduce(int dtype, const void *grad_out, void *grad_value, const TileReduceArgs &a, const Dims &d,
-                       hipStream_t st);
+                       uint32_t cap_extra, hipStream_t st);      // cap_extra: TileHeader::cap_extra (the host's copy)
 
 }  // namespace blk
 }  // namespace mmfs

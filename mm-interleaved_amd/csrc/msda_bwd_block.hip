@@ -127,7 +127,6 @@ __device__ void plan_cells_body(const PlanArgs &pa)
     if (th != nullptr && tid < 32) th->zero_row[tid] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == nthr - 1) {
         if (th != nullptr) {
-            for (int i = 0; i < kTileLanes; ++i) th->n_extra[i] = 0u;
             th->n_partials = 0u; th->cap_extra = pa.tile_cap_extra; th->cap_partials = pa.tile_cap_partials; th->n_multi = 0u;
             th->null_rec = make_uint4(0u, __float_as_uint(-8.f), __float_as_uint(-8.f), 0u);
         }
@@ -421,6 +420,10 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
 // counting pass and the placing pass, with the cell and the RANK inside the cell the counting atomic returned
 // -- the placing pass then needs no atomic and no second read of loc / attn: slot = off[cell] + rank.
 // (The second scan with its returning LDS atomics was 12 of the workgroup's 36 kclk at the north star.)
+#ifndef MMFS_SORT_WINDOW_ROUNDS
+#define MMFS_SORT_WINDOW_ROUNDS 1
+#endif
+constexpr bool kWindowRounds = MMFS_SORT_WINDOW_ROUNDS != 0;       // a kept scan may place its records window by window
 constexpr uint32_t kNoCell = 0xffffffffu;
 constexpr int kCellBits = 13;
 static_assert(kMaxTileCells <= (1 << kCellBits), "a cell index and a rank share one word");
@@ -478,10 +481,13 @@ struct KeptScan {
     }
 
     // list: the tile's records (the LDS window, or its place in the record area)
+    // slots [s0, s0 + cap) only (a tile of more records than the window holds is placed window by window: ``list`` is
+    // the window, slot s lands at s - s0); reload: read the words again first (they are not kept when NV == 2)
     __device__ __forceinline__ void place(const T *__restrict__ loc, const T *__restrict__ attn, const Dims &d,
-                                          const CTile &tl, int b, int h, bool in_place, const uint32_t *off, void *__restrict__ list)
+                                          const CTile &tl, int b, int h, bool in_place, const uint32_t *off, void *__restrict__ list,
+                                          uint32_t s0 = 0u, uint32_t cap = 0xffffffffu, bool reload = true)
     {
-        if (!kKeepRaw) load(loc, attn, d, tl, b, h, in_place);
+        if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const uint32_t q = threadIdx.x + u * kThreads;
@@ -498,7 +504,9 @@ struct KeptScan {
                 for (int i = 0; i < SPV; ++i) {
                     const uint32_t k = key[u][v][i];
                     if (k == kNoCell) continue;
-                    const uint32_t slot = off[k & ((1u << kCellBits) - 1u)] + (k >> kCellBits);
+                    uint32_t slot = off[k & ((1u << kCellBits) - 1u)] + (k >> kCellBits);
+                    if (slot - s0 >= cap) continue;                   // (another window's; unsigned: slot < s0 too)
+                    slot -= s0;
                     if (COMPACT)
                         reinterpret_cast<uint2 *>(list)[slot] =
                             make_uint2(q | (((aw[(i >> 1) & 1] >> (16 * (i & 1))) & 0xffffu) << 16), lw[i & 3]);
@@ -615,8 +623,39 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     pending.blk = -1;
     if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, kThreads);
     SPROF(3);
+    // (a kept scan whose records exceed the window places them window by window: the records of a window are
+    // consecutive slots, so each window leaves as one coalesced copy)
+    const uint32_t win_cap = win_bytes / (COMPACT ? 8u : 16u);
+    // the window's first n records -> slots s0 .. of the tile's place in the record area, coalesced
+    // (-DMMFS_SORT_NT_RECS: with the non-temporal hint -- experiment, profiles/r03_experiments.md r03p)
+    auto copy_out = [&](uint32_t s0, uint32_t n) {
+        if (COMPACT) {
+            const uint2 *src = reinterpret_cast<const uint2 *>(win);
+            uint2 *dst = reinterpret_cast<uint2 *>(area) + s0;
+            for (uint32_t i = tid; i < n; i += kThreads) {
+#ifdef MMFS_SORT_NT_RECS
+                __builtin_nontemporal_store(*reinterpret_cast<const unsigned long long *>(&src[i]), reinterpret_cast<unsigned long long *>(&dst[i]));
+#else
+                dst[i] = src[i];
+#endif
+            }
+        } else {
+            const uint4 *src = reinterpret_cast<const uint4 *>(win);
+            uint4 *dst = reinterpret_cast<uint4 *>(area) + s0;
+            for (uint32_t i = tid; i < n; i += kThreads) dst[i] = src[i];
+        }
+    };
+    const bool rounds = kept && !windowed && kWindowRounds;
     if (total) {
-        if (kept) {
+        if (rounds) {
+            for (uint32_t s0 = 0; s0 < total; s0 += win_cap) {
+                const uint32_t n = min(win_cap, total - s0);
+                ks.place(loc, attn, d, tl, b, h, in_place, off, win, s0, win_cap, true);
+                __syncthreads();
+                copy_out(s0, n);
+                __syncthreads();
+            }
+        } else if (kept) {
             ks.place(loc, attn, d, tl, b, h, in_place, off, windowed ? (void *)win : area);
         } else if (windowed) {
             __syncthreads();                                      // the table and the plan have read off[]; now off[] becomes the cursors
@@ -624,17 +663,9 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
         } else {
             scan_samples<T, kScatter, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, area);
         }
-        if (windowed) {
+        if (windowed && !rounds) {
             __syncthreads();
-            if (COMPACT) {
-                const uint2 *src = reinterpret_cast<const uint2 *>(win);
-                uint2 *dst = reinterpret_cast<uint2 *>(area);
-                for (uint32_t i = tid; i < total; i += kThreads) dst[i] = src[i];
-            } else {
-                const uint4 *src = reinterpret_cast<const uint4 *>(win);
-                uint4 *dst = reinterpret_cast<uint4 *>(area);
-                for (uint32_t i = tid; i < total; i += kThreads) dst[i] = src[i];
-            }
+            copy_out(0u, total);
         }
     }
     if (ta.th != nullptr) plan_tile_finish(ta, d, (int64_t)b * d.H + h, pending);
@@ -1101,7 +1132,10 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
     int64_t want = (int64_t)d.Nq * d.P * (compact ? 8 : 16);
     if (tp.nt_min > 1) want = want / tp.nt_min + want / tp.nt_min / 4;
     if (const char *e = getenv("MMFS_SORT_WINDOW_KB")) want = std::min<int64_t>(atoll(e) * 1024, kMaxSortWindow);
-    if (want > kMaxSortWindow) return floor_bytes;
+    // more records than the largest window: placed window by window while that takes few rounds (the SD block's
+    // 32768 samples per level: two), else the direct path (MMFS_SORT_ROUNDS=0: always the direct path)
+    static const int max_rounds = getenv("MMFS_SORT_ROUNDS") ? atoi(getenv("MMFS_SORT_ROUNDS")) : 4;
+    if (want > kMaxSortWindow) return (kWindowRounds && want <= (int64_t)max_rounds * kMaxSortWindow) ? kMaxSortWindow : floor_bytes;
     return (uint32_t)std::max<int64_t>(floor_bytes, (want + 15) / 16 * 16);
 }
 
@@ -1138,7 +1172,7 @@ struct Scratch {
     TileHeader *th;
     TileDesc *tdesc;
     TileItem *titems;
-    uint32_t *slice_done;
+    uint32_t *slice_done, *n_extra;
     float *tpartials;
     uint32_t tile_cap_extra, tile_cap_partials;
     int tile_blocks_bound;     // >= 4x4 blocks of one (b, h)
@@ -1154,7 +1188,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     char *p = (char *)workspace;
     s.loc_t = p;                 p += up(pts * 2 * es);
     s.attn_t = p;                p += up(pts * es);
-    s.cursor = (uint32_t *)p;    s.cursor_bytes = up(((int64_t)d.B * d.H * d.L + (int64_t)d.B * d.H) * 4);  p += s.cursor_bytes;   // + one arrival counter per slice
+    s.cursor = (uint32_t *)p;    s.cursor_bytes = up(((int64_t)d.B * d.H * d.L + 2 * (int64_t)d.B * d.H) * 4);  p += s.cursor_bytes;   // + per slice: an arrival counter, the length of its queue of extra items
     s.hdr = (CellHeader *)p;
     p += up((int64_t)sizeof(CellHeader) + (int64_t)d.L * sizeof(LevelRow) + (int64_t)make_params(d).tiles_bound * sizeof(CTile));
     s.celltab = (uint2 *)p;      p += up((int64_t)d.B * d.H * cell_stride_of(d) * 8);
@@ -1177,17 +1211,19 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     // ceil(n / kTileChunk) items, so items and partial tiles are bounded by twice the visits / kTileChunk.  (The
     // bounds assume the AVERAGE 25/16 visits per sample; a block whose items or tiles do not fit is walked by one
     // wave alone -- slow, still correct.)
-    s.th = nullptr; s.tdesc = nullptr; s.titems = nullptr; s.slice_done = nullptr; s.tpartials = nullptr;
+    s.th = nullptr; s.tdesc = nullptr; s.titems = nullptr; s.slice_done = nullptr; s.n_extra = nullptr; s.tpartials = nullptr;
     s.tile_cap_extra = s.tile_cap_partials = 0; s.tile_blocks_bound = 0;
     if (tile_reduce_supported(dtype, d)) {
         const int64_t tvisits = pts * (kTB + 1) * (kTB + 1) / (kTB * kTB);
         s.tile_blocks_bound = (int)std::min<int64_t>((int64_t)d.S / 4 + d.L + 1, 0x3fffffff);
         s.tile_cap_partials = (uint32_t)std::min<int64_t>(2 * (tvisits / kTileChunk) + 64, 0x3fffffff);
-        s.tile_cap_extra = (uint32_t)std::min<int64_t>((tvisits / kTileChunk) / kTileLanes * 2 + 64, 0x3fffffff);   // per lane
+        // queue places per (b, h) slice: twice what the slice's average share of the visits needs
+        s.tile_cap_extra = (uint32_t)std::min<int64_t>(2 * ((int64_t)d.Nq * d.L * d.P * (kTB + 1) * (kTB + 1) / (kTB * kTB) / kTileChunk) + 16, 0x3fffffff);
         s.th = (TileHeader *)p;      p += up(sizeof(TileHeader));
         s.tdesc = (TileDesc *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TileDesc));
-        s.titems = (TileItem *)p;    p += up((int64_t)kTileLanes * s.tile_cap_extra * sizeof(TileItem));
+        s.titems = (TileItem *)p;    p += up((int64_t)d.B * d.H * s.tile_cap_extra * sizeof(TileItem));
         s.slice_done = s.cursor + (int64_t)d.B * d.H * d.L;      // (zeroed with the cursors by backward_value_prepare)
+        s.n_extra = s.slice_done + (int64_t)d.B * d.H;
         s.tpartials = (float *)p;    p += up((int64_t)s.tile_cap_partials * kTB * kTB * d.D * 4);
     }
     s.total = p - (char *)workspace;
@@ -1222,7 +1258,7 @@ TileReduceArgs tile_args(const Scratch &sc, const Dims &d)
 {
     TileReduceArgs a;
     a.records = sc.records; a.celltab = sc.celltab; a.hdr = sc.hdr; a.cell_stride = cell_stride_of(d);
-    a.th = sc.th; a.tdesc = sc.tdesc; a.titems = sc.titems; a.slice_done = sc.slice_done; a.tpartials = sc.tpartials;
+    a.th = sc.th; a.tdesc = sc.tdesc; a.titems = sc.titems; a.slice_done = sc.slice_done; a.n_extra = sc.n_extra; a.tpartials = sc.tpartials;
     a.blocks_bound = sc.tile_blocks_bound;
     return a;
 }
@@ -1421,7 +1457,7 @@ hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *gr
     }
     if (sc.th != nullptr) {
         const TileReduceArgs a = tile_args(sc, d);
-        return tile_reduce(dtype, grad_out, grad_value, a, d, st);
+        return tile_reduce(dtype, grad_out, grad_value, a, d, sc.tile_cap_extra, st);
     }
     switch (dtype) {
         case 0: return dispatch_reduce<float>(sc, grad_out, grad_value, d, st);

@@ -58,7 +58,6 @@ constexpr int kKS = 16;                 // records per MFMA step (K of 32x32x16)
 constexpr int kStages = 2;              // row slots: one being multiplied, one in flight (more waves per CU beat a deeper pipe)
 constexpr int kRecBatch = 4 * kKS;      // records fetched at a time (one DMA, 64 lanes): four steps' worth
 constexpr int kRecSlots = 2;            // record batches in LDS
-constexpr int kQueueWgs = 256 * kTileLanes;   // workgroups that walk the queue of extra items
 
 template <typename T> struct TileMma;
 template <> struct TileMma<bf16_t> {
@@ -415,65 +414,68 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
     TPROF_FLUSH();
 }
 
-// One wave per work item.  The first kQueueWgs workgroups walk the queue of extra items (the later
-// parts of long lists: started first, they are the long poles); every other workgroup is one block.
+// One wave per work item.  A (b, h) slice's workgroups are consecutive in the dispatch order of their XCD (h is the
+// fastest index): first the slice's queue of extra items -- the later parts of long lists, the long poles -- then
+// its blocks, coarse levels first.  The XCD's L2 then holds one or two slices' grad_out rows at a time (a queue
+// shared by the whole batch, walked first, had every XCD read rows of all B slices of its head at once: 544 MB of
+// traffic for 156 MB of algorithmic bytes at the north star, r03q).
 template <typename T, int D>
 __global__ void __launch_bounds__(64, 4)
 msda_bwd_tile_reduce(const T *__restrict__ grad_out, T *__restrict__ grad_value, const TileReduceArgs a,
-                     const Dims d, const int blocks_grid)
+                     const Dims d, const int blocks_grid, const int extra_grid)
 {
     typedef TileGeom<D> G;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
-    int w = blockIdx.x;
-    if (w < kQueueWgs) {
-        const int ql = w % kTileLanes;
-        const uint32_t n = a.hdr->stamp == header_stamp(d) ? min(a.th->n_extra[ql], a.th->cap_extra) : 0u;
-        for (uint32_t i = (uint32_t)(w / kTileLanes); i < n; i += kQueueWgs / kTileLanes) {
-            const TileItem ti = a.titems[(size_t)ql * a.th->cap_extra + i];
-            if (ti.part == kVoidPart) continue;            // a reservation its block could not use
-            ItemArgs it;
-            it.b = (int)(ti.bh / (uint32_t)d.H); it.h = (int)(ti.bh % (uint32_t)d.H);
-            it.part = (int)ti.part; it.whole = false; it.partial_out = true; it.pidx = ti.pidx;
-            TileDesc *tdp = a.tdesc + ((int64_t)ti.bh * a.blocks_bound + ti.blk);
-            const TileDesc td = *tdp;
-            tile_item<T, D>(grad_out, grad_value, a, d, td, it, &tdp->arrived, lds);
-        }
-        return;
-    }
-    w -= kQueueWgs;
-    const int nblk = a.hdr->stamp == header_stamp(d) ? a.hdr->n_blocks4 : 0;       // (a plan made for other dimensions: nothing to do)
+    const int w = blockIdx.x;
     ItemArgs it;
     it.h = w % d.H;
     const int t = w / d.H;
-    const int j = t % blocks_grid;
-    it.b = t / blocks_grid;
+    const int per_slice = extra_grid + blocks_grid;
+    int j = t % per_slice;
+    it.b = t / per_slice;
+    if (a.hdr->stamp != header_stamp(d)) return;                 // (a plan made for other dimensions: nothing to do)
+    const int64_t bh = (int64_t)it.b * d.H + it.h;
+    if (j < extra_grid) {
+        const uint32_t n = min(a.n_extra[bh], a.th->cap_extra);
+        if ((uint32_t)j >= n) return;
+        const TileItem ti = a.titems[(size_t)bh * a.th->cap_extra + j];
+        if (ti.part == kVoidPart) return;                  // a reservation its block could not use
+        it.part = (int)ti.part; it.whole = false; it.partial_out = true; it.pidx = ti.pidx;
+        TileDesc *tdp = a.tdesc + (bh * a.blocks_bound + ti.blk);
+        const TileDesc td = *tdp;
+        tile_item<T, D>(grad_out, grad_value, a, d, td, it, &tdp->arrived, lds);
+        return;
+    }
+    j -= extra_grid;
+    const int nblk = a.hdr->n_blocks4;
     if (j >= nblk) return;
     const int blk = nblk - 1 - j;                          // coarse levels (long lists) first
-    TileDesc *tdp = a.tdesc + (((int64_t)it.b * d.H + it.h) * a.blocks_bound + blk);
+    TileDesc *tdp = a.tdesc + (bh * a.blocks_bound + blk);
     const TileDesc td = *tdp;
     it.part = 0; it.whole = td.parts <= 1; it.partial_out = td.parts > 1; it.pidx = td.pbase;
     tile_item<T, D>(grad_out, grad_value, a, d, td, it, &tdp->arrived, lds);
 }
 
 template <typename T, int D>
-hipError_t launch_tile(const void *go, void *gv, const TileReduceArgs &a, const Dims &d, hipStream_t st)
+hipError_t launch_tile(const void *go, void *gv, const TileReduceArgs &a, const Dims &d, uint32_t cap_extra, hipStream_t st)
 {
     // the exact block count is only known on the device; the grid takes the caller's hint (host copy
-    // of the level table) or the bound, surplus workgroups return at once
+    // of the level table) or the bound, surplus workgroups return at once.  Queue places: the slice's capacity
+    // (how many are taken is only known on the device)
     const int blocks_grid = d.blocks4 > 0 ? std::min(d.blocks4, a.blocks_bound) : a.blocks_bound;
-    const int64_t items = (int64_t)d.B * d.H * blocks_grid;
-    if (items + kQueueWgs > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_bwd_tile_reduce<T, D>), dim3((unsigned)(items + kQueueWgs)), dim3(64), 0, st,
-                       (const T *)go, (T *)gv, a, d, blocks_grid);
+    const int64_t items = (int64_t)d.B * d.H * ((int64_t)blocks_grid + cap_extra);
+    if (items > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((msda_bwd_tile_reduce<T, D>), dim3((unsigned)items), dim3(64), 0, st,
+                       (const T *)go, (T *)gv, a, d, blocks_grid, (int)cap_extra);
     return hipGetLastError();
 }
 template <typename T>
-hipError_t dispatch_tile(const void *go, void *gv, const TileReduceArgs &a, const Dims &d, hipStream_t st)
+hipError_t dispatch_tile(const void *go, void *gv, const TileReduceArgs &a, const Dims &d, uint32_t cap_extra, hipStream_t st)
 {
     switch (d.D) {
-        case 32: return launch_tile<T, 32>(go, gv, a, d, st);
-        case 64: return launch_tile<T, 64>(go, gv, a, d, st);
-        case 128: return launch_tile<T, 128>(go, gv, a, d, st);
+        case 32: return launch_tile<T, 32>(go, gv, a, d, cap_extra, st);
+        case 64: return launch_tile<T, 64>(go, gv, a, d, cap_extra, st);
+        case 128: return launch_tile<T, 128>(go, gv, a, d, cap_extra, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -503,7 +505,7 @@ bool tile_reduce_supported(int dtype, const Dims &d)
     if (d.L > kMaxLevels) return false;
     if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'b' || e[0] == 'p') return false;     // "block", "pixel"
     // queue entries carry (b, h) and the block in 32 bits each; grid = B*H*blocks (+ queue) workgroups
-    if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1) + kQueueWgs > 0x7fffffffLL) return false;
+    if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1 + 2 * ((int64_t)d.Nq * d.L * d.P * 25 / 16 / kTileChunk) + 16) > 0x7fffffffLL) return false;
     // the rows are fetched through a buffer descriptor over one (b, h) slice: 31-bit byte offsets
     const int64_t es = 2;
     if ((int64_t)d.Nq * d.H * d.D * es > kMaxSlabBytes) return false;
@@ -512,11 +514,11 @@ bool tile_reduce_supported(int dtype, const Dims &d)
 }
 
 hipError_t tile_reduce(int dtype, const void *grad_out, void *grad_value, const TileReduceArgs &a, const Dims &d,
-                       hipStream_t st)
+                       uint32_t cap_extra, hipStream_t st)
 {
     switch (dtype) {
-        case 1: return dispatch_tile<half_t>(grad_out, grad_value, a, d, st);
-        case 2: return dispatch_tile<bf16_t>(grad_out, grad_value, a, d, st);
+        case 1: return dispatch_tile<half_t>(grad_out, grad_value, a, d, cap_extra, st);
+        case 2: return dispatch_tile<bf16_t>(grad_out, grad_value, a, d, cap_extra, st);
         default: return hipErrorInvalidValue;
     }
 }

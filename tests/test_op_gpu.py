@@ -159,7 +159,8 @@ SORT_ROUTES = {
     "kept_window":          (torch.bfloat16, 4, 301, None, None),   # samples kept in registers, records through the LDS window, tiles plan their own blocks
     "kept_window_seams":    (torch.bfloat16, 4, 302, "3", None),    # levels cut into bands: local blocks + the seams' blocks by the slice's last workgroup
     "kept_window_p8":       (torch.float16, 8, 303, "2", None),     # two vectors per query: the placing pass reads the words again
-    "kept_window_too_small": (torch.bfloat16, 4, 1000, None, "21"), # a tile's records exceed the window: placed straight into memory
+    "kept_window_too_small": (torch.bfloat16, 4, 1000, None, "21"), # a tile's records exceed the window: placed window by window (two rounds)
+    "kept_window_rounds_p8": (torch.float16, 8, 900, None, "21"),   # ... three rounds, the words read again before each (the SD block's route)
     "two_scan_window":      (torch.bfloat16, 2, 304, None, None),   # 8-byte query rows (scalar scan): second scan into the window
     "two_scan_window_seams": (torch.bfloat16, 3, 305, "4", None),
     "direct":               (torch.bfloat16, 4, 306, None, "0"),    # no window: cursors + scattered stores
