@@ -102,13 +102,17 @@ __device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { r
 
 // ---------------------------------------------------------------- matrix-core reduce (msda_bwd_tile.hip)
 // Blocks of kTB x kTB pixels; their index space lives in LevelRow::bbase4 / nbx4 / nby4 and
-// CellHeader::n_blocks4.  A block's list of records is cut into work items of kTileChunk records;
+// CellHeader::n_blocks4.  A block's list of records is cut into work items of tile_chunk(D) records;
 // a block of more than one item leaves fp32 partial tiles that a last small kernel adds up.
 constexpr int kTB = 4;
 #ifndef MMFS_TILE_CHUNK
 #define MMFS_TILE_CHUNK 1024
 #endif
-constexpr int kTileChunk = MMFS_TILE_CHUNK;
+// (records per work item: MMFS_TILE_CHUNK for heads of 128 channels; narrower heads move half / a quarter of the bytes
+// per record, so their items hold twice / four times the records -- the same 256 KB of grad_out rows per item.  Measured,
+// r03r: 2048 at D = 128 costs the north star 18 us of reduce, 1024 at D = 64 costs the LLM shape 45 MB of fp32 partial
+// tiles each way -- and 20 us of the NEXT forward, whose inputs they push out of the memory-side cache)
+__host__ __device__ inline int tile_chunk(int D) { return MMFS_TILE_CHUNK * (D >= 128 ? 1 : D >= 64 ? 2 : 4); }
 
 struct TileHeader {
     uint32_t spare0[8];
@@ -151,7 +155,7 @@ constexpr uint32_t kVoidPart = 0xffffffffu;
 // items; the extra ones are queued, slice by slice.
 __device__ inline void queue_block(const TileReduceArgs &a, const Dims &d, int64_t bh, int blk, TileDesc &td, int64_t n)
 {
-    const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
+    const uint32_t parts = (uint32_t)((n + tile_chunk(d.D) - 1) / tile_chunk(d.D));
     if (parts > 1) {
         const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
         const uint32_t eb = atomicAdd(&a.n_extra[bh], parts - 1);
@@ -241,7 +245,7 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
     TileDesc td;
     const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
     a.tdesc[bh * a.blocks_bound + blk] = td;
-    const uint32_t parts = (uint32_t)((n + kTileChunk - 1) / kTileChunk);
+    const uint32_t parts = (uint32_t)((n + tile_chunk(d.D) - 1) / tile_chunk(d.D));
     if (parts > 1) {
         pd.blk = blk; pd.parts = parts;
         pd.pb = atomicAdd(&a.th->n_partials, parts);

@@ -4,6 +4,7 @@
 #include "../../include/mmfs_msda.h"
 #include "msda_launch.h"
 #include "msda_gv_mma.h"
+#include "msda_plan.h"
 #include <cstring>
 #include <cstdlib>
 
@@ -447,8 +448,13 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     // (one kernel for every level where the LDS-resident formulation applies: the "fine" stage then does all the
     // levels and the "coarse" stage has nothing left)
     const bool fused_taps = mmfs::taps_mma_applies(dtype, d);
+    // (when this call runs both halves and the grad_value half would open with nothing but "clear the cursors, plan",
+    // the first workgroup of the grad_loc / grad_attn kernel does that on the side: one launch less)
+    mmfs::blk::PrepareJob job;
+    const bool folded = fused_taps && (stages & MMFS_HYB_BWD_TAPS_FINE) && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels &&
+                        mmfs::value_prepare_job(dtype, loc, attn, shapes, start, workspace, d, &job);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && fused_taps)
-        e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn, d, false, st, nullptr);
+        e = mmfs::backward_taps_mma(dtype, value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, folded ? &job : nullptr);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && !fused_taps && !(dense_taps && plan.fine_taps.n == 0))
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
                                 d, false, st, dense_taps ? &plan.fine_taps : nullptr);
@@ -459,7 +465,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     // (the prepare stage always plans: a staged pass then runs the very kernels of the one-call pass)
     // (when the workgroup-local kernel serves every level, the sort and the tile reduce have nothing to do: not launched)
     bool planned = false;
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels)
+    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels && !folded)
         e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st, shapes, start, &planned);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_SORT) && sorted_levels)
         e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, true);

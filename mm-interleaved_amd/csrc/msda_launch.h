@@ -33,9 +33,16 @@ bool bwd_has_vector_path(int dtype, const Dims &d);
 // others by row gather (replaces msda_bwd_vec + msda_taps_coarse where it applies).             [msda_taps_mma.hip]
 bool taps_mma_supported(int dtype, const Dims &d);
 bool taps_mma_applies(int dtype, const Dims &d);        // supported, expected to pay, and d.taps_algo does not say otherwise
+// job (msda_plan.h; may be null): the grad_value half's opening launch -- clear the sort's cursors, plan -- done by this
+// kernel's first workgroup on the side; value_prepare_job says whether that is all the opening launch would do.
+namespace blk { struct PrepareJob; }
 hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *grad_out, void *grad_loc, void *grad_attn,
-                             const Dims &d, hipStream_t st);
+                             const Dims &d, hipStream_t st, const blk::PrepareJob *job = nullptr);
+// Fills *job and returns true when backward_value_prepare for these arguments would neither re-pack loc / attn nor do
+// anything but clear cursors and plan (block generation, the sort reads loc / attn where they are); else false.
+bool value_prepare_job(int dtype, const void *loc, const void *attn, const int64_t *shapes, const int64_t *start,
+                       void *workspace, const Dims &d, blk::PrepareJob *job);
 
 // grad_value by pixel-stationary tiles: no atomics, no fp32 buffer, every element of
 // grad_value (storage dtype) written exactly once.     [msda_bwd_value.hip]

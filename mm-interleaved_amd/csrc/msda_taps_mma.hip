@@ -25,6 +25,8 @@
 // brings a host copy of the level table).
 #include "msda_dots.h"
 #include "msda_mma_common.h"
+#include "msda_plan.h"
+#include <cstring>
 #include "msda_launch.h"
 #include <cstdlib>
 
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(kMmaThreads)
 msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
               const T *__restrict__ loc, const T *__restrict__ attn, const T *__restrict__ grad_out,
               T *__restrict__ grad_loc, T *__restrict__ grad_attn, const Dims d, const int q_per_wg, const int img_budget,
-              const int n_runs)
+              const int n_runs, const blk::PrepareJob job)
 {
     constexpr int LPI = D * 2 / 16, QPW = 64 / LPI;
     constexpr int GSH = QPW * D * 2;                                      // the wave's grad_out rows (B operand source)
@@ -315,13 +317,23 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         }
     }
     }   // runs
+    // ---- the opening launch of the grad_value half, hosted here (one launch less per backward): the FIRST workgroup --
+    // done long before the kernel is -- clears the sort's cursors and plans it; its LDS is free by now
+    if (job.cursor_words > 0 && blockIdx.x == 0) {
+        __syncthreads();
+        blk::prepare_tail(job, smem);
+    }
 }
 
 // ---------------------------------------------------------------- launcher
 template <typename T, int D>
 static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, const int64_t *start, const void *loc,
-                                  const void *attn, const void *go, void *gl, void *ga, Dims d, hipStream_t st)
+                                  const void *attn, const void *go, void *gl, void *ga, Dims d, hipStream_t st,
+                                  const blk::PrepareJob *job)
 {
+    blk::PrepareJob jb;
+    if (job != nullptr) jb = *job;
+    else { memset(&jb, 0, sizeof(jb)); }
     typedef MmaGeom<D, (64 / (D * 2 / 16)) * D * 2> G;
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_taps_mma<T, D>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
@@ -337,7 +349,7 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
     const int grid = (int)std::min<int64_t>(runs, persistent_grid());      // (= runs unless MMFS_MMA_GRID asks for persistent workgroups)
     hipLaunchKernelGGL((msda_taps_mma<T, D>), dim3((unsigned)grid), dim3(kMmaThreads), kLdsTotal, st,
                        (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga,
-                       d, q_per_wg, kLdsTotal - G::IMG0, (int)runs);
+                       d, q_per_wg, kLdsTotal - G::IMG0, (int)runs, jb);
     return hipGetLastError();
 }
 
@@ -361,10 +373,10 @@ bool taps_mma_applies(int dtype, const Dims &d)
 
 hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                              const void *loc, const void *attn, const void *grad_out, void *grad_loc, void *grad_attn,
-                             const Dims &d, hipStream_t st)
+                             const Dims &d, hipStream_t st, const blk::PrepareJob *job)
 {
-    if (dtype == 1) return launch_taps_mma<half_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st);
-    return launch_taps_mma<bf16_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st);
+    if (dtype == 1) return launch_taps_mma<half_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
+    return launch_taps_mma<bf16_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
 }
 
 }  // namespace mmfs

@@ -865,3 +865,18 @@ def test_lds_blocks_full_size_slab_against_the_sorted_path():
     assert np.isfinite(a).all()
     assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), np.abs(b)) + 1e-5 * np.abs(b).max())     # (+ cancellation)
     assert np.abs(a).max() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_value_plan_hosted_by_the_taps_kernel(dtype, monkeypatch):
+    """One-call backward on a registered table, heads of 128 channels, >= 256 queries: the grad_value half's opening
+    launch (clear the sort's cursors, plan) is done by the first workgroup of the grad_loc / grad_attn kernel
+    (csrc/msda_plan.h, PrepareJob).  Same gradients as with the launch of its own (MMFS_PREPARE_IN_TAPS=0) and as the
+    oracle's; repeated calls on recycled workspaces keep agreeing (the cursors ARE cleared)."""
+    import MultiScaleDeformableAttention as MSDA
+    x = make_inputs(2, 8, 128, 515, 4, [(64, 64), (32, 32), (16, 16), (8, 8)], seed=37, loc_range=(-0.1, 1.1), dtype=dtype)
+    want = run_oracle(x)
+    for setting in ("1", "0", "1"):
+        monkeypatch.setenv("MMFS_PREPARE_IN_TAPS", setting)
+        for _ in range(3):
+            check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, f"plan in taps = {setting}")
