@@ -1270,13 +1270,13 @@ bool value_prepare_job(int dtype, const void *loc, const void *attn, const int64
     if (off && off[0] == '0') return false;
     if (!bwd_value_tiled_supported(dtype, d) || !bwd_value_block_supported(dtype, d) || !shapes || !start) return false;
     const TileParams tp = make_params(d);
+    const Scratch sc = carve(workspace, dtype, d);
+    job->pa = plan_args(shapes, start, sc, d, tp);
+    job->cursor = sc.cursor; job->cursor_words = sc.cursor_bytes / 4;
     const bool aligned = (uintptr_t)loc % 16 == 0 && (uintptr_t)attn % 8 == 0;
     const char *e = getenv("MMFS_SORT_REPACK");
     if (!aligned || !sort_keeps_samples(dtype, d, tp) || (e && e[0] == '1')) return false;
-    const Scratch sc = carve(workspace, dtype, d);
-    job->pa = plan_args(shapes, start, sc, d, tp);
     job->pa.loc_src = loc; job->pa.attn_src = attn;
-    job->cursor = sc.cursor; job->cursor_words = sc.cursor_bytes / 4;
     return true;
 }
 
