@@ -451,7 +451,10 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     // (when this call runs both halves and the grad_value half would open with nothing but "clear the cursors, plan",
     // the first workgroup of the grad_loc / grad_attn kernel does that on the side: one launch less)
     mmfs::blk::PrepareJob job;
-    const bool folded = fused_taps && (stages & MMFS_HYB_BWD_TAPS_FINE) && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels &&
+    // (... or, with heads the LDS-levels kernel does not take, the first workgroup of the dense-levels kernel)
+    const bool host_mma = fused_taps && (stages & MMFS_HYB_BWD_TAPS_FINE);
+    const bool host_dense = !fused_taps && dense_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE);
+    const bool folded = (host_mma || host_dense) && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels &&
                         mmfs::value_prepare_job(dtype, loc, attn, shapes, start, workspace, d, &job);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_TAPS_FINE) && fused_taps)
         e = mmfs::backward_taps_mma(dtype, value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, folded ? &job : nullptr);
@@ -459,7 +462,8 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
         e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, nullptr, grad_loc, grad_attn,
                                 d, false, st, dense_taps ? &plan.fine_taps : nullptr);
     if (e == hipSuccess && dense_taps && !fused_taps && (stages & MMFS_HYB_BWD_TAPS_COARSE))
-        e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st);
+        e = mmfs::backward_taps_coarse(dtype, value, loc, attn, grad_out, grad_loc, grad_attn, d, plan, st,
+                                       folded && host_dense ? &job : nullptr);
     // (the plan rides in the prepare launch only when this very call also sorts; the hybrid path needs
     // MMFS_BWD_CANONICAL_LEVELS, so every grad_value row has an owner and no zero-fill pass is due)
     // (the prepare stage always plans: a staged pass then runs the very kernels of the one-call pass)

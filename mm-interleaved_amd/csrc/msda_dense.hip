@@ -23,6 +23,8 @@
 // matrix cores by another route: csrc/msda_bwd_tile.hip.)
 #include "msda_device.h"
 #include "msda_launch.h"
+#include "msda_plan.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace mmfs {
@@ -114,7 +116,7 @@ template <typename T, int NS, int MB>
 __global__ void __launch_bounds__(MB * 512)
 msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ attn,
                  const T *__restrict__ grad_out, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
-                 const Dims d, const DotPlan cp, const int chunks, const int tiles_per_chunk)
+                 const Dims d, const DotPlan cp, const int chunks, const int tiles_per_chunk, const blk::PrepareJob job)
 {
     constexpr int KB = 2 * NS;                      // 16-channel steps
     constexpr int VPR = 4 * NS;                     // 16-byte vectors per grad_out row (D / 8)
@@ -253,6 +255,12 @@ msda_taps_coarse(const T *__restrict__ value, const T *__restrict__ loc, const T
     }
     if (have_pending) lookups(pend, pxy, pa, G[buf ^ 1]);
     PROF_END(0);
+    // ---- the grad_value half's opening launch, hosted here when one call runs both halves (msda_plan.h): the first
+    // workgroup clears the sort's cursors and plans; the product tiles serve as its scratch
+    if (job.cursor_words > 0 && blockIdx.x == 0) {
+        __syncthreads();
+        blk::prepare_tail(job, reinterpret_cast<unsigned char *>(&G[0][0]));
+    }
 }
 
 // chunks of query tiles per (b, h) so that about ``target`` workgroups exist
@@ -269,8 +277,11 @@ int tile_chunks(const Dims &d, int tile_q = kTileQ, int target = 256)
 #endif
 template <typename T, int NS>
 hipError_t launch_taps_coarse(const void *value, const void *loc, const void *attn, const void *go,
-                              void *gl, void *ga, const Dims &d, const DotPlan &cp, hipStream_t st)
+                              void *gl, void *ga, const Dims &d, const DotPlan &cp, hipStream_t st, const blk::PrepareJob *job)
 {
+    blk::PrepareJob jb;
+    if (job != nullptr) jb = *job;
+    else memset(&jb, 0, sizeof(jb));
     constexpr int MB = MMFS_TAPS_MB;                // 2: 64-query tiles, 1024 lanes, one workgroup per CU (59 us at cfg2); 1: 68 us
     if (d.P > 16) return hipErrorInvalidValue;
     const int chunks = tile_chunks(d, 32 * MB, MB == 1 ? 768 : 256);
@@ -280,7 +291,7 @@ hipError_t launch_taps_coarse(const void *value, const void *loc, const void *at
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((msda_taps_coarse<T, NS, MB>), dim3((unsigned)blocks), dim3(512 * MB), 0, st,
                        (const T *)value, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga, d, cp,
-                       chunks, tpc);
+                       chunks, tpc, jb);
     return hipGetLastError();
 }
 
@@ -361,10 +372,10 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
 
 hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, const void *attn,
                                 const void *grad_out, void *grad_loc, void *grad_attn, const Dims &d,
-                                const HybridPlan &p, hipStream_t st)
+                                const HybridPlan &p, hipStream_t st, const blk::PrepareJob *job)
 {
     if (!p.dots_active) return hipErrorInvalidValue;
-    MMFS_DENSE_DISPATCH(launch_taps_coarse, value, loc, attn, grad_out, grad_loc, grad_attn, d, p.dots, st);
+    MMFS_DENSE_DISPATCH(launch_taps_coarse, value, loc, attn, grad_out, grad_loc, grad_attn, d, p.dots, st, job);
 }
 
 }  // namespace mmfs

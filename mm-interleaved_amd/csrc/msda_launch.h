@@ -89,7 +89,7 @@ struct HybridPlan {
 HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes, const int64_t *host_start);
 hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, const void *attn,
                                 const void *grad_out, void *grad_loc, void *grad_attn, const Dims &d,
-                                const HybridPlan &p, hipStream_t st);
+                                const HybridPlan &p, hipStream_t st, const blk::PrepareJob *job = nullptr);   // job: as backward_taps_mma
 
 hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st);
 

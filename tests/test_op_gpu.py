@@ -880,3 +880,10 @@ def test_value_plan_hosted_by_the_taps_kernel(dtype, monkeypatch):
         monkeypatch.setenv("MMFS_PREPARE_IN_TAPS", setting)
         for _ in range(3):
             check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, f"plan in taps = {setting}")
+    # heads of 64 channels: the dense-levels kernel (csrc/msda_dense.hip) is the host
+    x = make_inputs(2, 4, 64, 300, 8, [(32, 32), (16, 16), (8, 8)] * 2, seed=41, loc_range=(-0.1, 1.1), dtype=dtype)
+    want = run_oracle(x)
+    for setting in ("1", "0", "1"):
+        monkeypatch.setenv("MMFS_PREPARE_IN_TAPS", setting)
+        for _ in range(2):
+            check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, f"plan in dense taps = {setting}")
