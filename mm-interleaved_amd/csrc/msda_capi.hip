@@ -188,13 +188,21 @@ int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shap
         return MMFS_E_ALIGN;
 
     if (use_tiled(dtype, d, flags)) {
+        if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+        const bool canonical = (flags & MMFS_BWD_CANONICAL_LEVELS) != 0;
+        // (the grad_value half's opening launch hosted by the LDS-levels taps kernel where that one runs: msda_plan.h)
+        mmfs::blk::PrepareJob job;
+        if (mmfs::taps_mma_applies(dtype, d) && mmfs::value_prepare_job(dtype, loc, attn, shapes, start, workspace, d, &job)) {
+            hipError_t e = mmfs::backward_taps_mma(dtype, value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, &job);
+            if (e != hipSuccess) return (int)e;
+            return (int)mmfs::backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st, true, canonical);
+        }
         hipError_t e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out,
                                            nullptr, grad_loc, grad_attn, d, false, st);
         if (e != hipSuccess) return (int)e;
-        if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
-        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
         return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value,
-                                               workspace, d, st, (flags & MMFS_BWD_CANONICAL_LEVELS) != 0);
+                                               workspace, d, st, canonical);
     }
     // ---- float-atomic path
     const bool narrow = (dtype == MMFS_F16 || dtype == MMFS_BF16);
