@@ -270,6 +270,9 @@ struct KeptScan {
     // Two vectors per query (P = 8 of 16-bit storage): the samples' words AND their keys do not fit the 128
     // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits).
     static constexpr bool kKeepRaw = NV == 1;
+    // G > 1: a query's samples span G * NV vectors (many points per query: the reference's own speed test has 64);
+    // "virtual query" tid + u * kThreads then stands for vectors (qv % G) * NV .. + NV of query qv / G
+    int G = 1;
 
     // in_place: loc / attn are the op's own [B, Nq, H, L, P] arrays (a query's P samples of this (h, level) are
     // contiguous there too: the same vectors, one per 2 * H * L * P elements instead of back to back -- the
@@ -281,14 +284,15 @@ struct KeptScan {
         const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int q = (int)threadIdx.x + u * kThreads;
-            const int qq = min(q, d.Nq - 1);
+            const int qv = min((int)threadIdx.x + u * kThreads, d.Nq * G - 1);
+            const int qq = G == 1 ? qv : qv / G;
+            const int v0 = (qv - qq * G) * NV;
             const int64_t s0 = in_place ? ((((int64_t)b * d.Nq + qq) * d.H + h) * d.L + tl.level) * d.P
                                         : s_first + (int64_t)qq * d.P;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v];
-                araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v];
+                lraw[u][v] = reinterpret_cast<const uint4 *>(loc + 2 * s0)[v0 + v];
+                araw[u][v] = reinterpret_cast<const uint2 *>(attn + s0)[v0 + v];
             }
         }
     }
@@ -298,7 +302,7 @@ struct KeptScan {
         const int tw = tl.xb - tl.xa;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int q = (int)threadIdx.x + u * kThreads;
+            const int q = (int)threadIdx.x + u * kThreads;                // (virtual query)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float l[VEC], a[VEC];
@@ -306,7 +310,7 @@ struct KeptScan {
                 V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
 #pragma unroll
                 for (int i = 0; i < SPV; ++i) {
-                    const int pl = q < d.Nq ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw) : -1;
+                    const int pl = q < d.Nq * G ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw) : -1;
                     key[u][v][i] = pl < 0 ? kNoCell : ((uint32_t)pl | (atomicAdd(&off[pl], 1u) << kCellBits));
                 }
             }
@@ -323,7 +327,8 @@ struct KeptScan {
         if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const uint32_t q = threadIdx.x + u * kThreads;
+            const uint32_t qv = threadIdx.x + u * kThreads;
+            const uint32_t q = G == 1 ? qv : qv / (uint32_t)G;            // the record carries the query
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const uint32_t lw[4] = {lraw[u][v].x, lraw[u][v].y, lraw[u][v].z, lraw[u][v].w};
@@ -356,6 +361,7 @@ struct KeptScan {
 struct TileParams {
     int tiles_bound;
     int nt_min;
+    int vgroups;      // kept scan: groups of NV vectors per query (1 unless a query's samples of a level span more than NV vectors)
 };
 
 // Development aid (tools/exp_build.sh sprof "-DMMFS_PROFILE_SORT"; tools/sort_prof.py): shader clocks per phase of
@@ -413,8 +419,9 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     constexpr int KNV = NV > 0 ? NV : 1;
     // (only where the launch expects windows: into memory, the two-scan path's stores are the faster -- SD 512 px
     // geometry, 32768 samples per level: 151 us against 196)
-    const bool kept = NV > 0 && d.Nq <= kThreads * kScanUnroll && win_bytes > kMaxTileCells * 4u;
+    const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= kThreads * kScanUnroll && win_bytes > kMaxTileCells * 4u;
     KeptScan<T, KNV, COMPACT> ks;
+    ks.G = tp.vgroups;
 
     // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
     const bool in_place = hdr->loc_src != nullptr;
@@ -952,6 +959,7 @@ TileParams make_params(const Dims &d)
     const int64_t cells = 2LL * d.S + 2LL * d.L;
     const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((cells + kMaxTileCells - 1) / kMaxTileCells) + d.L;
     tp.tiles_bound = (int)std::min<int64_t>(bound, 0x3fffffff);
+    tp.vgroups = 1;
     return tp;
 }
 
@@ -974,12 +982,31 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
 
 // One trip of the scan with a window to sort into: the sort keeps its samples in registers (KeptScan) -- and can
 // then read them from the op's own arrays, so that nothing has to be re-packed.  (MMFS_SORT_REPACK=1 re-packs anyway.)
+// How the sort reads a query's samples of a level: NV 16-byte vectors per (virtual) query, G virtual queries per query.
+// One or two vectors per query (P <= 8 of 16-bit storage): G = 1, every path of the sort takes them.  More (the reference's
+// own speed test has 64 points per level): only the kept scan can, as G groups of NV vectors -- when all of them fit one
+// trip and a window exists; else NV = 0, the scalar scan.  (MMFS_SORT_MANY_POINTS=0: always the scalar scan.)
+struct KeptCfg { int nv, g; };
+KeptCfg kept_config(int es, const Dims &d, const TileParams &tp, bool compact)
+{
+    KeptCfg c = {0, 1};
+    const int loc_bytes = d.P * 2 * es;
+    if (loc_bytes % 16 != 0) return c;
+    const int vpq = loc_bytes / 16;
+    if (vpq <= 2) { c.nv = vpq; return c; }
+    const char *e = getenv("MMFS_SORT_MANY_POINTS");
+    if ((e && e[0] == '0') || sort_window_bytes(d, tp, compact) <= kMaxTileCells * 4u) return c;
+    if ((int64_t)d.Nq * vpq <= kThreads * kScanUnroll) { c.nv = 1; c.g = vpq; }
+    else if (vpq % 2 == 0 && (int64_t)d.Nq * (vpq / 2) <= kThreads * kScanUnroll) { c.nv = 2; c.g = vpq / 2; }
+    return c;
+}
+
 bool sort_keeps_samples(int dtype, const Dims &d, const TileParams &tp)
 {
-    const int es = dtype == 0 ? 4 : 2, loc_bytes = d.P * 2 * es;
-    if (loc_bytes % 16 != 0 || loc_bytes / 16 > 2) return false;
+    const int es = dtype == 0 ? 4 : 2;
     const bool compact = es == 2 && tile_reduce_supported(dtype, d);
-    return d.Nq <= kThreads * kScanUnroll && sort_window_bytes(d, tp, compact) > kMaxTileCells * 4u;
+    const KeptCfg c = kept_config(es, d, tp, compact);
+    return c.nv > 0 && (int64_t)d.Nq * c.g <= kThreads * kScanUnroll && sort_window_bytes(d, tp, compact) > kMaxTileCells * 4u;
 }
 
 int cell_stride_of(const Dims &d) { return 2 * d.S + 2 * d.L; }      // >= sum (H+1)(W+1)
@@ -1112,9 +1139,10 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
 
 template <typename T, int NV>
 hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
-                       hipStream_t st)
+                       hipStream_t st, int vgroups)
 {
-    const TileParams tp = make_params(d);
+    TileParams tp = make_params(d);
+    tp.vgroups = vgroups;
     const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
@@ -1145,13 +1173,11 @@ template <typename T>
 hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
                          hipStream_t st)
 {
-    const int loc_bytes = d.P * 2 * (int)sizeof(T);
-    int nv = 0;
-    if (loc_bytes % 16 == 0 && loc_bytes / 16 <= 2) nv = loc_bytes / 16;
-    switch (nv) {
-        case 1: return launch_sort<T, 1>(shapes, start, sc, d, planned, st);
-        case 2: return launch_sort<T, 2>(shapes, start, sc, d, planned, st);
-        default: return launch_sort<T, 0>(shapes, start, sc, d, planned, st);
+    const KeptCfg c = kept_config((int)sizeof(T), d, make_params(d), sizeof(T) == 2 && sc.th != nullptr);
+    switch (c.nv) {
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, planned, st, c.g);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, planned, st, c.g);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, planned, st, 1);
     }
 }
 

@@ -654,6 +654,8 @@ MANY_POINT_CASES = [
     (2, 8, 128, 128, 64, [(16, 16), (8, 8)]),                  # the reference's speed test, batch cut to 2
     (1, 4, 64, 70, 32, [(12, 9), (6, 5), (3, 3)]),             # P = 32, K = 96, odd extents
     (1, 2, 32, 33, 64, [(20, 20), (7, 4)]),                    # D = 32 (scalar record scan), a level of 400 pixels
+    (1, 2, 64, 300, 16, [(9, 9), (4, 4)]),                     # 4 vectors x 300 queries = 1200 virtual queries: one vector each, two trips' worth of threads
+    (1, 2, 64, 1500, 12, [(9, 9), (4, 4)]),                    # 3 vectors per query, 4500 virtual queries: too many for one trip -> the scalar scan
 ]
 
 
@@ -669,7 +671,12 @@ def test_many_points_per_level(case, dtype, route, monkeypatch):
     if route == "atomic":
         monkeypatch.setattr(MSDA, "_bwd_algo", "atomic")
     got = run_hip(x, dtype, use_autograd=False, register=(route == "registered"))
-    check(got, run_oracle(x), dtype, f"P={P} {route}")
+    want = run_oracle(x)
+    check(got, want, dtype, f"P={P} {route}")
+    if route == "registered":
+        # many vectors per query: the kept scan takes them as groups of virtual queries (default) -- or the scalar scan does
+        monkeypatch.setenv("MMFS_SORT_MANY_POINTS", "0")
+        check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, f"P={P} scalar scan")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
