@@ -102,7 +102,7 @@ int mmfs_msda_forward(int dtype,
  *   LDS levels   (csrc/msda_fwd_mma.hip)  16-bit storage, D in {64, 128}, L <= 64: the levels of the pyramid
  *                that fit in the CU's LDS (smallest first, decided on the device from the table) are copied
  *                there once per workgroup and sampled by the matrix cores, the others by row gather.
- * flags = 0 picks LDS levels for heads of 128 channels when a (b, h) slab has at least 256 queries (heads of
+ * flags = 0 picks LDS levels for heads of 128 channels when a (b, h) slab has at least 64 queries and 4096 samples (heads of
  * 64 channels measured no faster that way and stay on the row gather unless MMFS_FWD_LDS_LEVELS asks).
  * MMFS_FWD_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED.
  */
@@ -147,7 +147,7 @@ int mmfs_msda_forward_flags(int dtype,
  *                matrix-core product over all their pixels (csrc/msda_dense.hip);
  *   LDS levels   csrc/msda_taps_mma.hip: one kernel for all levels, 16-bit storage, D = 128, L <= 64; the levels that
  *                fit in the CU's LDS (decided on the device) are contracted on the matrix cores from GATHERED rows,
- *                the others by row gather.  Default from 256 queries per (b, h) slab on.
+ *                the others by row gather.  Default from 64 queries and 4096 samples per (b, h) slab on.
  * MMFS_BWD_TAPS_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
 #define MMFS_BWD_TAPS_ROW_GATHER 64u
 #define MMFS_BWD_TAPS_LDS_LEVELS 128u

@@ -432,7 +432,9 @@ bool fwd_mma_applies(int dtype, const Dims &d)
     // channels (the decoders' real geometry: 128-byte rows, 8 queries per wave) measured no faster than the
     // row-gather kernel (profiles/r03_experiments.md, r03c: SD block 364 vs 345 us, LLM 4 images 250 vs 248):
     // they stay on msda_fwd_vec unless asked for (MMFS_FWD_LDS_LEVELS / MMFS_FWD_ALGO=mma)
-    return d.D == 128 && d.Nq >= 256;
+    // (r03ac: what matters is the samples a workgroup sees per image fill -- the reference's speed-test shape, 128 queries
+    // of 128 samples, runs 132 -> 91 us this way; 128 queries of 16 samples do not pay)
+    return d.D == 128 && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;
 }
 
 hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

@@ -368,7 +368,7 @@ bool taps_mma_applies(int dtype, const Dims &d)
     if (d.taps_algo == 1 || (d.taps_algo == 0 && algo && algo[0] == 'v')) return false;
     if (!taps_mma_supported(dtype, d)) return false;
     if (d.taps_algo == 2 || (algo && algo[0] == 'm')) return true;
-    return d.Nq >= 256;
+    return d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;          // (as fwd_mma_applies: samples per image fill; speed-test shape 139 -> 102 us)
 }
 
 hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

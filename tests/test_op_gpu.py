@@ -596,9 +596,12 @@ def test_lds_levels_forward_non_finite_rows_stay_with_their_queries(D):
 
 
 def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
-    """From 256 queries per (b, h) slab on, 16-bit heads of 64 / 128 channels take the LDS-resident formulation
-    (and the autograd function's outputs and gradients still match the oracle on such a shape)."""
-    x = make_inputs(1, 4, 128, 300, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    """From 4096 samples per (b, h) slab on (and at least 64 queries), 16-bit heads of 128 channels take the LDS-resident
+    formulation (and the autograd function's outputs and gradients still match the oracle on such a shape); below, the
+    row gather."""
+    x = make_inputs(1, 4, 128, 100, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0     # 1200 samples
+    x = make_inputs(1, 4, 128, 352, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
     a, g = run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "lds")
     assert max_abs(a, g) == 0.0
     assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0        # (a different summation order: not bit-equal)
@@ -726,11 +729,11 @@ def test_lds_levels_taps_match_oracle(case, dtype, route, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_lds_levels_taps_are_the_default_and_agree_with_the_row_gather(dtype, monkeypatch):
-    """From 256 queries per slab on, heads of 128 channels take the fused kernel; against the row gather + dense pair
+    """From 4096 samples per slab on, heads of 128 channels take the fused kernel; against the row gather + dense pair
     the same dots come out in another summation order, the algebra after them is the same code."""
     import MultiScaleDeformableAttention as MSDA
-    x = make_inputs(2, 4, 128, 300, 4, [(24, 24), (16, 16), (8, 8)], seed=19, loc_range=(-0.1, 1.1), dtype=dtype)
-    keep = (torch.rand(2, 300, 1, 3, 1, generator=torch.Generator().manual_seed(1)) < 0.6).double()
+    x = make_inputs(2, 4, 128, 352, 4, [(24, 24), (16, 16), (8, 8)], seed=19, loc_range=(-0.1, 1.1), dtype=dtype)
+    keep = (torch.rand(2, 352, 1, 3, 1, generator=torch.Generator().manual_seed(1)) < 0.6).double()
     x["attn"] = (x["attn"] * keep).to(dtype).to(torch.float64)
     res = {}
     for algo in ("auto", "lds", "gather"):
@@ -743,7 +746,7 @@ def test_lds_levels_taps_are_the_default_and_agree_with_the_row_gather(dtype, mo
         check(res[algo], want, dtype, algo)
     # the lazy hint (MMFS's softmax never reads the gradients of a zero weight): zeros there, the rest bit-equal
     dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
-    args = [dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn")] + [dev(x["grad"]).reshape(2, 300, -1), 1]
+    args = [dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn")] + [dev(x["grad"]).reshape(2, 352, -1), 1]
     monkeypatch.setattr(MSDA, "_taps_algo", "lds")
     full = MSDA.ms_deform_attn_backward(*args)
     lazy = MSDA.ms_deform_attn_backward(*args, lazy_zero_attn=True)
