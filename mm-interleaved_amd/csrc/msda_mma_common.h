@@ -20,7 +20,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kMmaWaves = 16;                 // waves per workgroup (one workgroup per CU: the LDS image is shared)
+#ifndef MMFS_MMA_WAVES
+#define MMFS_MMA_WAVES 16
+#endif
+constexpr int kMmaWaves = MMFS_MMA_WAVES;     // waves per workgroup (one workgroup per CU: the LDS image is shared)
 constexpr int kMmaThreads = kMmaWaves * 64;
 constexpr int kMmaMaxLevels = 64;             // level table kept in LDS
 constexpr int kChunk = 16;                    // samples of a query staged at a time (one per lane of a 16-lane group)
