@@ -27,7 +27,7 @@ def one_case(rng, idx):
     B = rng.randint(1, 3)
     H = rng.choice([1, 2, 3, 4, 8, 16])
     D = rng.choice([8, 16, 24, 32, 64, 64, 128, 128, 256])
-    P = rng.choice([1, 2, 3, 4, 4, 8, 8, 16])
+    P = rng.choice([1, 2, 3, 4, 4, 8, 8, 16, 32, 64])
     L = rng.randint(1, 6)
     shapes = [(rng.randint(1, 24), rng.randint(1, 24)) for _ in range(L)]
     if rng.random() < 0.3:
@@ -38,7 +38,7 @@ def one_case(rng, idx):
         shapes = [(rng.randint(1, 64), rng.randint(1, 64)) for _ in range(L)]
         Nq = rng.choice([1024, 3000, 4097])
     elif B * Nq * H * L * P * D > 6e7:
-        Nq = 33
+        Nq = 33 if P < 32 else 130
     g = torch.Generator().manual_seed(idx)
     sh = torch.tensor(shapes, dtype=torch.long)
     st = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
@@ -74,6 +74,15 @@ def one_case(rng, idx):
         os.environ["MMFS_VALUE_ALGO"] = algo
     MSDA._hybrid = hybrid
     MSDA._bwd_algo = "atomic" if rng.random() < 0.08 else "auto"
+    # round 3's routes: the grad_value plan hosted by the taps kernels or launched on its own; a small sort window (records
+    # placed window by window); the scalar scan for queries of many points
+    os.environ["MMFS_PREPARE_IN_TAPS"] = rng.choice(["0", "1", "1"])
+    if rng.random() < 0.25:
+        os.environ["MMFS_SORT_WINDOW_KB"] = "21"
+    else:
+        os.environ.pop("MMFS_SORT_WINDOW_KB", None)
+    os.environ["MMFS_SORT_MANY_POINTS"] = rng.choice(["0", "1", "1"])
+    MSDA._ws_cache.clear()
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
     desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
             f"value={algo} bwd={MSDA._bwd_algo}")
