@@ -41,10 +41,19 @@ class MMFSRMSNorm(nn.Module):
         return self.weight * x
 
 
+_centre = {}
+
+
 def centre_reference_points(n_tokens, device):
     """[1, n_tokens, 1, 2] filled with (0.5, 0.5): the pixel centre of a 1x1 grid, what the
-    reference's get_reference_points([(1, 1)]) yields, repeated per token (:306-307)."""
-    return torch.full((1, 1, 1, 2), 0.5, dtype=torch.float32, device=device).expand(1, n_tokens, 1, 2)
+    reference's get_reference_points([(1, 1)]) yields, repeated per token (:306-307).  One 2-element tensor per
+    device, made once (outside any inference mode: it outlives the call), expanded per call."""
+    key = str(torch.device(device))
+    base = _centre.get(key)
+    if base is None:
+        with torch.inference_mode(False), torch.no_grad():
+            base = _centre[key] = torch.full((1, 1, 1, 2), 0.5, dtype=torch.float32, device=device)
+    return base.expand(1, n_tokens, 1, 2)
 
 
 def deform_inputs(hidden_states, vision_hidden_states, spatial_shapes=((16, 16),)):
@@ -88,19 +97,31 @@ class LlamaMMFSAttention(nn.Module):
         self.norm1 = MMFSRMSNorm(config.hidden_size, eps=eps)
         self.norm2 = MMFSRMSNorm(self.vision_hidden_size, eps=eps)
 
-    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None):
+    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None, image_ranks=None):
         """hidden_states [B, Lq, hidden]; vision_hidden_states [B, n, sum hw, image_embed_dim];
         cross_attention_mask [B, Lq', n] (float, 1 = visible) -> [B, Lq, hidden].
         ``value`` (an addition): this layer's ``value_proj(norm2(vision_hidden_states))`` [B, n, sum hw, d_inner] as
-        a ``LlamaMMFSSchedule`` projected it for all layers at once; the bank is then only looked at for its shape."""
+        a ``LlamaMMFSSchedule`` projected it for all layers at once; the bank is then only looked at for its shape.
+        ``image_ranks`` (another): ``LlamaMMFSSchedule.image_ranks(cross_attention_mask, Lq)``, made once per step."""
         hidden_states = self.norm1(hidden_states)
         if value is None:
             vision_hidden_states = self.norm2(vision_hidden_states)
         ref, shapes, start = deform_inputs(hidden_states, vision_hidden_states, self.spatial_shapes)
         out = self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                         input_spatial_shapes=shapes, input_level_start_index=start,
-                        input_padding_mask=None, attention_mask=cross_attention_mask, value=value)
-        return out * self.gate.tanh()
+                        input_padding_mask=None, attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks)
+        return out * self._gate()
+
+    def _gate(self):
+        """tanh(gate) (modeling_llama_mmfs.py:356): a one-element kernel per layer and step; without gradients it is
+        kept until the parameter moves."""
+        if torch.is_grad_enabled():
+            return self.gate.tanh()
+        sig = (self.gate.data_ptr(), self.gate._version, self.gate.dtype, torch.is_inference_mode_enabled())
+        hit = getattr(self, "_gate_tanh", None)
+        if hit is None or hit[0] != sig:
+            hit = self._gate_tanh = (sig, self.gate.tanh())
+        return hit[1]
 
 
 class ProjectedBank:
@@ -142,6 +163,12 @@ class LlamaMMFSSchedule:
         self.layers = list(layers)
         assert self.layers and all(isinstance(l, LlamaMMFSAttention) for l in self.layers)
         self._projected = None
+
+    def image_ranks(self, cross_attention_mask, n_queries):
+        """The images' ranks among the visible ones, per token (ops/modules/mmfs.py:154-163): a function of the mask
+        only, the same for every layer of a step -- half a dozen small integer kernels once instead of once per layer.
+        Pass it to each layer as ``image_ranks=``."""
+        return self.layers[0].attn._image_relpos(cross_attention_mask, n_queries)
 
     def can_fuse(self):
         n0, v0 = self.layers[0].norm2, self.layers[0].attn.value_proj

@@ -57,7 +57,7 @@ class GraphedLlamaMMFSStack:
     8-10 layers are ~850 small launches that the host issues several times more slowly than the GPU runs them.
 
     ``g = GraphedLlamaMMFSStack(layers, hidden, features, mask)`` projects the bank once (LlamaMMFSSchedule), records
-    ``for k: h = h + layers[k](h, features, mask, value=bank.values[k])`` over a static input buffer and
+    ``for k: h = h + layers[k](h, features, mask, value=bank.values[k], image_ranks=ranks)`` over a static input buffer and
     ``g(hidden)`` replays it.  The dense LLaMA layers that sit between the MMFS layers in the real decoder are out
     of scope here (a caller that graphs its whole decode step captures these layers with the rest: the op and the
     modules are capture-safe as they are -- no device->host copy, current stream, allocator workspaces).
@@ -71,6 +71,8 @@ class GraphedLlamaMMFSStack:
                 else LlamaMMFSSchedule(self.layers).project(vision_hidden_states)
             self._bank, self._mask = bank, cross_attention_mask.clone()
             self._hidden = hidden.clone()
+            # (the mask is fixed for the life of the graph: the images' ranks are made here, once, not in it)
+            self._ranks = self.layers[0].attn._image_relpos(self._mask, hidden.shape[1])
             side = torch.cuda.Stream(device=hidden.device)
             side.wait_stream(torch.cuda.current_stream(hidden.device))
             with torch.cuda.stream(side):          # first calls fill the caches (level tables)
@@ -84,7 +86,7 @@ class GraphedLlamaMMFSStack:
     def _run(self):
         h = self._hidden
         for k, layer in enumerate(self.layers):
-            h = h + layer(h, self._bank.bank, self._mask, value=self._bank.values[k])
+            h = h + layer(h, self._bank.bank, self._mask, value=self._bank.values[k], image_ranks=self._ranks)
         return h
 
     @torch.no_grad()

@@ -82,6 +82,7 @@ class MMFS(nn.Module):
         self.value_proj = nn.Linear(d_value, d_inner)
         self.output_proj = nn.Linear(d_inner, d_out)
         self.query_relpos = nn.Embedding(max_num_image_per_seq, d_query)
+        self._tables = None                       # (parameter signature, what _plan_tables made of them) -- no-grad calls only
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -102,7 +103,9 @@ class MMFS(nn.Module):
     # ------------------------------------------------------------------ pieces
     def _image_relpos(self, attention_mask, Lq):
         """Newest visible image -> 1, older -> 2, 3, ...; invisible -> 0 (mmfs.py:154-163).
-        Returns [N, 1 or Lq, n] (long)."""
+        Returns [N, 1 or Lq, n] (long).  It depends on the mask only: the MMFS layers of a decoder, which are all
+        handed the same mask in a step (modeling_llama_mmfs.py:352-353), can share it -- ``forward(...,
+        image_ranks=...)``, ``LlamaMMFSSchedule.image_ranks``."""
         m = attention_mask.long()
         relpos = (m.sum(-1, keepdim=True) + 1 - m.cumsum(-1)) * m
         if relpos.dim() == 2:
@@ -111,7 +114,36 @@ class MMFS(nn.Module):
             relpos = relpos[:, -1:, :]
         return relpos
 
-    def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images, sampler=None):
+    def _plan_tables(self, fused):
+        """What the plan needs that depends on the PARAMETERS only: the relative-position table pushed through the two
+        heads (``off_tab`` [max_img, H*P*2]; ``att_tab`` -- all H*L*(P+1) columns for the framework-op statement, the
+        P point columns for the fused kernel) and, for the fused kernel, the point columns of the attention head
+        itself.  With gradients they are part of the graph and made per call (mmfs.py:174-176 evaluates them inside
+        head(q + table[relpos])); without (sampling, decoding) they are kept until a parameter moves -- three of a
+        layer's six small GEMMs and two weight-slicing copies per decode step."""
+        keep = not torch.is_grad_enabled()
+        sig = None
+        if keep:
+            ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.attention_weights.weight, self.attention_weights.bias)
+            sig = (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps)
+            if self._tables is not None and self._tables[0] == sig:
+                return self._tables[1]
+        table = self.query_relpos.weight                                      # [max_img, d_query]
+        off_tab = F.linear(table, self.sampling_offsets.weight)               # [max_img, H*P*2]
+        if fused:
+            H, L, P = self.n_heads, self.n_levels, self.n_points
+            dq = self.attention_weights.in_features
+            aw_w = self.attention_weights.weight.view(H, L, P + 1, dq)[:, :, :P].reshape(H * L * P, dq)
+            aw_b = self.attention_weights.bias.view(H, L, P + 1)[:, :, :P].reshape(H * L * P)
+            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b)
+        else:
+            res = (off_tab, F.linear(table, self.attention_weights.weight), None, None)   # [max_img, H*L*(P+1)]
+        if keep:
+            self._tables = (sig, res)
+        return res
+
+    def sampling_plan(self, query, reference_points, input_spatial_shapes, attention_mask, n_images, sampler=None,
+                      image_ranks=None):
         """Everything between the query and the op: sampling locations [N,Lq,H,n*L,P,2],
         attention weights over the real points [N,Lq,H,n*L,P], and the summed sink weights
         [N,Lq,H] (mmfs.py:154-163, 174-265)."""
@@ -120,23 +152,19 @@ class MMFS(nn.Module):
         nL = n * L
         assert attention_mask.dim() in (2, 3) and attention_mask.shape[-1] == n
 
-        relpos = self._image_relpos(attention_mask, Lq)                       # [N, 1|Lq, n]
+        relpos = self._image_relpos(attention_mask, Lq) if image_ranks is None else image_ranks     # [N, 1|Lq, n]
+        assert relpos.dim() == 3 and relpos.shape[0] == N and relpos.shape[1] in (1, Lq) and relpos.shape[2] == n
         if n >= self.max_num_image_per_seq:       # only then can an index leave the table
             assert int(relpos.max()) < self.max_num_image_per_seq
 
         q = self.dynamic_offset_mask(query)                                   # one GEMM, not n
-        table = self.query_relpos.weight                                      # [max_img, d_query]
-        off_tab = F.linear(table, self.sampling_offsets.weight)               # [max_img, H*P*2]
-        att_tab = F.linear(table, self.attention_weights.weight)              # [max_img, H*L*(P+1)]
 
         if self.fused_plan and mmfs_plan_supported(q, reference_points, L, P, n):
             # one gfx950 kernel for the rest (csrc/mmfs_plan.hip), fp32 inside, rounded once.  Only
             # the P point columns of the attention head are evaluated: its (P+1)-th column is
             # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
-            dq = self.attention_weights.in_features
-            aw_w = self.attention_weights.weight.view(H, L, P + 1, dq)[:, :, :P].reshape(H * L * P, dq)
-            aw_b = self.attention_weights.bias.view(H, L, P + 1)[:, :, :P].reshape(H * L * P)
-            heads = (self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, F.linear(table, aw_w), relpos,
+            off_tab, att_tab, aw_w, aw_b = self._plan_tables(True)
+            heads = (self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, att_tab, relpos,
                      reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
             if sampler is not None:
                 # inference: the plan feeds the sampler inside one kernel (``sampler`` = (value, level starts));
@@ -148,6 +176,7 @@ class MMFS(nn.Module):
             loc, attn, sink_sum = MMFSPlanFunction.apply(*heads)
             return loc, attn, sink_sum
 
+        off_tab, att_tab, _, _ = self._plan_tables(False)
         # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
         offsets = self.sampling_offsets(q)[:, :, None, :] + off_tab[relpos]
         offsets = offsets.view(N, Lq, n, H, 1, P, 2) * self.scale_ratios.view(1, 1, 1, 1, L, 1, 1).to(offsets.dtype)
@@ -181,10 +210,11 @@ class MMFS(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, attention_mask=None, value=None):
+                input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None):
         """Arguments and result as mmfs.py:120-141 (``value`` is an addition: the caller's own
         ``value_proj(input_flatten)`` [N, n, hw, d_inner], e.g. one an ``MMFSNet`` projected for
-        all its blocks at once; ``input_flatten`` is then only looked at for its shape):
+        all its blocks at once; ``input_flatten`` is then only looked at for its shape; ``image_ranks`` another: this
+        module's ``_image_relpos(attention_mask, Lq)`` as a caller made it once for several layers):
         query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
         input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
         input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
@@ -210,7 +240,8 @@ class MMFS(nn.Module):
                 and not (torch.is_grad_enabled() and (query.requires_grad or value.requires_grad
                                                       or any(p.requires_grad for p in self.parameters()))))
         loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes, attention_mask, n,
-                                               sampler=(value, input_level_start_index) if fuse else None)
+                                               sampler=(value, input_level_start_index) if fuse else None,
+                                               image_ranks=image_ranks)
         if loc is None:
             out = attn                            # (the fused kernel's result)
         else:

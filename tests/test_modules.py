@@ -449,3 +449,49 @@ def test_llama_schedule_keeps_the_projected_bank_only_while_nothing_moves():
     assert d is not c and sched._projected is None
     for k, l in enumerate(layers):
         assert torch.allclose(d.values[k], l.attn.value_proj(l.norm2(feats)), atol=1e-12)
+
+
+def test_decode_caches_follow_the_parameters_and_the_mask(oracle_op):
+    """Without gradients (sampling, decoding) a layer keeps what depends on its PARAMETERS only -- the relative-position
+    table pushed through the two heads, tanh(gate) -- and the layers of a step can share the images' ranks
+    (``LlamaMMFSSchedule.image_ranks``: a function of the mask only).  Same outputs as with gradients enabled (where
+    nothing is kept); a parameter that moves in place is seen."""
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    layers = _llama_stack(2, seed=5)
+    g = torch.Generator().manual_seed(2)
+    B, Lq, n, hw = 2, 3, 2, 64 + 16 + 4
+    hidden = torch.randn(B, Lq, 64, generator=g, dtype=torch.float64)
+    feats = torch.randn(B, n, hw, 32, generator=g, dtype=torch.float64)
+    mask = torch.tensor([[[1, 1]] * Lq, [[1, 0]] * Lq], dtype=torch.float32)
+
+    sched = LlamaMMFSSchedule(layers)
+
+    def stack(m, shared=False):
+        ranks = sched.image_ranks(m, Lq) if shared else None
+        h = hidden
+        for l in layers:
+            h = h + l(h, feats, m, image_ranks=ranks)
+        return h
+
+    want = stack(mask.clone()).detach()                                  # gradients enabled: nothing kept
+    assert all(l.attn._tables is None for l in layers)
+    with torch.no_grad():
+        a = stack(mask)
+        t0 = layers[0].attn._tables
+        assert t0 is not None
+        b = stack(mask, shared=True)
+        assert layers[0].attn._tables is t0                              # second step: kept
+        close(a, want.numpy(), 1e-12); close(b, want.numpy(), 1e-12)
+        # a parameter moves in place (an optimiser step between two evaluations): seen
+        layers[0].attn.query_relpos.weight.add_(0.5)
+        layers[1].gate.add_(0.25)
+        c = stack(mask)
+        assert layers[0].attn._tables is not t0
+    want2 = stack(mask.clone()).detach()
+    close(c, want2.numpy(), 1e-12)
+    assert not torch.allclose(c, a)
+    with torch.no_grad():
+        mask[1, :, 1] = 1.0                                              # (the second sequence's second image becomes visible)
+        d = stack(mask, shared=True)
+    close(d, stack(mask.clone()).detach().numpy(), 1e-12)
+    assert not torch.allclose(d, c)

@@ -1,0 +1,45 @@
+"""Which kernels a decode step of the 8 MMFS layers (Vicuna-7B geometry) launches: name, count, device time
+(tools/module_bench.py's cfg3, Lq = 1, projected bank kept)."""
+import contextlib, io, os, sys, types
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd")]
+import torch
+from torch.profiler import ProfilerActivity, profile
+from mmfs_amd.blocks import LlamaMMFSAttention, LlamaMMFSSchedule
+
+dev, dt = "cuda", torch.bfloat16
+cfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, rms_norm_eps=1e-6,
+                            max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
+torch.manual_seed(0)
+with contextlib.redirect_stdout(io.StringIO()):
+    layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt) for i in range(8)]
+B, n, S, Lq = 4, 1, 1344, int(sys.argv[1]) if len(sys.argv) > 1 else 1
+feats = torch.randn(B, n, S, 1024, device=dev, dtype=dt)
+hidden = torch.randn(B, Lq, 4096, device=dev, dtype=dt)
+mask = torch.ones(B, Lq, n, device=dev)
+sched = LlamaMMFSSchedule(layers)
+
+
+def step():
+    with torch.no_grad():
+        bank = sched.project(feats)
+        ranks = sched.image_ranks(mask, Lq)
+        h = hidden
+        for k, l in enumerate(layers):
+            h = h + l(h, feats, mask, value=bank.values[k], image_ranks=ranks)
+        return h
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+iters = 5
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+tot = sum(e.device_time_total for e in rows) / iters
+print("Lq = %d: %.0f us of kernels per step, %d launches" % (Lq, tot, sum(e.count for e in rows) // iters))
+for e in rows[:40]:
+    print("  %7.1f us  x%-4d %s" % (e.device_time_total / iters, e.count // iters, e.key[:150]))

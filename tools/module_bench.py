@@ -126,9 +126,10 @@ def cfg3():
                 if not keep:
                     sched.clear_cache()
                 bank = sched.project(feats)
+                ranks = sched.image_ranks(mask, Lq)
                 h = hidden
                 for k, l in enumerate(layers):
-                    h = h + l(h, feats, mask, value=bank.values[k])
+                    h = h + l(h, feats, mask, value=bank.values[k], image_ranks=ranks)
                 return h
 
         def train_sched():
