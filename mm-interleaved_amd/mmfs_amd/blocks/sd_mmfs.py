@@ -121,14 +121,14 @@ class MMFSBlock(nn.Module):
             self.__dict__["_pos_cache"] = hit
         return hit[1]
 
-    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None):
+    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None):
         B, C, H, W = sample.shape
         n_images = ms_feat_mask.shape[-1]
         ref, shapes, start = deform_inputs(sample, spatial_shapes, n_images)
         query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
         query = query + self._pos_table(H * W)
         out = self.mmfs(query, ref, self.feat_norm(ms_feat) if value is None else ms_feat, shapes, start,
-                        input_padding_mask=None, attention_mask=ms_feat_mask, value=value)
+                        input_padding_mask=None, attention_mask=ms_feat_mask, value=value, image_ranks=image_ranks)
         # the zero-initialised 1x1 convolution (sd_mmfs.py:88-94, 146) is a per-token linear map:
         # applied on the token-major tensor it is one GEMM each way (the convolution library's 1x1
         # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
@@ -137,18 +137,19 @@ class MMFSBlock(nn.Module):
             return out.transpose(1, 2).reshape(B, C, H, W)
         return self.conv(out.transpose(1, 2).reshape(B, C, H, W))
 
-    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None):
+    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None):
         """sample [B, C_q, H, W]; ms_feat [B, n, sum_l H_l*W_l, C_v]; ms_feat_mask [B, n];
         spatial_shapes: the levels of ONE image, list of (H_l, W_l)  ->  [B, C_q, H, W].
         ``value`` (an addition to sd_mmfs.py:121-146): this block's
-        ``mmfs.value_proj(feat_norm(ms_feat))`` when the caller already has it (``MMFSNet``)."""
+        ``mmfs.value_proj(feat_norm(ms_feat))`` when the caller already has it (``MMFSNet``); ``image_ranks``
+        (another): ``mmfs._image_relpos(ms_feat_mask, ...)``, a function of the mask only, made once for all blocks."""
         spatial_shapes = [tuple(int(v) for v in s) for s in spatial_shapes]
         if self.gradient_checkpointing and self.training:
             # the op is stateless and re-entrant: the forward is simply re-run in backward
             # (a projected ``value`` is an input of the checkpoint: kept, not recomputed)
-            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value,
+            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
                                  use_reentrant=False)
-        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value)
+        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks)
 
 
 class ProjectedFeatures:
@@ -283,7 +284,9 @@ class MMFSNet(nn.Module):
             shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
             bank = self._pack(mmfs_features)
             values = [None] * (len(self.mmfs_down_blocks) + 1)
-        new_res = tuple(r + blk(r, bank, mmfs_mask, shapes, value=v)
+        # (the images' ranks among the visible ones depend on the mask only: once for the 13 blocks)
+        ranks = self.mmfs_mid_block.mmfs._image_relpos(mmfs_mask, 1) if mmfs_mask.dim() == 2 else None
+        new_res = tuple(r + blk(r, bank, mmfs_mask, shapes, value=v, image_ranks=ranks)
                         for r, blk, v in zip(down_block_res_samples, self.mmfs_down_blocks, values))
-        sample = sample + self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1])
+        sample = sample + self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1], image_ranks=ranks)
         return sample, new_res
