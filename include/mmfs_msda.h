@@ -426,6 +426,13 @@ int mmfs_rmsnorm_forward(int dtype, const void *x, const void *weight, void *y, 
                          int64_t rows, int64_t C, float eps, void *stream);
 int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
                           void *grad_x, float *grad_weight_f32, int64_t rows, int64_t C, void *stream);
+/* The same backward without atomics: workgroup g leaves ITS sum of the gain gradient in row g of
+ * ``grad_weight_partials`` [mmfs_rmsnorm_backward_partials_rows(rows), C] fp32 (every element written: no zeroing), and
+ * the caller adds the rows up (one framework reduction).  2 M float atomics on C addresses from hundreds of workgroups on
+ * 8 XCDs were 150 of mmfs_rmsnorm_backward's 180 us at 8192 x 4096; what the Python operator package calls. */
+int mmfs_rmsnorm_backward_partials_rows(int64_t rows);
+int mmfs_rmsnorm_backward_partials(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
+                                   void *grad_x, float *grad_weight_partials, int64_t rows, int64_t C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 // one fp32 atomic per column and workgroup.
 #include "../../include/mmfs_msda.h"
 #include "msda_device.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace mmfs {
@@ -90,7 +91,7 @@ rmsnorm_fwd(const T *__restrict__ x, const T *__restrict__ w, T *__restrict__ y,
 template <typename T, int NV>
 __global__ void __launch_bounds__(kNormThreads)
 rmsnorm_bwd(const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ w, const float *__restrict__ rstd_in,
-            T *__restrict__ dx, float *__restrict__ dw, const int64_t rows, const int C)
+            T *__restrict__ dx, float *__restrict__ dw, const int64_t rows, const int C, const int partials)
 {
     typedef NormIO<T> IO;
     constexpr int N = IO::N;
@@ -164,7 +165,11 @@ rmsnorm_bwd(const T *__restrict__ dy, const T *__restrict__ x, const T *__restri
                     float s = dwa[i][j0 + j];
 #pragma unroll
                     for (int ow = 0; ow < kNormThreads / 64 - 1; ++ow) s += red[(ow * 64 + lane) * 4 + j];
-                    if (v < nvec && s != 0.f)
+                    if (v >= nvec) continue;
+                    // partials: this workgroup's row of a [gridDim.x, C] fp32 matrix the caller adds up (plain stores: 2 M
+                    // atomics on 4096 addresses from 512 workgroups on 8 XCDs took 150 of this kernel's 180 us); else dw += s
+                    if (partials) dw[(int64_t)blockIdx.x * C + (int64_t)v * N + j0 + j] = s;
+                    else if (s != 0.f)
                         __hip_atomic_fetch_add(dw + (int64_t)v * N + j0 + j, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -230,25 +235,46 @@ int mmfs_rmsnorm_forward(int dtype, const void *x, const void *weight, void *y, 
     return (int)hipGetLastError();
 }
 
-int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
-                          void *grad_x, float *grad_weight_f32, int64_t rows, int64_t C, void *stream)
+static int rmsnorm_backward_impl(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
+                                 void *grad_x, float *gw, int64_t rows, int64_t C, int grid, int partials, void *stream)
 {
     if (dtype != MMFS_F32 && dtype != MMFS_F16 && dtype != MMFS_BF16) return MMFS_E_DTYPE;
     if (rows < 0 || C < 0) return MMFS_E_DIMS;
     if (rows == 0 || C == 0) return MMFS_OK;
     if (!mmfs_rmsnorm_supported(dtype, C)) return MMFS_E_UNSUPPORTED;
-    if (!grad_y || !x || !weight || !rstd || !grad_x || !grad_weight_f32) return MMFS_E_NULLPTR;
+    if (!grad_y || !x || !weight || !rstd || !grad_x || !gw) return MMFS_E_NULLPTR;
     if (((uintptr_t)grad_y | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)grad_x) % 16) return MMFS_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = std::min(mmfs::norm_grid(rows), 512);          // (fewer workgroups: fewer atomics on the gain gradient)
     using namespace mmfs;
     const int nv = norm_nv(dtype, C);
     switch (dtype) {
-        case MMFS_F32: MMFS_NORM_DISPATCH(rmsnorm_bwd, float, (const float *)grad_y, (const float *)x, (const float *)weight, rstd, (float *)grad_x, grad_weight_f32, rows, (int)C); break;
-        case MMFS_F16: MMFS_NORM_DISPATCH(rmsnorm_bwd, half_t, (const half_t *)grad_y, (const half_t *)x, (const half_t *)weight, rstd, (half_t *)grad_x, grad_weight_f32, rows, (int)C); break;
-        default: MMFS_NORM_DISPATCH(rmsnorm_bwd, bf16_t, (const bf16_t *)grad_y, (const bf16_t *)x, (const bf16_t *)weight, rstd, (bf16_t *)grad_x, grad_weight_f32, rows, (int)C); break;
+        case MMFS_F32: MMFS_NORM_DISPATCH(rmsnorm_bwd, float, (const float *)grad_y, (const float *)x, (const float *)weight, rstd, (float *)grad_x, gw, rows, (int)C, partials); break;
+        case MMFS_F16: MMFS_NORM_DISPATCH(rmsnorm_bwd, half_t, (const half_t *)grad_y, (const half_t *)x, (const half_t *)weight, rstd, (half_t *)grad_x, gw, rows, (int)C, partials); break;
+        default: MMFS_NORM_DISPATCH(rmsnorm_bwd, bf16_t, (const bf16_t *)grad_y, (const bf16_t *)x, (const bf16_t *)weight, rstd, (bf16_t *)grad_x, gw, rows, (int)C, partials); break;
     }
     return (int)hipGetLastError();
+}
+
+int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
+                          void *grad_x, float *grad_weight_f32, int64_t rows, int64_t C, void *stream)
+{
+    static const int env_grid = getenv("MMFS_NORM_BWD_GRID") ? atoi(getenv("MMFS_NORM_BWD_GRID")) : 0;      // tuning
+    // (few workgroups: the atomics on the gain gradient are what this entry point spends its time on)
+    const int grid = std::min(mmfs::norm_grid(rows), env_grid > 0 ? env_grid : 128);
+    return rmsnorm_backward_impl(dtype, grad_y, x, weight, rstd, grad_x, grad_weight_f32, rows, C, grid, 0, stream);
+}
+
+int mmfs_rmsnorm_backward_partials_rows(int64_t rows)
+{
+    static const int env_grid = getenv("MMFS_NORM_BWD_GRID") ? atoi(getenv("MMFS_NORM_BWD_GRID")) : 0;      // tuning
+    return rows <= 0 ? 0 : std::min(mmfs::norm_grid(rows), env_grid > 0 ? env_grid : 512);
+}
+
+int mmfs_rmsnorm_backward_partials(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
+                                   void *grad_x, float *grad_weight_partials, int64_t rows, int64_t C, void *stream)
+{
+    return rmsnorm_backward_impl(dtype, grad_y, x, weight, rstd, grad_x, grad_weight_partials, rows, C,
+                                 mmfs_rmsnorm_backward_partials_rows(rows), 1, stream);
 }
 
 }  // extern "C"

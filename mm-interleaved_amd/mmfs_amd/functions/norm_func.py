@@ -23,6 +23,10 @@ _lib.mmfs_rmsnorm_forward.restype = _int
 _lib.mmfs_rmsnorm_forward.argtypes = [_int, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp]
 _lib.mmfs_rmsnorm_backward.restype = _int
 _lib.mmfs_rmsnorm_backward.argtypes = [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
+_lib.mmfs_rmsnorm_backward_partials.restype = _int
+_lib.mmfs_rmsnorm_backward_partials.argtypes = [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
+_lib.mmfs_rmsnorm_backward_partials_rows.restype = _int
+_lib.mmfs_rmsnorm_backward_partials_rows.argtypes = [_i64]
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _ok = {}
 
@@ -67,10 +71,11 @@ class RMSNormFunction(Function):
         rows = xc.numel() // C
         gy = MSDA._aligned(grad_y.to(xc.dtype).contiguous())
         gx = torch.empty_like(xc)
-        gw = torch.zeros(C, dtype=torch.float32, device=xc.device)
+        # every workgroup leaves its share of the gain gradient in a row of its own (no atomics), added up here
+        parts = torch.empty((int(_lib.mmfs_rmsnorm_backward_partials_rows(rows)), C), dtype=torch.float32, device=xc.device)
         with MSDA._on_device(xc.device):
-            rc = MSDA._launch("mmfs_rmsnorm_bwd", xc.device, _lib.mmfs_rmsnorm_backward, _CODE[xc.dtype], gy.data_ptr(),
-                              xc.data_ptr(), wc.data_ptr(), rstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), rows, C,
-                              MSDA._stream(xc.device))
-        MSDA._check(rc, "mmfs_rmsnorm_backward")
-        return gx, gw.to(wc.dtype), None
+            rc = MSDA._launch("mmfs_rmsnorm_bwd", xc.device, _lib.mmfs_rmsnorm_backward_partials, _CODE[xc.dtype],
+                              gy.data_ptr(), xc.data_ptr(), wc.data_ptr(), rstd.data_ptr(), gx.data_ptr(), parts.data_ptr(),
+                              rows, C, MSDA._stream(xc.device))
+        MSDA._check(rc, "mmfs_rmsnorm_backward_partials")
+        return gx, parts.sum(0).to(wc.dtype), None
