@@ -388,6 +388,16 @@ int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, con
                         const int64_t *relpos, const float *ref, const float *ratios, void *out, float *sink,
                         int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
                         int64_t M, int64_t Lr, int64_t Nr, void *stream);
+/* The same with MMFS's ignore-token term folded into the store (mmfs.py:236-241, 274: ``out + ignore_token * sink``;
+ * three framework kernels and a full-size temporary per block otherwise): ``token`` [H, D] of the storage type, 16-byte
+ * aligned, or NULL (= mmfs_sample_forward).  Roundings as the framework statement's: the sampled output, the sink
+ * weight and their product are each rounded to the storage type before the sum -- bit-identical to the three kernels. */
+int mmfs_sample_forward_token(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *off_q, const void *att_q, const void *off_tab, const void *att_tab,
+                              const int64_t *relpos, const float *ref, const float *ratios, const void *token,
+                              void *out, float *sink,
+                              int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                              int64_t M, int64_t Lr, int64_t Nr, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-image feature bank: MMFS's ``input_flatten`` built in one pass.

@@ -295,12 +295,14 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 const T *__restrict__ off_q, const T *__restrict__ att_q,
                 const T *__restrict__ off_tab, const T *__restrict__ att_tab,
                 const int64_t *__restrict__ relpos, const float *__restrict__ ref, const float *__restrict__ ratios,
-                T *__restrict__ out, float *__restrict__ sink, const Dims d, const PlanDims pd, const int G)
+                T *__restrict__ out, float *__restrict__ sink, const Dims d, const PlanDims pd, const int G,
+                const T *__restrict__ token)
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
     constexpr int QPB = kThreads / LPI;
     constexpr int KC = (kSampleRecs / QPB) > P ? (kSampleRecs / QPB) : P;      // samples per query per chunk: whole rows of P
+    __shared__ float ssum[QPB];                           // the queries' summed sink weights (for the ignore-token term)
     static_assert(KC % P == 0 && KC % kSampleUnroll == 0, "chunks hold whole rows of P points");
     constexpr int STRIDE = 2 * KC + 1;
     __shared__ uint4 lds[QPB * STRIDE];
@@ -367,6 +369,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         const float sink_sum = rgroup_add(my_sink, G) * inv;
         if (item_ok && gl == 0) {
             stat[rq] = make_float2(m, inv);
+            ssum[rq] = sink_sum;
             if (sink != nullptr) sink[((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h] = sink_sum;
         }
     }
@@ -519,6 +522,21 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     }
     if (q_ok) {
         T *o = out + (((int64_t)bc.b * d.Nq + q) * d.H + bc.h) * d.D + lig * VEC;
+        if (token != nullptr) {
+            // the sinks' share goes to the ignore token (mmfs.py:236-241, 274): out + token * sink, with the framework
+            // statement's roundings -- sampled output, sink weight and product each rounded to the storage type first
+            const float sw = to_f32((T)ssum[qi]);
+            float tk[VEC];
+            V::unpack(*reinterpret_cast<const uint4 *>(token + (int64_t)bc.h * d.D + lig * VEC), tk);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                // (two roundings, as the framework's two kernels: the product must not be contracted into the sum --
+                // __fmul_rn / __fadd_rn do not stop this compiler, an opaque register does)
+                float prod = tk[i] * sw;
+                asm volatile("" : "+v"(prod));
+                acc[i] = to_f32((T)acc[i]) + to_f32((T)prod);
+            }
+        }
         *reinterpret_cast<uint4 *>(o) = V::pack(acc);
     }
 }
@@ -639,6 +657,17 @@ int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, con
                         int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
                         int64_t M, int64_t Lr, int64_t Nr, void *stream)
 {
+    return mmfs_sample_forward_token(dtype, value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios,
+                                     nullptr, out, sink, N, S, Lq, H, D, L, P, n, M, Lr, Nr, stream);
+}
+
+int mmfs_sample_forward_token(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *off_q, const void *att_q, const void *off_tab, const void *att_tab,
+                              const int64_t *relpos, const float *ref, const float *ratios, const void *token,
+                              void *out, float *sink,
+                              int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                              int64_t M, int64_t Lr, int64_t Nr, void *stream)
+{
     using namespace mmfs;
     const int es = esize(dtype);
     if (!es) return MMFS_E_DTYPE;
@@ -655,7 +684,7 @@ int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, con
     if (S * H * D * (int64_t)es > kMaxSlabBytes) return MMFS_E_UNSUPPORTED;        // buffer-descriptor rows only
     if (!value || !shapes || !start || !off_q || !att_q || !off_tab || !att_tab || !relpos || !ref || !ratios || !out)
         return MMFS_E_NULLPTR;
-    if (((uintptr_t)value | (uintptr_t)out) % 16) return MMFS_E_ALIGN;
+    if (((uintptr_t)value | (uintptr_t)out | (uintptr_t)token) % 16) return MMFS_E_ALIGN;
     Dims d;
     d.B = (int)N; d.S = (int)S; d.H = (int)H; d.D = (int)D; d.L = (int)(n * L); d.Nq = (int)Lq; d.P = (int)P;
     d.K = d.L * d.P; d.lazy_attn = 0; d.blocks4 = 0;
@@ -672,7 +701,8 @@ int mmfs_sample_forward(int dtype, const void *value, const int64_t *shapes, con
         if (blocks > 0x7fffffffLL) return (int)MMFS_E_DIMS;
         hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)off_q, (const T *)att_q,
-                           (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, dd, pd, G);
+                           (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, dd, pd, G,
+                           (const T *)token);
         return (int)hipGetLastError();
     };
     auto by_p = [&](auto tag_t, auto tag_lpi) {

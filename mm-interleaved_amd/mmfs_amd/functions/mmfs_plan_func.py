@@ -24,6 +24,8 @@ _lib.mmfs_plan_backward.restype = _int
 _lib.mmfs_plan_backward.argtypes = [_int] + [_vp] * 12 + [_i64] * 9 + [_vp]
 _lib.mmfs_sample_forward.restype = _int
 _lib.mmfs_sample_forward.argtypes = [_int] + [_vp] * 12 + [_i64] * 11 + [_vp]
+_lib.mmfs_sample_forward_token.restype = _int
+_lib.mmfs_sample_forward_token.argtypes = [_int] + [_vp] * 13 + [_i64] * 11 + [_vp]
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -88,12 +90,13 @@ class MMFSPlanFunction(Function):
                 d_att_tab.to(dt).reshape(s3), None, None, None, None, None, None, None)
 
 
-def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P):
+def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P, token=None):
     """Plan -> sampler in ONE kernel (``mmfs_sample_forward`` in include/mmfs_msda.h):
     the locations / weights [N, Lq, H, n*L, P(, 2)] are never written.  Inference only (no autograd graph);
     bit-identical to ``MMFSPlanFunction`` + ``MSDeformAttnFunction``.  value [N, S, H, D]; the other
     arguments as for ``MMFSPlanFunction``.  Returns (out [N, Lq, H*D], sink [N, Lq, H] fp32), or None when
-    the shape is outside the fused kernel's range (the caller then runs the two kernels)."""
+    the shape is outside the fused kernel's range (the caller then runs the two kernels).  ``token`` [.., H, D]
+    (MMFS's ignore token): ``out + token * sink`` is formed inside the kernel, with the framework statement's roundings."""
     dt = value.dtype
     if dt not in _CODE or off_q.dtype != dt or not value.is_cuda:
         return None
@@ -109,11 +112,16 @@ def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, re
     dev = value.device
     out = torch.empty((N, Lq, Hh * D), dtype=dt, device=dev)
     sink = torch.empty((N, Lq, Hh), dtype=torch.float32, device=dev)
+    tok = None
+    if token is not None:
+        if token.dtype != dt or token.numel() != Hh * D:
+            return None
+        tok = MSDA._aligned(token.reshape(Hh, D).contiguous())
     with torch.cuda.device(dev):
-        rc = MSDA._launch("mmfs_sample_fwd", dev, _lib.mmfs_sample_forward, _CODE[dt], value.data_ptr(),
+        rc = MSDA._launch("mmfs_sample_fwd", dev, _lib.mmfs_sample_forward_token, _CODE[dt], value.data_ptr(),
                           shapes.data_ptr(), start.data_ptr(), off_q.data_ptr(), att_q.data_ptr(),
                           off_tab.data_ptr(), att_tab.data_ptr(), relpos.data_ptr(), ref.data_ptr(),
-                          ratios.data_ptr(), out.data_ptr(), sink.data_ptr(),
+                          ratios.data_ptr(), tok.data_ptr() if tok is not None else None, out.data_ptr(), sink.data_ptr(),
                           N, S, Lq, Hh, D, L, P, n, M, Lr, Nr, MSDA._stream(dev))
     if rc == MSDA._E_UNSUPPORTED:
         return None

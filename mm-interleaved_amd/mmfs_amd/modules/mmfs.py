@@ -169,10 +169,11 @@ class MMFS(nn.Module):
             if sampler is not None:
                 # inference: the plan feeds the sampler inside one kernel (``sampler`` = (value, level starts));
                 # returns the op's output and the sink weights instead of loc / attn
+                # (``sampler[2]``: the ignore token, whose term the kernel then adds itself -- the sink weights come back None)
                 res = mmfs_sample_forward(sampler[0], input_spatial_shapes, sampler[1], *heads[:4], relpos,
-                                          heads[5], self.scale_ratios, H, L, P)
+                                          heads[5], self.scale_ratios, H, L, P, token=sampler[2])
                 if res is not None:
-                    return None, res[0], res[1]
+                    return None, res[0], (res[1] if sampler[2] is None else None)
             loc, attn, sink_sum = MMFSPlanFunction.apply(*heads)
             return loc, attn, sink_sum
 
@@ -239,11 +240,15 @@ class MMFS(nn.Module):
         fuse = (self.fused_sampler and self.fused_plan and value.is_cuda and query.dtype == value.dtype
                 and not (torch.is_grad_enabled() and (query.requires_grad or value.requires_grad
                                                       or any(p.requires_grad for p in self.parameters()))))
+        # (the ignore token's term inside the fused kernel where the types agree: else three framework kernels below)
+        tok_in = self.ignore_token if (fuse and self.ignore_token.dtype == value.dtype) else None
         loc, attn, sink_w = self.sampling_plan(query, reference_points, input_spatial_shapes, attention_mask, n,
-                                               sampler=(value, input_level_start_index) if fuse else None,
+                                               sampler=(value, input_level_start_index, tok_in) if fuse else None,
                                                image_ranks=image_ranks)
         if loc is None:
             out = attn                            # (the fused kernel's result)
+            if sink_w is None:                    # ... the ignore token's term included
+                return self.output_proj(out)
         else:
             # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
             # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)

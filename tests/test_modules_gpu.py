@@ -492,6 +492,16 @@ def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype):
     assert torch.equal(outs[True], outs[False])
     if dtype == torch.float32:
         assert rel_err(outs[True], z["out"]) <= 2e-5
+    # a non-zero ignore token (the reference initialises it to zeros and freezes it; a checkpoint may hold anything): its
+    # term -- out + token * sink -- is formed inside the fused kernel with the framework statement's roundings: still equal
+    with torch.no_grad():
+        m.ignore_token.copy_(torch.randn(m.ignore_token.shape, generator=torch.Generator().manual_seed(3)).to(dtype))
+    for fused in (True, False):
+        m.fused_sampler = fused
+        with torch.no_grad():
+            outs[fused] = m(*args)
+    assert torch.equal(outs[True], outs[False]) and bool(torch.isfinite(outs[True]).all())
+    m.ignore_token.zero_()
 
 
 def test_fused_sampler_is_not_taken_when_a_gradient_is_wanted():
