@@ -444,6 +444,21 @@ int mmfs_rmsnorm_backward_partials_rows(int64_t rows);
 int mmfs_rmsnorm_backward_partials(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
                                    void *grad_x, float *grad_weight_partials, int64_t rows, int64_t C, void *stream);
 
+/* ---- the two layout changes around the image decoder's synchronizer block (csrc/mmfs_query.hip) ----------------------
+ * MMFSBlock (mm_interleaved/models/decoders/sd_mmfs.py:121-146) gets a UNet residual [B, C, H, W] and works on tokens:
+ *   mmfs_query_prep:  q[b, p, :] = round(LayerNorm_C(x[b, :, p]) * gamma + beta) + pos[p, :]      (sd_mmfs.py:124-131)
+ *                     x [B, C, HW] -> q [B, HW, C]; statistics in fp32; ``pos`` [HW, C] may be NULL (no second term);
+ *                     ``mean`` / ``rstd`` [B * HW] fp32, both or neither: what a LayerNorm backward needs.
+ *   mmfs_tokens_add:  y[b, c, p] = round(tok[b, p, c] + res[b, c, p])     (the rearrange back + the caller's residual add,
+ *                     sd_mmfs.py:146, 262-270); tok [B, HW, C], res and y [B, C, HW].
+ * One read of the input and one write of the output each (a transposing tile in LDS) instead of a copy, a normalisation
+ * and two adds.  16-bit storage types, C % 8 == 0, C <= 2048, HW % 8 == 0 (mmfs_query_prep_supported); else
+ * MMFS_E_UNSUPPORTED and the caller keeps the framework's kernels. */
+int mmfs_query_prep_supported(int dtype, int64_t C, int64_t HW);
+int mmfs_query_prep(int dtype, const void *x, const void *gamma, const void *beta, const void *pos, void *q,
+                    float *mean, float *rstd, int64_t B, int64_t C, int64_t HW, float eps, void *stream);
+int mmfs_tokens_add(int dtype, const void *tok, const void *res, void *y, int64_t B, int64_t C, int64_t HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
+from ..functions.query_func import layout_supported, query_prep, tokens_add
 from ..levels import make_level_tables
 from ..modules.mmfs import MMFS
 
@@ -121,12 +122,28 @@ class MMFSBlock(nn.Module):
             self.__dict__["_pos_cache"] = hit
         return hit[1]
 
-    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None):
+    def _layout_kernels(self, sample):
+        """Whether the two layout changes around the block run as one kernel each (csrc/mmfs_query.hip): nothing on
+        the way needs a gradient (the kernels are forward-only), a plain affine LayerNorm over the channels, one
+        16-bit storage type throughout."""
+        n = self.query_norm
+        return (not torch.is_grad_enabled() and not torch.is_autocast_enabled() and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None
+                and tuple(n.normalized_shape) == (sample.shape[1],) and n.weight.dtype == sample.dtype
+                and n.bias.dtype == sample.dtype and self.pos_embed.dtype == sample.dtype
+                and self.conv.kernel_size == (1, 1) and layout_supported(sample))
+
+    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None):
         B, C, H, W = sample.shape
         n_images = ms_feat_mask.shape[-1]
         ref, shapes, start = deform_inputs(sample, spatial_shapes, n_images)
-        query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
-        query = query + self._pos_table(H * W)
+        fast = self._layout_kernels(sample)
+        if fast:
+            # "b c h w -> b (h w) c", the normalisation and the position term in one pass over the residual
+            query = query_prep(sample, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps,
+                               self._pos_table(H * W))
+        else:
+            query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
+            query = query + self._pos_table(H * W)
         out = self.mmfs(query, ref, self.feat_norm(ms_feat) if value is None else ms_feat, shapes, start,
                         input_padding_mask=None, attention_mask=ms_feat_mask, value=value, image_ranks=image_ranks)
         # the zero-initialised 1x1 convolution (sd_mmfs.py:88-94, 146) is a per-token linear map:
@@ -134,22 +151,29 @@ class MMFSBlock(nn.Module):
         # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
         if self.conv.kernel_size == (1, 1):
             out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
-            return out.transpose(1, 2).reshape(B, C, H, W)
-        return self.conv(out.transpose(1, 2).reshape(B, C, H, W))
+            if fast and residual is not None and residual.shape == sample.shape and residual.dtype == out.dtype:
+                return tokens_add(out, residual)                                  # "b (h w) c -> b c h w" + the caller's add
+            out = out.transpose(1, 2).reshape(B, C, H, W)
+        else:
+            out = self.conv(out.transpose(1, 2).reshape(B, C, H, W))
+        return out if residual is None else residual + out
 
-    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None):
+    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None):
         """sample [B, C_q, H, W]; ms_feat [B, n, sum_l H_l*W_l, C_v]; ms_feat_mask [B, n];
         spatial_shapes: the levels of ONE image, list of (H_l, W_l)  ->  [B, C_q, H, W].
         ``value`` (an addition to sd_mmfs.py:121-146): this block's
         ``mmfs.value_proj(feat_norm(ms_feat))`` when the caller already has it (``MMFSNet``); ``image_ranks``
-        (another): ``mmfs._image_relpos(ms_feat_mask, ...)``, a function of the mask only, made once for all blocks."""
+        (another): ``mmfs._image_relpos(ms_feat_mask, ...)``, a function of the mask only, made once for all blocks;
+        ``residual`` (another): a [B, C_q, H, W] tensor the result is added to -- the add ``MMFSNet`` does with every
+        block's output (sd_mmfs.py:262-270), here so that it can share the pass that restores the layout."""
         spatial_shapes = [tuple(int(v) for v in s) for s in spatial_shapes]
         if self.gradient_checkpointing and self.training:
             # the op is stateless and re-entrant: the forward is simply re-run in backward
             # (a projected ``value`` is an input of the checkpoint: kept, not recomputed)
-            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
-                                 use_reentrant=False)
-        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks)
+            out = cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
+                                use_reentrant=False)
+            return out if residual is None else residual + out
+        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual)
 
 
 class ProjectedFeatures:
@@ -286,7 +310,7 @@ class MMFSNet(nn.Module):
             values = [None] * (len(self.mmfs_down_blocks) + 1)
         # (the images' ranks among the visible ones depend on the mask only: once for the 13 blocks)
         ranks = self.mmfs_mid_block.mmfs._image_relpos(mmfs_mask, 1) if mmfs_mask.dim() == 2 else None
-        new_res = tuple(r + blk(r, bank, mmfs_mask, shapes, value=v, image_ranks=ranks)
+        new_res = tuple(blk(r, bank, mmfs_mask, shapes, value=v, image_ranks=ranks, residual=r)
                         for r, blk, v in zip(down_block_res_samples, self.mmfs_down_blocks, values))
-        sample = sample + self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1], image_ranks=ranks)
+        sample = self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1], image_ranks=ranks, residual=sample)
         return sample, new_res

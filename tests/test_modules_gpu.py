@@ -601,3 +601,94 @@ def test_llama_layer_with_the_fused_norm_and_schedule_matches_the_layerwise_path
     a, b = run(True), run(False)
     assert float((a - b).abs().max() / b.abs().max()) <= 3e-2
     assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 4e-3
+
+
+# ---------------------------------------------------------------- layout kernels around the image decoder's block
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("shape", [(2, 320, 16, 16), (3, 640, 8, 8), (1, 1280, 8, 16), (2, 64, 5, 8), (1, 2048, 4, 6),
+                                   (2, 328, 12, 10)])
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_query_prep_kernel_matches_the_framework_chain(dtype, ulp, shape, with_pos):
+    """csrc/mmfs_query.hip ``query_prep``: LayerNorm over the channels of a [B, C, H, W] sample + position rows, as
+    token rows -- against fp64 on the same 16-bit inputs (bar: the two roundings of the framework's chain) and against
+    the framework's chain itself (the same value up to one unit in the last place of the storage type)."""
+    from mmfs_amd.functions.query_func import layout_supported, query_prep
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(DEV, dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(DEV, dtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV, dtype)
+    pos = torch.randn(H * W, C, generator=g).to(DEV, dtype) if with_pos else None
+    assert layout_supported(x)
+    got = query_prep(x, w, b, 1e-6, pos)
+    tok = x.flatten(2).transpose(1, 2)
+    chain = torch.nn.functional.layer_norm(tok, (C,), w, b, 1e-6)
+    if with_pos:
+        chain = chain + pos
+    ln64 = torch.nn.functional.layer_norm(tok.double(), (C,), w.double(), b.double(), 1e-6)
+    want = ln64 + pos.double() if with_pos else ln64
+    assert got.shape == (B, H * W, C) and got.dtype == dtype
+    scale = want.abs().clamp_min(1.0)
+    err = float(((got.double() - want).abs() / scale).max())
+    ref_err = float(((chain.double() - want).abs() / scale).max())
+    assert err <= max(2.0 * ulp, 1.25 * ref_err), (err, ref_err)
+    far = (got.double() - chain.double()).abs() > 2.0 * ulp * scale
+    assert not bool(far.any()), int(far.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 320, 16, 16), (1, 1280, 8, 8), (2, 64, 5, 8), (3, 2048, 2, 4), (2, 328, 12, 10)])
+def test_tokens_add_kernel_is_the_transposed_add(dtype, shape):
+    """csrc/mmfs_query.hip ``tokens_add``: residual + rearrange(tokens, "b (h w) c -> b c h w"), bit for bit."""
+    from mmfs_amd.functions.query_func import tokens_add
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C * H)
+    tok = torch.randn(B, H * W, C, generator=g).to(DEV, dtype)
+    res = torch.randn(shape, generator=g).to(DEV, dtype)
+    want = res + tok.transpose(1, 2).reshape(B, C, H, W)
+    assert torch.equal(tokens_add(tok, res), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_mmfs_net_takes_the_layout_kernels_without_gradients(dtype, tol, monkeypatch):
+    """Under no_grad the 16-bit ``MMFSNet`` runs ``query_prep`` / ``tokens_add`` once per block; its outputs are the
+    framework-kernel path's within the storage type's rounding, and a call that wants gradients does not take them."""
+    from mmfs_amd.blocks import MMFSNet, sd_mmfs
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV, dtype).eval()
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    mid = T(z["mid"], dtype)
+    res = [T(z[f"res.{i}"], dtype) for i in range(6)]
+    feats = [T(z[f"feat.{i}"], dtype) for i in range(3)]
+    mask = T(z["ms_mask"], None)
+    calls = {"prep": 0, "add": 0}
+    real_prep, real_add = sd_mmfs.query_prep, sd_mmfs.tokens_add
+    monkeypatch.setattr(sd_mmfs, "query_prep", lambda *a, **k: (calls.__setitem__("prep", calls["prep"] + 1), real_prep(*a, **k))[1])
+    monkeypatch.setattr(sd_mmfs, "tokens_add", lambda *a, **k: (calls.__setitem__("add", calls["add"] + 1), real_add(*a, **k))[1])
+    with torch.no_grad():
+        fast = net(mid, res, feats, mask)
+    n_fast = sum(bool(sd_mmfs.layout_supported(r)) for r in res + [mid])       # (maps of fewer than 8 pixels: framework kernels)
+    assert n_fast >= 3 and calls == {"prep": n_fast, "add": n_fast}
+    monkeypatch.setattr(sd_mmfs.MMFSBlock, "_layout_kernels", lambda self, sample: False)
+    with torch.no_grad():
+        slow = net(mid, res, feats, mask)
+    assert calls == {"prep": n_fast, "add": n_fast}
+    for a, b in zip([fast[0]] + list(fast[1]), [slow[0]] + list(slow[1])):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        err = float((a.float() - b.float()).abs().max() / max(1.0, float(b.float().abs().max())))
+        assert err <= tol, err
+    assert float((slow[0] - mid).abs().max()) > 1e-3                  # the blocks did contribute
+    monkeypatch.undo()
+    calls2 = {"n": 0}
+    monkeypatch.setattr(sd_mmfs, "query_prep", lambda *a, **k: calls2.__setitem__("n", calls2["n"] + 1))
+    net(mid.clone().requires_grad_(True), res, feats, mask)[0].float().sum().backward()
+    assert calls2["n"] == 0
