@@ -362,6 +362,7 @@ struct TileParams {
     int tiles_bound;
     int nt_min;
     int vgroups;      // kept scan: groups of NV vectors per query (1 unless a query's samples of a level span more than NV vectors)
+    int hgroup;       // sort: heads whose workgroups share an XCD (their loc / attn words share 128-byte lines); <= 1: head h on XCD h % 8
 };
 
 // Development aid (tools/exp_build.sh sprof "-DMMFS_PROFILE_SORT"; tools/sort_prof.py): shader clocks per phase of
@@ -401,9 +402,20 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     __shared__ uint32_t region;
 
     const int bid = blockIdx.x;
-    const int h = bid % d.H;
-    const int t = (bid / d.H) % tp.tiles_bound;
-    const int b = (bid / d.H) / tp.tiles_bound;
+    int h = bid % d.H;
+    int t = (bid / d.H) % tp.tiles_bound;
+    int b = (bid / d.H) / tp.tiles_bound;
+    if (tp.hgroup > 1) {
+        // workgroups go to the XCDs round-robin: the 4 x tiles workgroups that read the same lines of loc / attn -- the
+        // levels of ``hgroup`` neighbouring heads of one batch slice -- take consecutive slots of ONE XCD
+        const int per = tp.hgroup * tp.tiles_bound, hg = d.H / tp.hgroup;
+        const int x = bid & 7, k = bid >> 3;
+        const int group = (k / per) * 8 + x, within = k % per;
+        if (group >= d.B * hg) return;
+        b = group / hg;
+        h = (group % hg) * tp.hgroup + within % tp.hgroup;
+        t = within / tp.hgroup;
+    }
     if (hdr->stamp != header_stamp(d) || t >= hdr->n_tiles) return;      // (a plan made for other dimensions: not ours)
     const CTile tl = tiles_of(hdr, d.L)[t];
     // (matrix-core reduce: the level's row, for the blocks this tile plans itself; asked for early)
@@ -960,6 +972,7 @@ TileParams make_params(const Dims &d)
     const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((cells + kMaxTileCells - 1) / kMaxTileCells) + d.L;
     tp.tiles_bound = (int)std::min<int64_t>(bound, 0x3fffffff);
     tp.vgroups = 1;
+    tp.hgroup = 1;
     return tp;
 }
 
@@ -1143,7 +1156,16 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
 {
     TileParams tp = make_params(d);
     tp.vgroups = vgroups;
-    const int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
+    // Four heads whose weights share a 128-byte line of attn (L * P * element size <= 32 bytes per head; their loc words
+    // share lines in pairs): their workgroups on one XCD -- north star: the sort fetched 66 MB for 25 MB of loc + attn,
+    // 37.9 -> 34.6 us (profiles/r03_experiments.md r03ay).  Pairs of heads (SD / LLM geometry, 64 bytes of attn per
+    // head) measured slower than head h on XCD h % 8: 147 -> 154 us.  MMFS_SORT_HGROUP: tuning
+    static const int env_hg = getenv("MMFS_SORT_HGROUP") ? atoi(getenv("MMFS_SORT_HGROUP")) : -1;
+    int hgroup = env_hg >= 0 ? std::min(env_hg, 4) : ((int64_t)d.L * d.P * (int64_t)sizeof(T) <= 32 ? 4 : 1);
+    while (hgroup > 1 && d.H % hgroup) --hgroup;
+    tp.hgroup = std::max(hgroup, 1);
+    int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
+    if (tp.hgroup > 1) blocks = ((int64_t)d.B * (d.H / tp.hgroup) + 7) / 8 * 8 * tp.hgroup * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // (every cell of every level lies in exactly one tile, so the sort writes the whole cell table)
     if (!planned)
