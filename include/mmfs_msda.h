@@ -398,6 +398,17 @@ int mmfs_sample_forward_token(int dtype, const void *value, const int64_t *shape
                               void *out, float *sink,
                               int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
                               int64_t M, int64_t Lr, int64_t Nr, void *stream);
+/* The same with the two query heads as COLUMNS of wider matrices: token row t of ``off_q`` starts ``ld_off`` elements
+ * after row t - 1 (``ld_att`` for ``att_q``; 0 = packed, H*2P / H*L*P).  What a caller that evaluates
+ * sampling_offsets and attention_weights as ONE GEMM (their weights stacked: both read the same activations,
+ * mmfs.py:174-176) hands over: two column ranges of its [N*Lq, H*2P + H*L*P] result, no copies. */
+int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *off_q, const void *att_q, int64_t ld_off, int64_t ld_att,
+                              const void *off_tab, const void *att_tab,
+                              const int64_t *relpos, const float *ref, const float *ratios, const void *token,
+                              void *out, float *sink,
+                              int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                              int64_t M, int64_t Lr, int64_t Nr, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-image feature bank: MMFS's ``input_flatten`` built in one pass.

@@ -35,6 +35,7 @@ constexpr int kQueryRun = 8;            // backward: consecutive queries a lane 
 
 struct PlanDims {
     int N, Lq, H, L, P, n, M, Lr, Nr;
+    int ld_off, ld_att;     // sampler only: elements between the rows of two tokens in off_q / att_q (H*2P / H*L*P when packed)
 };
 
 // lane group: G = 2^k lanes, one per (image, level) row of P points; reductions stay inside it
@@ -330,11 +331,11 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 
     // logits of row gl (= image k, level l) of the item (bc.b, sq, bc.h), as plan_forward_kernel forms them
     auto row_logits = [&](int sq, int gl, float (&lg)[P]) {
-        const int64_t it = ((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h;
+        const int64_t tk = (int64_t)bc.b * pd.Lq + sq;
         const int k = gl / pd.L, l = gl % pd.L;
         const int64_t r = relpos[((int64_t)bc.b * pd.Lr + (pd.Lr == 1 ? 0 : sq)) * pd.n + k];
         float a[P], t[P];
-        load_row<T, P>(att_q + (it * pd.L + l) * P, a);
+        load_row<T, P>(att_q + tk * pd.ld_att + (bc.h * pd.L + l) * P, a);
         load_row<T, P>(att_tab + ((r * pd.H + bc.h) * pd.L + l) * P, t);
         const float pen = r == 0 ? -10000.f : 0.f;
 #pragma unroll
@@ -397,10 +398,9 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             float lg[P];
             const int64_t r = row_logits(sq, gl, lg);
             const float2 st2 = stat[rq];
-            const int64_t it = ((int64_t)bc.b * pd.Lq + sq) * pd.H + bc.h;
             const int l = gl % pd.L;
             float oq[2 * P], ot[2 * P];
-            load_row<T, 2 * P>(off_q + it * 2 * P, oq);
+            load_row<T, 2 * P>(off_q + ((int64_t)bc.b * pd.Lq + sq) * pd.ld_off + bc.h * 2 * P, oq);
             load_row<T, 2 * P>(off_tab + (r * pd.H + bc.h) * 2 * P, ot);
             const float rx = ref[((int64_t)(pd.Nr == 1 ? 0 : bc.b) * pd.Lq + sq) * 2];
             const float ry = ref[((int64_t)(pd.Nr == 1 ? 0 : bc.b) * pd.Lq + sq) * 2 + 1];
@@ -554,6 +554,7 @@ int check_dims(int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n
     if (N * Lq * H > lim) return MMFS_E_DIMS;
     d->N = (int)N; d->Lq = (int)Lq; d->H = (int)H; d->L = (int)L; d->P = (int)P; d->n = (int)n;
     d->M = (int)M; d->Lr = (int)Lr; d->Nr = (int)Nr;
+    d->ld_off = d->ld_att = 0;
     return MMFS_OK;
 }
 
@@ -668,6 +669,18 @@ int mmfs_sample_forward_token(int dtype, const void *value, const int64_t *shape
                               int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
                               int64_t M, int64_t Lr, int64_t Nr, void *stream)
 {
+    return mmfs_sample_forward_heads(dtype, value, shapes, start, off_q, att_q, 0, 0, off_tab, att_tab, relpos, ref, ratios,
+                                     token, out, sink, N, S, Lq, H, D, L, P, n, M, Lr, Nr, stream);
+}
+
+int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *off_q, const void *att_q, int64_t ld_off, int64_t ld_att,
+                              const void *off_tab, const void *att_tab,
+                              const int64_t *relpos, const float *ref, const float *ratios, const void *token,
+                              void *out, float *sink,
+                              int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
+                              int64_t M, int64_t Lr, int64_t Nr, void *stream)
+{
     using namespace mmfs;
     const int es = esize(dtype);
     if (!es) return MMFS_E_DTYPE;
@@ -685,6 +698,14 @@ int mmfs_sample_forward_token(int dtype, const void *value, const int64_t *shape
     if (!value || !shapes || !start || !off_q || !att_q || !off_tab || !att_tab || !relpos || !ref || !ratios || !out)
         return MMFS_E_NULLPTR;
     if (((uintptr_t)value | (uintptr_t)out | (uintptr_t)token) % 16) return MMFS_E_ALIGN;
+    // token rows of off_q / att_q: packed, or ld elements apart (columns of one wider matrix); vector loads of P
+    // (2 P) elements need the rows aligned like the packed ones
+    if (ld_off == 0) ld_off = H * 2 * P;
+    if (ld_att == 0) ld_att = H * L * P;
+    if (ld_off < H * 2 * P || ld_att < H * L * P || ld_off > 0x7fffffffLL || ld_att > 0x7fffffffLL) return MMFS_E_DIMS;
+    if ((ld_off * es) % (2 * P * es) || (ld_att * es) % (P * es) || (uintptr_t)off_q % (2 * P * es) || (uintptr_t)att_q % (P * es))
+        return MMFS_E_ALIGN;
+    pd.ld_off = (int)ld_off; pd.ld_att = (int)ld_att;
     Dims d;
     d.B = (int)N; d.S = (int)S; d.H = (int)H; d.D = (int)D; d.L = (int)(n * L); d.Nq = (int)Lq; d.P = (int)P;
     d.K = d.L * d.P; d.lazy_attn = 0; d.blocks4 = 0;

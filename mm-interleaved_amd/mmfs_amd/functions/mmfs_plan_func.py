@@ -26,6 +26,8 @@ _lib.mmfs_sample_forward.restype = _int
 _lib.mmfs_sample_forward.argtypes = [_int] + [_vp] * 12 + [_i64] * 11 + [_vp]
 _lib.mmfs_sample_forward_token.restype = _int
 _lib.mmfs_sample_forward_token.argtypes = [_int] + [_vp] * 13 + [_i64] * 11 + [_vp]
+_lib.mmfs_sample_forward_heads.restype = _int
+_lib.mmfs_sample_forward_heads.argtypes = [_int] + [_vp] * 5 + [_i64] * 2 + [_vp] * 8 + [_i64] * 11 + [_vp]
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -90,6 +92,20 @@ class MMFSPlanFunction(Function):
                 d_att_tab.to(dt).reshape(s3), None, None, None, None, None, None, None)
 
 
+def _token_rows(t, vec):
+    """[N, Lq, cols] -> (tensor, elements between two token rows; 0 = packed): a column range of a wider row-major
+    matrix is handed over as it lies when its rows allow the kernel's vector loads of ``vec`` elements."""
+    if t.is_contiguous():
+        return t, 0
+    if t.dim() == 3 and t.stride(2) == 1:
+        ld = t.stride(1) if t.shape[1] > 1 else t.stride(0)
+        by = vec * t.element_size()
+        if ((t.shape[1] == 1 or t.stride(0) == t.shape[1] * ld) and ld >= t.shape[2] and (ld * t.element_size()) % by == 0
+                and t.data_ptr() % by == 0):
+            return t, ld
+    return t.contiguous(), 0
+
+
 def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P, token=None):
     """Plan -> sampler in ONE kernel (``mmfs_sample_forward`` in include/mmfs_msda.h):
     the locations / weights [N, Lq, H, n*L, P(, 2)] are never written.  Inference only (no autograd graph);
@@ -104,7 +120,8 @@ def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, re
     Lq = off_q.shape[1]
     n, Lr, Nr, M = relpos.shape[-1], relpos.shape[1], ref.shape[0], off_tab.shape[0]
     value = value.contiguous()
-    off_q, att_q = off_q.contiguous(), att_q.to(dt).contiguous()
+    off_q, ld_off = _token_rows(off_q, 2 * P)
+    att_q, ld_att = _token_rows(att_q.to(dt), P)
     off_tab, att_tab = off_tab.to(dt).contiguous(), att_tab.to(dt).contiguous()
     relpos, ref, ratios = relpos.contiguous(), ref.float().contiguous(), ratios.float().contiguous()
     assert shapes.dtype == torch.int64 and shapes.is_contiguous() and shapes.shape == (n * L, 2)
@@ -118,8 +135,8 @@ def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, re
             return None
         tok = MSDA._aligned(token.reshape(Hh, D).contiguous())
     with torch.cuda.device(dev):
-        rc = MSDA._launch("mmfs_sample_fwd", dev, _lib.mmfs_sample_forward_token, _CODE[dt], value.data_ptr(),
-                          shapes.data_ptr(), start.data_ptr(), off_q.data_ptr(), att_q.data_ptr(),
+        rc = MSDA._launch("mmfs_sample_fwd", dev, _lib.mmfs_sample_forward_heads, _CODE[dt], value.data_ptr(),
+                          shapes.data_ptr(), start.data_ptr(), off_q.data_ptr(), att_q.data_ptr(), ld_off, ld_att,
                           off_tab.data_ptr(), att_tab.data_ptr(), relpos.data_ptr(), ref.data_ptr(),
                           ratios.data_ptr(), tok.data_ptr() if tok is not None else None, out.data_ptr(), sink.data_ptr(),
                           N, S, Lq, Hh, D, L, P, n, M, Lr, Nr, MSDA._stream(dev))

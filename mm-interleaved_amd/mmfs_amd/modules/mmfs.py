@@ -124,7 +124,8 @@ class MMFS(nn.Module):
         keep = not torch.is_grad_enabled()
         sig = None
         if keep:
-            ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.attention_weights.weight, self.attention_weights.bias)
+            ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.sampling_offsets.bias,
+                  self.attention_weights.weight, self.attention_weights.bias)
             sig = (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
@@ -135,9 +136,14 @@ class MMFS(nn.Module):
             dq = self.attention_weights.in_features
             aw_w = self.attention_weights.weight.view(H, L, P + 1, dq)[:, :, :P].reshape(H * L * P, dq)
             aw_b = self.attention_weights.bias.view(H, L, P + 1)[:, :, :P].reshape(H * L * P)
-            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b)
+            # (kept tables only: the two heads read the same activations -- stacked, they are ONE GEMM per call whose
+            # result's two column ranges the fused sampler takes as they lie, ``mmfs_sample_forward_heads``)
+            so = self.sampling_offsets
+            stack = keep and so.bias is not None and so.weight.dtype == aw_w.dtype and so.bias.dtype == aw_b.dtype
+            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b,
+                   torch.cat((so.weight, aw_w), 0) if stack else None, torch.cat((so.bias, aw_b), 0) if stack else None)
         else:
-            res = (off_tab, F.linear(table, self.attention_weights.weight), None, None)   # [max_img, H*L*(P+1)]
+            res = (off_tab, F.linear(table, self.attention_weights.weight), None, None, None, None)   # [max_img, H*L*(P+1)]
         if keep:
             self._tables = (sig, res)
         return res
@@ -163,8 +169,13 @@ class MMFS(nn.Module):
             # one gfx950 kernel for the rest (csrc/mmfs_plan.hip), fp32 inside, rounded once.  Only
             # the P point columns of the attention head are evaluated: its (P+1)-th column is
             # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
-            off_tab, att_tab, aw_w, aw_b = self._plan_tables(True)
-            heads = (self.sampling_offsets(q), F.linear(q, aw_w, aw_b), off_tab, att_tab, relpos,
+            off_tab, att_tab, aw_w, aw_b, cat_w, cat_b = self._plan_tables(True)
+            if cat_w is not None and q.dtype == cat_w.dtype:                   # (no gradients wanted: see _plan_tables)
+                both = F.linear(q, cat_w, cat_b)                              # [N, Lq, H*P*2 + H*L*P]
+                off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
+            else:
+                off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
+            heads = (off_q, att_q, off_tab, att_tab, relpos,
                      reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
             if sampler is not None:
                 # inference: the plan feeds the sampler inside one kernel (``sampler`` = (value, level starts));
@@ -174,10 +185,10 @@ class MMFS(nn.Module):
                                           heads[5], self.scale_ratios, H, L, P, token=sampler[2])
                 if res is not None:
                     return None, res[0], (res[1] if sampler[2] is None else None)
-            loc, attn, sink_sum = MMFSPlanFunction.apply(*heads)
+            loc, attn, sink_sum = MMFSPlanFunction.apply(off_q.contiguous(), att_q.contiguous(), *heads[2:])
             return loc, attn, sink_sum
 
-        off_tab, att_tab, _, _ = self._plan_tables(False)
+        off_tab, att_tab = self._plan_tables(False)[:2]
         # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
         offsets = self.sampling_offsets(q)[:, :, None, :] + off_tab[relpos]
         offsets = offsets.view(N, Lq, n, H, 1, P, 2) * self.scale_ratios.view(1, 1, 1, 1, L, 1, 1).to(offsets.dtype)

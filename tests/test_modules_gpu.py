@@ -692,3 +692,40 @@ def test_mmfs_net_takes_the_layout_kernels_without_gradients(dtype, tol, monkeyp
     monkeypatch.setattr(sd_mmfs, "query_prep", lambda *a, **k: calls2.__setitem__("n", calls2["n"] + 1))
     net(mid.clone().requires_grad_(True), res, feats, mask)[0].float().sum().backward()
     assert calls2["n"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Lq", [1, 37])
+def test_fused_sampler_takes_the_query_heads_as_columns_of_one_matrix(dtype, Lq):
+    """``mmfs_sample_forward_heads``: off_q / att_q as two column ranges of the stacked heads' GEMM result (token rows
+    ld elements apart) against the same numbers as packed tensors -- bit-equal; a range whose rows do not allow the
+    kernel's vector loads is copied by the wrapper (same result)."""
+    from mmfs_amd.functions.mmfs_plan_func import mmfs_sample_forward, _token_rows
+    from mmfs_amd.levels import make_level_tables
+    g = torch.Generator().manual_seed(11)
+    N, H, L, P, n, D, M = 2, 4, 3, 4, 2, 16, 5
+    sh, st, S = make_level_tables([(8, 8), (4, 4), (2, 2)], n, DEV)
+    value = torch.randn(N, S, H, D, generator=g).to(DEV, dtype)
+    n_off, n_att = H * P * 2, H * L * P
+    both = (torch.randn(N, Lq, n_off + n_att + 8, generator=g) * 0.5).to(DEV, dtype)
+    off_tab = (torch.randn(M, n_off, generator=g) * 0.3).to(DEV, dtype)
+    att_tab = (torch.randn(M, n_att, generator=g) * 0.3).to(DEV, dtype)
+    relpos = torch.randint(0, M, (N, 1, n), generator=g).to(DEV)
+    ref = torch.rand(1, Lq, 2, generator=g).to(DEV)
+    ratios = torch.tensor([1.0, 0.5, 0.25], device=DEV)
+    tok = torch.randn(H, D, generator=g).to(DEV, dtype)
+    views = (both[..., :n_off], both[..., n_off:n_off + n_att])
+    assert _token_rows(views[0], 2 * P)[1] == both.shape[-1] and _token_rows(views[1], P)[1] == both.shape[-1]
+    got = mmfs_sample_forward(value, sh, st, views[0], views[1], off_tab, att_tab, relpos, ref, ratios, H, L, P, token=tok)
+    want = mmfs_sample_forward(value, sh, st, views[0].contiguous(), views[1].contiguous(), off_tab, att_tab, relpos, ref,
+                               ratios, H, L, P, token=tok)
+    assert got is not None and want is not None
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and bool(torch.isfinite(got[0]).all())
+    assert float(got[0].float().abs().max()) > 1e-3
+    odd = both[..., 1:1 + n_off]                        # rows that start 1 element off: not aligned for the vector loads
+    assert _token_rows(odd, 2 * P)[1] == 0
+    got2 = mmfs_sample_forward(value, sh, st, odd, views[1], off_tab, att_tab, relpos, ref, ratios, H, L, P, token=tok)
+    want2 = mmfs_sample_forward(value, sh, st, odd.contiguous(), views[1].contiguous(), off_tab, att_tab, relpos, ref,
+                                ratios, H, L, P, token=tok)
+    assert torch.equal(got2[0], want2[0])
