@@ -19,7 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
-from ..functions.query_func import layout_supported, query_prep, tokens_add
+from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
 from ..levels import make_level_tables
 from ..modules.mmfs import MMFS
 
@@ -82,6 +82,8 @@ def deform_inputs(sample, spatial_shapes=((8, 8),), n_images=1):
 
 # ------------------------------------------------------------------ blocks
 class MMFSBlock(nn.Module):
+    layout_kernels_in_training = True
+
     def __init__(self, attn_dim=1024, query_dim=320, feat_dim=1024, num_heads=16, n_points=8,
                  n_levels=1, deform_ratio=1.0, norm_layer=partial(nn.LayerNorm, eps=1e-6),
                  gradient_checkpointing=False, grid_size=64, offset_init_magnitude=1,
@@ -123,24 +125,35 @@ class MMFSBlock(nn.Module):
         return hit[1]
 
     def _layout_kernels(self, sample):
-        """Whether the two layout changes around the block run as one kernel each (csrc/mmfs_query.hip): nothing on
-        the way needs a gradient (the kernels are forward-only), a plain affine LayerNorm over the channels, one
-        16-bit storage type throughout."""
+        """Whether the two layout changes around the block run as one kernel each (csrc/mmfs_query.hip): a plain affine
+        LayerNorm over the channels, one 16-bit storage type throughout, no autocast.  (With gradients the same kernels
+        run inside ``QueryPrepFunction`` / ``TokensAddFunction``; ``layout_kernels_in_training = False`` keeps a training
+        step on the framework's kernels.)"""
         n = self.query_norm
-        return (not torch.is_grad_enabled() and not torch.is_autocast_enabled() and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None
+        if torch.is_grad_enabled() and not self.layout_kernels_in_training:
+            return False
+        return (not torch.is_autocast_enabled() and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None
                 and tuple(n.normalized_shape) == (sample.shape[1],) and n.weight.dtype == sample.dtype
                 and n.bias.dtype == sample.dtype and self.pos_embed.dtype == sample.dtype
                 and self.conv.kernel_size == (1, 1) and layout_supported(sample))
 
-    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None):
+    def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None, normed=None):
         B, C, H, W = sample.shape
+        if value is None and normed is not None:
+            # the bank already normalised WITHOUT the affine (MMFSNet, shared by its blocks): this block's affine folds
+            # into its projection, value_proj(g * xhat + b) = (W diag g) xhat + (W b + bias)
+            proj, ln = self.mmfs.value_proj, self.feat_norm
+            value = F.linear(normed, proj.weight * ln.weight, F.linear(ln.bias, proj.weight, proj.bias))
         n_images = ms_feat_mask.shape[-1]
         ref, shapes, start = deform_inputs(sample, spatial_shapes, n_images)
         fast = self._layout_kernels(sample)
         if fast:
             # "b c h w -> b (h w) c", the normalisation and the position term in one pass over the residual
-            query = query_prep(sample, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps,
-                               self._pos_table(H * W))
+            pos = self._pos_table(H * W)
+            if torch.is_grad_enabled():
+                query = QueryPrepFunction.apply(sample, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps, pos)
+            else:
+                query = query_prep(sample, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps, pos)
         else:
             query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
             query = query + self._pos_table(H * W)
@@ -152,28 +165,31 @@ class MMFSBlock(nn.Module):
         if self.conv.kernel_size == (1, 1):
             out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
             if fast and residual is not None and residual.shape == sample.shape and residual.dtype == out.dtype:
-                return tokens_add(out, residual)                                  # "b (h w) c -> b c h w" + the caller's add
+                # "b (h w) c -> b c h w" + the caller's add
+                return TokensAddFunction.apply(out, residual) if torch.is_grad_enabled() else tokens_add(out, residual)
             out = out.transpose(1, 2).reshape(B, C, H, W)
         else:
             out = self.conv(out.transpose(1, 2).reshape(B, C, H, W))
         return out if residual is None else residual + out
 
-    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None):
+    def forward(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None, normed=None):
         """sample [B, C_q, H, W]; ms_feat [B, n, sum_l H_l*W_l, C_v]; ms_feat_mask [B, n];
         spatial_shapes: the levels of ONE image, list of (H_l, W_l)  ->  [B, C_q, H, W].
         ``value`` (an addition to sd_mmfs.py:121-146): this block's
         ``mmfs.value_proj(feat_norm(ms_feat))`` when the caller already has it (``MMFSNet``); ``image_ranks``
         (another): ``mmfs._image_relpos(ms_feat_mask, ...)``, a function of the mask only, made once for all blocks;
         ``residual`` (another): a [B, C_q, H, W] tensor the result is added to -- the add ``MMFSNet`` does with every
-        block's output (sd_mmfs.py:262-270), here so that it can share the pass that restores the layout."""
+        block's output (sd_mmfs.py:262-270), here so that it can share the pass that restores the layout; ``normed``
+        (another): ``layer_norm(ms_feat)`` without the affine, when the caller has it -- the block then folds its
+        ``feat_norm`` affine into its value projection (inside its checkpoint: the projected bank is not kept)."""
         spatial_shapes = [tuple(int(v) for v in s) for s in spatial_shapes]
         if self.gradient_checkpointing and self.training:
             # the op is stateless and re-entrant: the forward is simply re-run in backward
             # (a projected ``value`` is an input of the checkpoint: kept, not recomputed)
-            out = cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
-                                use_reentrant=False)
-            return out if residual is None else residual + out
-        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual)
+            # (``residual`` is an input the caller holds anyway -- for ``MMFSNet`` the sample itself)
+            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
+                                 normed, use_reentrant=False)
+        return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual, normed)
 
 
 class ProjectedFeatures:
@@ -204,6 +220,7 @@ class MMFSNet(nn.Module):
     # unmodified feature tensors.  Both are additions; off -> the reference's schedule.
     fused_schedule = True
     cache_projected_features = True
+    share_normalised_bank = True        # training under gradient checkpointing: see forward
 
     def __init__(self, input_channel, block_out_channels, layers_per_block, downsample_factor=1,
                  n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]):
@@ -291,7 +308,8 @@ class MMFSNet(nn.Module):
         # Under gradient checkpointing the reference recomputes feat_norm + value_proj inside every block's
         # checkpoint and keeps none of them; handing each block a projected bank as a checkpoint INPUT would
         # keep all 13 bank-sized tensors alive through the whole step -- on exactly the path where
-        # checkpointing was meant to save memory.  Training with checkpointing takes the reference's schedule.
+        # checkpointing was meant to save memory.  Training with checkpointing recomputes every block's projection as
+        # the reference does (the un-affined normalisation alone is shared: below).
         ckpt = self.training and torch.is_grad_enabled() and any(b.gradient_checkpointing for b in self._blocks())
         if proj is None and self.fused_schedule and self._can_fuse() and not ckpt:
             keep = self.cache_projected_features and not torch.is_grad_enabled()
@@ -302,15 +320,23 @@ class MMFSNet(nn.Module):
                 self.__dict__["_projected"] = proj
             else:
                 self.clear_feature_cache()
+        normed = None
         if proj is not None:
             bank, shapes, values = proj.bank, proj.shapes, proj.values
         else:
             shapes = [(f.shape[-2], f.shape[-1]) for f in mmfs_features]
             bank = self._pack(mmfs_features)
             values = [None] * (len(self.mmfs_down_blocks) + 1)
+            if ckpt and self.fused_schedule and self.share_normalised_bank and self._can_fuse():
+                # ... but the normalisation WITHOUT the affine is one bank-sized tensor for all 13 blocks: each block
+                # folds its own affine into its projection inside its checkpoint (13 + 13 LayerNorm passes over the bank
+                # and 13 LayerNorm backward passes become 1 + 1; the projected banks are still recomputed, not kept)
+                norm = self.mmfs_mid_block.feat_norm
+                normed = F.layer_norm(bank, norm.normalized_shape, None, None, norm.eps)
         # (the images' ranks among the visible ones depend on the mask only: once for the 13 blocks)
         ranks = self.mmfs_mid_block.mmfs._image_relpos(mmfs_mask, 1) if mmfs_mask.dim() == 2 else None
-        new_res = tuple(blk(r, bank, mmfs_mask, shapes, value=v, image_ranks=ranks, residual=r)
+        new_res = tuple(blk(r, bank, mmfs_mask, shapes, value=v, image_ranks=ranks, residual=r, normed=normed)
                         for r, blk, v in zip(down_block_res_samples, self.mmfs_down_blocks, values))
-        sample = self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1], image_ranks=ranks, residual=sample)
+        sample = self.mmfs_mid_block(sample, bank, mmfs_mask, shapes, value=values[-1], image_ranks=ranks, residual=sample,
+                                     normed=normed)
         return sample, new_res

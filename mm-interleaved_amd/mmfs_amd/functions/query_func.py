@@ -6,12 +6,17 @@
 ``tokens_add(tokens, residual)``    = ``residual + rearrange(tokens, "b (h w) c -> b c h w")``
                                       (sd_mmfs.py:146 and the caller's add, :262-270)
 
-Forward-only: ``MMFSBlock`` takes them when nothing on the way needs a gradient (sampling: 30 denoising steps per
-image), the framework's kernels otherwise -- which is also what the CPU tests run.
+``query_prep`` / ``tokens_add`` are the plain calls (no autograd graph: sampling, 30 denoising steps per image);
+``QueryPrepFunction`` / ``TokensAddFunction`` run the same kernels in a training step's forward (twice under gradient
+checkpointing) and evaluate the backward with the framework's own LayerNorm backward on the statistics the kernel
+returned.  Anything the kernels do not take (fp32 storage, CPU tensors: what the CPU tests run) stays on the framework's
+kernels in ``MMFSBlock``.
 """
 import ctypes
 
 import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import MultiScaleDeformableAttention as MSDA
 
@@ -38,20 +43,49 @@ def layout_supported(sample):
     return ok
 
 
-def query_prep(sample, weight, bias, eps, pos=None):
-    """sample [B, C, H, W]; weight, bias [C]; pos [H*W, C] or None -> [B, H*W, C] (no autograd)."""
+def query_prep(sample, weight, bias, eps, pos=None, stats=False):
+    """sample [B, C, H, W]; weight, bias [C]; pos [H*W, C] or None -> [B, H*W, C] (no autograd);
+    ``stats``: also the rows' (mean, rstd) [B, H*W, 1] fp32, what a LayerNorm backward needs."""
     B, C, H, W = sample.shape
     x = MSDA._aligned(sample.contiguous())
     g, b = MSDA._aligned(weight.contiguous()), MSDA._aligned(bias.contiguous())
     p = MSDA._aligned(pos.contiguous()) if pos is not None else None
     assert g.dtype == x.dtype and b.dtype == x.dtype and (p is None or (p.dtype == x.dtype and p.shape == (H * W, C)))
     q = torch.empty((B, H * W, C), dtype=x.dtype, device=x.device)
+    mean = torch.empty((B, H * W, 1), dtype=torch.float32, device=x.device) if stats else None
+    rstd = torch.empty_like(mean) if stats else None
     with MSDA._on_device(x.device):
         rc = MSDA._launch("mmfs_query_prep", x.device, _lib.mmfs_query_prep, _CODE[x.dtype], x.data_ptr(), g.data_ptr(),
-                          b.data_ptr(), p.data_ptr() if p is not None else None, q.data_ptr(), None, None,
+                          b.data_ptr(), p.data_ptr() if p is not None else None, q.data_ptr(),
+                          mean.data_ptr() if stats else None, rstd.data_ptr() if stats else None,
                           B, C, H * W, float(eps), MSDA._stream(x.device))
     MSDA._check(rc, "mmfs_query_prep")
-    return q
+    return (q, mean, rstd) if stats else q
+
+
+class QueryPrepFunction(Function):
+    """(sample [B, C, H, W], weight [C], bias [C], eps, pos [H*W, C] | None) -> LayerNorm_C(sample as tokens) + pos.
+    Forward: ``mmfs_query_prep``; backward: the framework's LayerNorm backward on the token view of the sample with the
+    kernel's statistics (gradients for sample, weight, bias; for ``pos`` the sum over the batch)."""
+
+    @staticmethod
+    def forward(ctx, sample, weight, bias, eps, pos):
+        q, mean, rstd = query_prep(sample, weight, bias, eps, pos, stats=True)
+        ctx.save_for_backward(sample, weight, bias, mean, rstd)
+        ctx.pos_grad = pos is not None and pos.requires_grad
+        return q
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_q):
+        sample, weight, bias, mean, rstd = ctx.saved_tensors
+        B, C, H, W = sample.shape
+        tok = sample.flatten(2).transpose(1, 2)
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
+        gq = grad_q.to(sample.dtype)
+        gx, gw, gb = torch.ops.aten.native_layer_norm_backward(gq, tok, [C], mean, rstd, weight, bias, mask)
+        gs = gx.transpose(1, 2).reshape(B, C, H, W) if mask[0] else None
+        return gs, gw, gb, None, (gq.sum(0) if ctx.pos_grad else None)
 
 
 def tokens_add(tokens, residual):
@@ -66,3 +100,18 @@ def tokens_add(tokens, residual):
                           y.data_ptr(), B, C, H * W, MSDA._stream(r.device))
     MSDA._check(rc, "mmfs_tokens_add")
     return y
+
+
+class TokensAddFunction(Function):
+    """(tokens [B, H*W, C], residual [B, C, H, W]) -> residual + tokens as a [B, C, H, W] map (``mmfs_tokens_add``);
+    the gradient is the incoming one for the residual and its token view for the tokens."""
+
+    @staticmethod
+    def forward(ctx, tokens, residual):
+        return tokens_add(tokens, residual)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        gt = grad_y.flatten(2).transpose(1, 2) if ctx.needs_input_grad[0] else None
+        return gt, (grad_y if ctx.needs_input_grad[1] else None)

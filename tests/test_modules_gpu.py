@@ -655,7 +655,7 @@ def test_tokens_add_kernel_is_the_transposed_add(dtype, shape):
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 def test_mmfs_net_takes_the_layout_kernels_without_gradients(dtype, tol, monkeypatch):
     """Under no_grad the 16-bit ``MMFSNet`` runs ``query_prep`` / ``tokens_add`` once per block; its outputs are the
-    framework-kernel path's within the storage type's rounding, and a call that wants gradients does not take them."""
+    framework-kernel path's within the storage type's rounding."""
     from mmfs_amd.blocks import MMFSNet, sd_mmfs
     z = load_golden("block_sd_mmfs_net")
     with contextlib.redirect_stdout(io.StringIO()):
@@ -688,10 +688,60 @@ def test_mmfs_net_takes_the_layout_kernels_without_gradients(dtype, tol, monkeyp
         assert err <= tol, err
     assert float((slow[0] - mid).abs().max()) > 1e-3                  # the blocks did contribute
     monkeypatch.undo()
-    calls2 = {"n": 0}
-    monkeypatch.setattr(sd_mmfs, "query_prep", lambda *a, **k: calls2.__setitem__("n", calls2["n"] + 1))
-    net(mid.clone().requires_grad_(True), res, feats, mask)[0].float().sum().backward()
-    assert calls2["n"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("ckpt", [False, True])
+def test_layout_kernels_in_a_training_step(dtype, tol, ckpt):
+    """With gradients the same two kernels run inside ``QueryPrepFunction`` / ``TokensAddFunction`` (also inside a
+    block's checkpoint, forward and recompute): outputs and every gradient -- residuals, features, parameters --
+    against the framework-kernel path (``MMFSBlock.layout_kernels_in_training = False``), norm-wise within the
+    storage type's rounding."""
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.blocks import MMFSNet, MMFSBlock
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=ckpt,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV, dtype).train()
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    mask = T(z["ms_mask"], None)
+    runs = {}
+    for fast in (True, False):
+        MMFSBlock.layout_kernels_in_training = fast
+        log = []
+        MSDA._event_log = log
+        try:
+            net.zero_grad()
+            mid = T(z["mid"], dtype).requires_grad_(True)
+            res = [T(z[f"res.{i}"], dtype).requires_grad_(True) for i in range(6)]
+            feats = [T(z[f"feat.{i}"], dtype).requires_grad_(True) for i in range(3)]
+            new_mid, new_res = net(mid, res, feats, mask)
+            g = torch.Generator().manual_seed(5)
+            loss = (new_mid.float() * torch.randn(new_mid.shape, generator=g).to(DEV)).sum()
+            for r in new_res:
+                loss = loss + (r.float() * torch.randn(r.shape, generator=g).to(DEV)).sum()
+            loss.backward()
+        finally:
+            MSDA._event_log = None
+            MMFSBlock.layout_kernels_in_training = True
+        n_prep = sum(n == "mmfs_query_prep" for n, _, _ in log)
+        assert n_prep == ((14 if ckpt else 7) if fast else 0), n_prep
+        # (the recompute pass of a checkpoint stops once everything the backward saved is there again: the closing add saved nothing)
+        assert sum(n == "mmfs_tokens_add" for n, _, _ in log) == (7 if fast else 0)
+        runs[fast] = ([new_mid.detach()] + [r.detach() for r in new_res] + [mid.grad] + [r.grad for r in res]
+                      + [f.grad for f in feats], {k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a.shape == b.shape
+        assert float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-6)) <= tol
+    assert sorted(runs[True][1]) == sorted(runs[False][1]) and any("query_norm.weight" in k for k in runs[True][1])
+    for k, b in runs[False][1].items():
+        a = runs[True][1][k]
+        assert float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-6)) <= tol, k
 
 
 @pytest.mark.gpu
