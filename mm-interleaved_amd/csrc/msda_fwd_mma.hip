@@ -87,7 +87,7 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
     // One run of queries per workgroup, dealt by the dispatcher in the order run -> (b, h, queries) with h = run mod H
-    // (a head's slab stays in one XCD's L2).  The loop serves the persistent variant (MMFS_MMA_GRID, msda_mma_common.h).
+    // (a head's slab stays in one XCD's L2).  The loop serves persistent workgroups (persistent_grid, msda_mma_common.h).
     for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
     const int h = run % d.H;
     const int tq = run / d.H;
@@ -406,7 +406,7 @@ static hipError_t launch_mma(const void *value, const int64_t *shapes, const int
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
     const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int grid = (int)std::min<int64_t>(runs, persistent_grid());      // (= runs unless MMFS_MMA_GRID asks for persistent workgroups)
+    const int grid = (int)persistent_grid(runs, d.H);                       // (one workgroup per CU when there are many runs, else = runs)
     hipLaunchKernelGGL((msda_fwd_mma<T, D>), dim3((unsigned)grid), dim3(kMmaThreads), lds_total, st,
                        (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (T *)out, d, q_per_wg,
                        lds_total - G::IMG0, (int)runs);

@@ -10,6 +10,7 @@
 #pragma once
 #include "msda_device.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace mmfs {
 namespace mma {
@@ -97,18 +98,29 @@ template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// Workgroups of a launch.  Default: one per run of queries (the dispatcher deals them; a CU holds one at a time).
-// MMFS_MMA_GRID=n makes the kernels PERSISTENT -- n workgroups (a multiple of 8, so that run -> XCD stays what the
-// head -> XCD affinity expects), runs dealt statically w, w + n, ...: measured slower (profiles/r03_experiments.md,
-// r03e: every wave waits at the barrier between two runs for the slowest wave of the previous one, 22 k clocks per
-// run against 9 k for the image fill of a fresh workgroup), kept as a tuning knob.
-inline int64_t persistent_grid()
+// Workgroups of a launch.  Few runs of queries (< 2 per CU): one workgroup per run, dealt by the dispatcher.  Else the
+// kernels are PERSISTENT: one workgroup per CU, runs dealt w, w + n, ... -- n a multiple of H, so that run -> head -> XCD
+// stays what the head's slab in the XCD's L2 expects, and at any moment an XCD's workgroups cover 32 consecutive runs of
+// its head = two (b, h) slabs, as the dispatcher's deal did.  A CU holds one of these workgroups at a time; relaunching a
+// 1024-lane, 160 KB workgroup per run left it idle for a quarter of the kernel (r03c).  Round 3's first measurement of
+// this (r03e) had it slower -- every wave waiting at the barrier between two runs for the slowest wave of the previous
+// one; on the closing build (image fill level by level, hosted plan, ...) it is faster: north star forward 135.6 ->
+// 132.3 us, grad_loc / grad_attn 137.3 -> 131.3, step -1.7 % (r03be / r03bf).  A slab-major deal (a workgroup's runs in
+// ONE slab, its image filled once) loses far more than the fills it saves: all B slabs of a head are then in flight in
+// an XCD at once, 11 MB against 4 MB of L2 -- forward 183 us (r03bf; = one run of 1024 queries).
+// MMFS_MMA_GRID=n: n workgroups whatever the shape (tuning); MMFS_MMA_PERSIST=0: always one workgroup per run.
+inline int64_t persistent_grid(int64_t runs, int H)
 {
-    static const int64_t n = [] {
-        if (const char *e = getenv("MMFS_MMA_GRID")) if (atoi(e) > 0) return (int64_t)atoi(e);
-        return (int64_t)0x7fffffff;
+    static const int env_grid = [] { const char *e = getenv("MMFS_MMA_GRID"); return e ? atoi(e) : 0; }();
+    static const int env_persist = [] { const char *e = getenv("MMFS_MMA_PERSIST"); return e ? atoi(e) : 1; }();
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
     }();
-    return n;
+    if (env_grid > 0) return std::min<int64_t>(runs, env_grid);
+    if (!env_persist || cus <= 0 || H <= 0 || cus % H || runs < 2 * (int64_t)cus) return runs;
+    return cus;
 }
 
 // Level table -> LDS, and which levels live in the image: smallest first (ties: lower index), while they fit

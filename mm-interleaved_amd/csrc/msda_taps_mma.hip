@@ -63,7 +63,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     const int64_t HD = (int64_t)d.H * d.D;
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
-    // one run per workgroup (or persistent workgroups: MMFS_MMA_GRID, msda_mma_common.h)
+    // one run per workgroup, or persistent workgroups (persistent_grid, msda_mma_common.h)
     for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
     const int h = run % d.H;
     const int tq = run / d.H;
@@ -346,7 +346,7 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
     const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int grid = (int)std::min<int64_t>(runs, persistent_grid());      // (= runs unless MMFS_MMA_GRID asks for persistent workgroups)
+    const int grid = (int)persistent_grid(runs, d.H);                       // (one workgroup per CU when there are many runs, else = runs)
     hipLaunchKernelGGL((msda_taps_mma<T, D>), dim3((unsigned)grid), dim3(kMmaThreads), kLdsTotal, st,
                        (const T *)value, shapes, start, (const T *)loc, (const T *)attn, (const T *)go, (T *)gl, (T *)ga,
                        d, q_per_wg, kLdsTotal - G::IMG0, (int)runs, jb);
