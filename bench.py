@@ -31,6 +31,8 @@ Extra objects on the JSON line:
                pass) vs 8 TB/s; "traffic" = HBM bytes of that kernel from profiles/pmc_traffic.json
                when that file has an entry for this workload and kernel ("traffic_from" names the
                rocprofv3 --pmc run it was taken from), else null
+  kernels_frac the same fraction for EVERY kernel of the step (its own algorithmic bytes / its mean duration / 8 TB/s):
+               with three kernels within a few us of each other the "dominant" one changes from box to box
   exchange     N > 1 only: the path's one exchange step, timed after the main region:
                every rank all-gathers the multiscale features of its block of context images (LLM
                geometry, 4 images per sequence: BASELINE config 5) and builds its sequences' bank
@@ -470,6 +472,10 @@ def main():
                          "traffic_from": traffic_from,
                          "algorithmic_bytes": ab[dom], "mean_us": round(mean_ms[dom] * 1e3, 2)},
             "kernels_mean_us": {k: round(v * 1e3, 2) for k, v in mean_ms.items()},
+            # every kernel of the step against the same roofline (algorithmic bytes of ITS tensors / its mean time / peak):
+            # with three kernels within a few us of each other, which one is "dominant" changes from box to box
+            "kernels_frac": {k: round(ab[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in mean_ms.items()
+                             if k in ab and v > 0 and ab[k] > 0},
             # event brackets cost a few us each and span a stage's helper launches: their sum may exceed the clean step
             "event_overhead_us": round(sum(mean_ms.values()) * 1e3 - elapsed / args.steps * 1e6, 2),
             "levels": "fresh per call, unregistered (reference call pattern)" if args.fresh_levels else "make_level_tables (built once, known to the shim)",
