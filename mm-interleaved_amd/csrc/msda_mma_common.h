@@ -111,8 +111,9 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // MMFS_MMA_GRID=n: n workgroups whatever the shape (tuning); MMFS_MMA_PERSIST=0: always one workgroup per run.
 inline int64_t persistent_grid(int64_t runs, int H)
 {
-    static const int env_grid = [] { const char *e = getenv("MMFS_MMA_GRID"); return e ? atoi(e) : 0; }();
-    static const int env_persist = [] { const char *e = getenv("MMFS_MMA_PERSIST"); return e ? atoi(e) : 1; }();
+    // (read per call: the tests compare the deals inside one process)
+    const char *eg = getenv("MMFS_MMA_GRID"), *ep = getenv("MMFS_MMA_PERSIST");
+    const int env_grid = eg ? atoi(eg) : 0, env_persist = ep ? atoi(ep) : 1;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;

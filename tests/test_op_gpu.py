@@ -595,6 +595,41 @@ def test_lds_levels_forward_non_finite_rows_stay_with_their_queries(D):
     assert np.allclose(got[same], got[0, 0, 0]) and got[9, 0, 0] < got[0, 0, 0]
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8192), (1, 16, 4096 * 3 + 77), (3, 4, 300)])
+def test_persistent_workgroups_compute_what_one_workgroup_per_run_does(shape, monkeypatch):
+    """The LDS-resident kernels run as one persistent workgroup per CU when there are at least two runs of queries
+    per CU (msda_mma_common.h, persistent_grid): a workgroup then serves several runs -- other (b, h) slabs: the image
+    is refilled behind a barrier -- instead of one.  Which workgroup serves a run changes nothing a query sees:
+    forward and both gradients bit-equal to one workgroup per run (MMFS_MMA_PERSIST=0), also with only 8 workgroups
+    for everything (MMFS_MMA_GRID=8), also where a workgroup's last run is a ragged one."""
+    import MultiScaleDeformableAttention as MSDA
+    B, H, Nq = shape
+    x = make_inputs(B, H, 128, Nq, 4, [(24, 24), (16, 16), (8, 8)], seed=9, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    dev = lambda t: t.to(DEV, torch.bfloat16) if t.is_floating_point() else t.to(DEV)
+    args = [dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn")]
+    grad = torch.randn(B, Nq, H * 128, generator=torch.Generator().manual_seed(2)).to(DEV, torch.bfloat16)
+    old_f, old_t = MSDA._fwd_algo, MSDA._taps_algo
+    MSDA._fwd_algo, MSDA._taps_algo = "lds", "lds"
+    res = {}
+    try:
+        for name, env in (("default", {}), ("per_run", {"MMFS_MMA_PERSIST": "0"}), ("grid8", {"MMFS_MMA_GRID": "8"})):
+            monkeypatch.delenv("MMFS_MMA_PERSIST", raising=False)
+            monkeypatch.delenv("MMFS_MMA_GRID", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out = MSDA.ms_deform_attn_forward(*args, 1)
+            gv, gl, ga = MSDA.ms_deform_attn_backward(*args, grad, 1)
+            torch.cuda.synchronize()
+            res[name] = (out, gl, ga)
+    finally:
+        MSDA._fwd_algo, MSDA._taps_algo = old_f, old_t
+    for name in ("per_run", "grid8"):
+        for a, b in zip(res["default"], res[name]):
+            assert torch.equal(a, b), name
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    assert max_abs(res["default"][0].double().cpu().numpy(), want) <= TOL[torch.bfloat16] * max(1.0, float(np.abs(want).max()))
+
+
 def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
     """From 4096 samples per (b, h) slab on (and at least 64 queries), 16-bit heads of 128 channels take the LDS-resident
     formulation (and the autograd function's outputs and gradients still match the oracle on such a shape); below, the
