@@ -117,7 +117,7 @@ plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
     if (item_ok && gl == 0) sink[item] = sink_sum;
     if (!act) return;
 #pragma unroll
-    for (int p = 0; p < P; ++p) lg[p] *= inv;
+    for (int p = 0; p < P; ++p) { lg[p] *= inv; asm volatile("" : "+v"(lg[p])); }       // (fp32 product, then rounded: see below)
     const int64_t row = item * nL + gl;
     store_row<T, P>(attn + row * P, lg);
     // locations: ref + (offset_q + offset_table) * ratio_l / (W, H)        (mmfs.py:193-198, 243-250)
@@ -129,8 +129,14 @@ plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
     const float sx = ratios[l] / (float)shapes[2 * gl + 1], sy = ratios[l] / (float)shapes[2 * gl];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        xy[2 * p] = rx + (oq[2 * p] + ot[2 * p]) * sx;
-        xy[2 * p + 1] = ry + (oq[2 * p + 1] + ot[2 * p + 1]) * sy;
+        // An fp32 result, THEN rounded to the storage type -- in both kernels that evaluate the plan (here and
+        // mmfs_sample_fwd).  For fp16 storage the compiler folds ``(half)fma(a, b, c)`` into v_fma_mixlo_f16, which rounds
+        // the exact sum ONCE; with offsets that are halves and scales that are powers of two the fp32 result often sits
+        // exactly on a half-precision tie, where the two roundings part (a golden: one location in 4608 -> two outputs one
+        // unit apart between the fused sampler and plan + op).  The opaque register keeps the fp32 rounding.
+        xy[2 * p] = fmaf(oq[2 * p] + ot[2 * p], sx, rx);
+        xy[2 * p + 1] = fmaf(oq[2 * p + 1] + ot[2 * p + 1], sy, ry);
+        asm volatile("" : "+v"(xy[2 * p]), "+v"(xy[2 * p + 1]));
     }
     store_row<T, 2 * P>(loc + row * 2 * P, xy);
 }
@@ -411,8 +417,10 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
             for (int p = 0; p < P; ++p) {
                 float wgt = __expf(lg[p] - st2.x);
                 wgt *= st2.y;
-                dst[p] = make_float4(to_f32((T)(rx + (oq[2 * p] + ot[2 * p]) * sx)),
-                                     to_f32((T)(ry + (oq[2 * p + 1] + ot[2 * p + 1]) * sy)), to_f32((T)wgt), 0.f);
+                // (as plan_forward_kernel: fp32 results behind an opaque register, then rounded to the storage type)
+                float lx = fmaf(oq[2 * p] + ot[2 * p], sx, rx), ly = fmaf(oq[2 * p + 1] + ot[2 * p + 1], sy, ry);
+                asm volatile("" : "+v"(lx), "+v"(ly), "+v"(wgt));
+                dst[p] = make_float4(to_f32((T)lx), to_f32((T)ly), to_f32((T)wgt), 0.f);
             }
         }
         __syncthreads();

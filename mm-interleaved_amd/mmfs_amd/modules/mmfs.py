@@ -66,6 +66,7 @@ class MMFS(nn.Module):
         self.offset_init_magnitude = offset_init_magnitude
         self.max_num_image_per_seq = max_num_image_per_seq
         self.fused_plan = True                    # use csrc/mmfs_plan.hip when it applies
+        self.fold_query_projection = True         # no-grad calls: dynamic_offset_mask folded into the heads (_plan_tables)
         # inference: plan -> sampler in one kernel, no loc / attn tensors (MMFS_FUSED_SAMPLER=0: measurements)
         self.fused_sampler = os.environ.get("MMFS_FUSED_SAMPLER", "1") != "0"
         d_inner = int(d_model * ratio)
@@ -125,8 +126,10 @@ class MMFS(nn.Module):
         sig = None
         if keep:
             ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.sampling_offsets.bias,
-                  self.attention_weights.weight, self.attention_weights.bias)
-            sig = (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps)
+                  self.attention_weights.weight, self.attention_weights.bias,
+                  self.dynamic_offset_mask.weight, self.dynamic_offset_mask.bias)
+            sig = (self.fold_query_projection,)
+            sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps if t is not None)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
         table = self.query_relpos.weight                                      # [max_img, d_query]
@@ -140,10 +143,27 @@ class MMFS(nn.Module):
             # result's two column ranges the fused sampler takes as they lie, ``mmfs_sample_forward_heads``)
             so = self.sampling_offsets
             stack = keep and so.bias is not None and so.weight.dtype == aw_w.dtype and so.bias.dtype == aw_b.dtype
-            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b,
-                   torch.cat((so.weight, aw_w), 0) if stack else None, torch.cat((so.bias, aw_b), 0) if stack else None)
+            cat_w = torch.cat((so.weight, aw_w), 0) if stack else None
+            cat_b = torch.cat((so.bias, aw_b), 0) if stack else None
+            # ... and nothing non-linear stands between ``dynamic_offset_mask`` (d_query x d_query: 32 MB of weights at the
+            # LLM's width, two thirds of the bytes a decode step of a layer streams) and the heads:
+            #     heads(W_a x + b_a) = (W_h W_a) x + (W_h b_a + b_h)
+            # so the kept weights are the PRODUCT (formed once in fp32, rounded once to the storage type) and a call
+            # evaluates one [H*P*2 + H*L*P, d_query] GEMM on the query itself.  Same mathematics, other rounding points
+            # (the intermediate is not rounded to 16 bits, the folded weights are): ``fold_query_projection = False``
+            # keeps the two GEMMs.
+            dom = self.dynamic_offset_mask
+            fold = stack and self.fold_query_projection and dom.weight.dtype == cat_w.dtype
+            fold_w = fold_b = None
+            if fold:
+                ft = torch.promote_types(cat_w.dtype, torch.float32)           # (fp32 for 16-bit storage)
+                wh = cat_w.to(ft)
+                fold_w = (wh @ dom.weight.to(ft)).to(cat_w.dtype)
+                fold_b = cat_b.to(ft) if dom.bias is None else torch.addmv(cat_b.to(ft), wh, dom.bias.to(ft))
+                fold_b = fold_b.to(cat_b.dtype)
+            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b, cat_w, cat_b, fold_w, fold_b)
         else:
-            res = (off_tab, F.linear(table, self.attention_weights.weight), None, None, None, None)   # [max_img, H*L*(P+1)]
+            res = (off_tab, F.linear(table, self.attention_weights.weight), None, None, None, None, None, None)   # [max_img, H*L*(P+1)]
         if keep:
             self._tables = (sig, res)
         return res
@@ -163,18 +183,21 @@ class MMFS(nn.Module):
         if n >= self.max_num_image_per_seq:       # only then can an index leave the table
             assert int(relpos.max()) < self.max_num_image_per_seq
 
-        q = self.dynamic_offset_mask(query)                                   # one GEMM, not n
-
-        if self.fused_plan and mmfs_plan_supported(q, reference_points, L, P, n):
+        if self.fused_plan and mmfs_plan_supported(query, reference_points, L, P, n):
             # one gfx950 kernel for the rest (csrc/mmfs_plan.hip), fp32 inside, rounded once.  Only
             # the P point columns of the attention head are evaluated: its (P+1)-th column is
             # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
-            off_tab, att_tab, aw_w, aw_b, cat_w, cat_b = self._plan_tables(True)
-            if cat_w is not None and q.dtype == cat_w.dtype:                   # (no gradients wanted: see _plan_tables)
-                both = F.linear(q, cat_w, cat_b)                              # [N, Lq, H*P*2 + H*L*P]
+            off_tab, att_tab, aw_w, aw_b, cat_w, cat_b, fold_w, fold_b = self._plan_tables(True)
+            if fold_w is not None and query.dtype == fold_w.dtype:            # (no gradients wanted: see _plan_tables)
+                both = F.linear(query, fold_w, fold_b)                        # [N, Lq, H*P*2 + H*L*P], straight from the query
                 off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
             else:
-                off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
+                q = self.dynamic_offset_mask(query)                           # one GEMM, not n
+                if cat_w is not None and q.dtype == cat_w.dtype:
+                    both = F.linear(q, cat_w, cat_b)                          # [N, Lq, H*P*2 + H*L*P]
+                    off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
+                else:
+                    off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
             heads = (off_q, att_q, off_tab, att_tab, relpos,
                      reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
             if sampler is not None:
@@ -188,6 +211,7 @@ class MMFS(nn.Module):
             loc, attn, sink_sum = MMFSPlanFunction.apply(off_q.contiguous(), att_q.contiguous(), *heads[2:])
             return loc, attn, sink_sum
 
+        q = self.dynamic_offset_mask(query)                                   # one GEMM, not n
         off_tab, att_tab = self._plan_tables(False)[:2]
         # offsets: [N, Lq, 1, :] + [N, 1|Lq, n, :]  ->  [N, Lq, n, H, P, 2]
         offsets = self.sampling_offsets(q)[:, :, None, :] + off_tab[relpos]

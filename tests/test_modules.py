@@ -536,3 +536,41 @@ def test_decode_caches_follow_the_parameters_and_the_mask(oracle_op):
         d = stack(mask, shared=True)
     close(d, stack(mask.clone()).detach().numpy(), 1e-12)
     assert not torch.allclose(d, c)
+
+
+def test_folded_query_projection_is_the_two_gemms():
+    """Without gradients ``MMFS._plan_tables`` keeps the stacked heads' weights already multiplied with
+    ``dynamic_offset_mask`` (nothing non-linear stands between them): one GEMM on the query itself.  The kept product
+    equals the two-GEMM statement (fp64: to rounding), follows every parameter that went into it, is not made with
+    gradients enabled, and ``fold_query_projection = False`` keeps the two GEMMs."""
+    from mmfs_amd.modules import MMFS
+    torch.manual_seed(4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MMFS(d_model=32, d_query=24, d_value=16, d_out=24, n_levels=2, n_heads=4, n_points=4, ratio=1.0,
+                 spatial_shapes=[8, 4], base_spatial_shape=4, max_num_image_per_seq=6).double()
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.1)
+        m.attention_weights.weight.normal_(0, 0.1)
+        m.dynamic_offset_mask.bias.normal_(0, 0.1)
+    x = torch.randn(3, 5, 24, dtype=torch.float64)
+    H, L, P = 4, 2, 4
+    with torch.no_grad():
+        off_tab, att_tab, aw_w, aw_b, cat_w, cat_b, fold_w, fold_b = m._plan_tables(True)
+        assert fold_w.shape == (H * P * 2 + H * L * P, 24) and cat_w.shape == fold_w.shape
+        want = torch.nn.functional.linear(m.dynamic_offset_mask(x), cat_w, cat_b)
+        got = torch.nn.functional.linear(x, fold_w, fold_b)
+        assert float((got - want).abs().max()) <= 1e-12
+        # the two column ranges are the two heads (the attention head without its sink columns)
+        assert torch.allclose(want[..., :H * P * 2], m.sampling_offsets(m.dynamic_offset_mask(x)), atol=1e-13)
+        full = m.attention_weights(m.dynamic_offset_mask(x)).view(3, 5, H, L, P + 1)[..., :P].reshape(3, 5, -1)
+        assert torch.allclose(want[..., H * P * 2:], full, atol=1e-13)
+        assert m._plan_tables(True)[6] is fold_w                          # kept
+        m.dynamic_offset_mask.weight.mul_(1.5)                             # a parameter of the product moves in place
+        again = m._plan_tables(True)
+        assert again[6] is not fold_w
+        assert float((torch.nn.functional.linear(x, again[6], again[7])
+                      - torch.nn.functional.linear(m.dynamic_offset_mask(x), again[4], again[5])).abs().max()) <= 1e-12
+        m.fold_query_projection = False
+        assert m._plan_tables(True)[6] is None and m._plan_tables(True)[4] is not None
+        m.fold_query_projection = True
+    assert m._plan_tables(True)[4] is None and m._plan_tables(True)[6] is None     # with gradients: nothing kept, nothing folded
