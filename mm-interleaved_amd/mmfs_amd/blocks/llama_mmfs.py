@@ -17,7 +17,7 @@ from torch import nn
 
 from ..functions.norm_func import RMSNormFunction, rmsnorm_supported
 from ..levels import make_level_tables
-from ..modules.mmfs import MMFS
+from ..modules.mmfs import MMFS, FoldedLinear
 
 
 class MMFSRMSNorm(nn.Module):
@@ -96,6 +96,8 @@ class LlamaMMFSAttention(nn.Module):
         eps = getattr(config, "rms_norm_eps", 1e-6)
         self.norm1 = MMFSRMSNorm(config.hidden_size, eps=eps)
         self.norm2 = MMFSRMSNorm(self.vision_hidden_size, eps=eps)
+        self.fold_gate = True                     # no-grad calls: tanh(gate) folded into the output projection (forward)
+        self._gate_fold = FoldedLinear()
 
     def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None, image_ranks=None):
         """hidden_states [B, Lq, hidden]; vision_hidden_states [B, n, sum hw, image_embed_dim];
@@ -107,6 +109,15 @@ class LlamaMMFSAttention(nn.Module):
         if value is None:
             vision_hidden_states = self.norm2(vision_hidden_states)
         ref, shapes, start = deform_inputs(hidden_states, vision_hidden_states, self.spatial_shapes)
+        if self.fold_gate and not torch.is_grad_enabled():
+            # tanh(gate) * output_proj(x) = ((tanh(gate) W) x + tanh(gate) b): without gradients the gate rides in the
+            # output projection's weights (kept until a parameter moves) -- one full-size multiply per layer less
+            proj = self.attn.output_proj
+            folded = self._gate_fold.get(proj.weight, proj.bias, self._gate(), None)
+            return self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
+                             input_spatial_shapes=shapes, input_level_start_index=start, input_padding_mask=None,
+                             attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks,
+                             output_weights=folded)
         out = self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                         input_spatial_shapes=shapes, input_level_start_index=start,
                         input_padding_mask=None, attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks)

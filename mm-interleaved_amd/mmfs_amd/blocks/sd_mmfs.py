@@ -21,7 +21,7 @@ from torch import nn
 from ..bank import gather_bank
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
 from ..levels import make_level_tables
-from ..modules.mmfs import MMFS
+from ..modules.mmfs import MMFS, FoldedLinear
 
 
 # ------------------------------------------------------------------ constant tables
@@ -83,6 +83,7 @@ def deform_inputs(sample, spatial_shapes=((8, 8),), n_images=1):
 # ------------------------------------------------------------------ blocks
 class MMFSBlock(nn.Module):
     layout_kernels_in_training = True
+    fold_conv = True
 
     def __init__(self, attn_dim=1024, query_dim=320, feat_dim=1024, num_heads=16, n_points=8,
                  n_levels=1, deform_ratio=1.0, norm_layer=partial(nn.LayerNorm, eps=1e-6),
@@ -101,6 +102,7 @@ class MMFSBlock(nn.Module):
         self.conv = nn.Conv2d(query_dim, query_dim, kernel_size=1, stride=1)
         nn.init.zeros_(self.conv.weight)          # zero_module (sd_mmfs.py:88-94, 148-151)
         nn.init.zeros_(self.conv.bias)
+        self._conv_fold = FoldedLinear()
 
     def _reset_parameters(self):
         self.mmfs._reset_parameters()
@@ -157,13 +159,22 @@ class MMFSBlock(nn.Module):
         else:
             query = self.query_norm(sample.flatten(2).transpose(1, 2))            # b (h w) c
             query = query + self._pos_table(H * W)
+        # the zero-initialised 1x1 convolution follows the output projection with nothing non-linear between them: without
+        # gradients the two are ONE GEMM on kept product weights (FoldedLinear; ``fold_conv = False``: two)
+        one_gemm = self.fold_conv and not torch.is_grad_enabled() and self.conv.kernel_size == (1, 1)
+        folded = None
+        if one_gemm:
+            proj = self.mmfs.output_proj
+            folded = self._conv_fold.get(proj.weight, proj.bias, self.conv.weight.view(C, C), self.conv.bias)
         out = self.mmfs(query, ref, self.feat_norm(ms_feat) if value is None else ms_feat, shapes, start,
-                        input_padding_mask=None, attention_mask=ms_feat_mask, value=value, image_ranks=image_ranks)
+                        input_padding_mask=None, attention_mask=ms_feat_mask, value=value, image_ranks=image_ranks,
+                        output_weights=folded)
         # the zero-initialised 1x1 convolution (sd_mmfs.py:88-94, 146) is a per-token linear map:
         # applied on the token-major tensor it is one GEMM each way (the convolution library's 1x1
         # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
         if self.conv.kernel_size == (1, 1):
-            out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
+            if not one_gemm:
+                out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
             if fast and residual is not None and residual.shape == sample.shape and residual.dtype == out.dtype:
                 # "b (h w) c -> b c h w" + the caller's add
                 return TokensAddFunction.apply(out, residual) if torch.is_grad_enabled() else tokens_add(out, residual)

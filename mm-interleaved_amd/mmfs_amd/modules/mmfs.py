@@ -31,6 +31,39 @@ from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mm
 from ..levels import host_shapes
 
 
+class FoldedLinear:
+    """``outer(inner(x))`` of two Linear layers with nothing non-linear between them as ONE Linear layer, for calls that
+    want no gradients: W = W_outer W_inner, b = W_outer b_inner + b_outer (``outer`` may also be a scalar tensor: a gate).
+    Formed once in fp32 (fp64 for fp64 parameters), rounded once to the storage type, kept until one of the parameters
+    moves (data pointer + version counter, as ``MMFS._plan_tables``); made in inference mode it is not used outside it.
+    Same mathematics as the two layers, other rounding points: the intermediate is not rounded, the product is."""
+
+    def __init__(self):
+        self._kept = None
+
+    def get(self, inner_w, inner_b, outer_w, outer_b):
+        ps = tuple(t for t in (inner_w, inner_b, outer_w, outer_b) if t is not None)
+        sig = (torch.is_inference_mode_enabled(),) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps)
+        if self._kept is not None and self._kept[0] == sig:
+            return self._kept[1]
+        dt = inner_w.dtype
+        ft = torch.promote_types(dt, torch.float32)
+        wi = inner_w.to(ft)
+        bi = inner_b.to(ft) if inner_b is not None else None
+        if outer_w.dim() <= 1 and outer_w.numel() == 1:                  # a scalar in front: gate * (W x + b)
+            g = outer_w.to(ft).reshape(())
+            w, b = g * wi, (g * bi if bi is not None else None)
+        else:
+            wo = outer_w.to(ft)
+            w = wo @ wi
+            b = wo @ bi if bi is not None else None
+            if outer_b is not None:
+                b = outer_b.to(ft) if b is None else b + outer_b.to(ft)
+        res = (w.to(dt), b.to(dt) if b is not None else None)
+        self._kept = (sig, res)
+        return res
+
+
 class MMFS(nn.Module):
     def __init__(
         self,
@@ -246,11 +279,13 @@ class MMFS(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None):
+                input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None,
+                output_weights=None):
         """Arguments and result as mmfs.py:120-141 (``value`` is an addition: the caller's own
         ``value_proj(input_flatten)`` [N, n, hw, d_inner], e.g. one an ``MMFSNet`` projected for
         all its blocks at once; ``input_flatten`` is then only looked at for its shape; ``image_ranks`` another: this
-        module's ``_image_relpos(attention_mask, Lq)`` as a caller made it once for several layers):
+        module's ``_image_relpos(attention_mask, Lq)`` as a caller made it once for several layers; ``output_weights``
+        a third: (weight, bias) to use in ``output_proj``'s place -- a caller's ``FoldedLinear`` of it with what follows):
         query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
         input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
         input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
@@ -283,7 +318,7 @@ class MMFS(nn.Module):
         if loc is None:
             out = attn                            # (the fused kernel's result)
             if sink_w is None:                    # ... the ignore token's term included
-                return self.output_proj(out)
+                return self.output_proj(out) if output_weights is None else F.linear(out, *output_weights)
         else:
             # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
             # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
@@ -292,4 +327,4 @@ class MMFS(nn.Module):
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
-        return self.output_proj(out)
+        return self.output_proj(out) if output_weights is None else F.linear(out, *output_weights)

@@ -574,3 +574,56 @@ def test_folded_query_projection_is_the_two_gemms():
         assert m._plan_tables(True)[6] is None and m._plan_tables(True)[4] is not None
         m.fold_query_projection = True
     assert m._plan_tables(True)[4] is None and m._plan_tables(True)[6] is None     # with gradients: nothing kept, nothing folded
+
+
+def test_folded_linear_is_the_two_layers_and_follows_its_parameters():
+    """``FoldedLinear`` (what ``MMFSBlock`` does with output_proj + its 1x1 convolution and ``LlamaMMFSAttention`` with
+    output_proj + tanh(gate) when no gradient is wanted): the kept product equals the two layers to rounding (fp64), is
+    kept while nothing moves, follows a parameter that moves in place; and the blocks' no-grad outputs are their
+    with-grad ones."""
+    from mmfs_amd.modules.mmfs import FoldedLinear
+    g = torch.Generator().manual_seed(1)
+    wi, bi = torch.randn(7, 5, generator=g, dtype=torch.float64), torch.randn(7, generator=g, dtype=torch.float64)
+    wo, bo = torch.randn(3, 7, generator=g, dtype=torch.float64), torch.randn(3, generator=g, dtype=torch.float64)
+    x = torch.randn(4, 5, generator=g, dtype=torch.float64)
+    F_ = torch.nn.functional
+    fl = FoldedLinear()
+    w, b = fl.get(wi, bi, wo, bo)
+    assert float((F_.linear(x, w, b) - F_.linear(F_.linear(x, wi, bi), wo, bo)).abs().max()) <= 1e-13
+    assert fl.get(wi, bi, wo, bo)[0] is w
+    wo.mul_(2.0)
+    w2, b2 = fl.get(wi, bi, wo, bo)
+    assert w2 is not w and float((F_.linear(x, w2, b2) - F_.linear(F_.linear(x, wi, bi), wo, bo)).abs().max()) <= 1e-13
+    gate = torch.tensor([0.3], dtype=torch.float64).tanh()
+    wg, bg = FoldedLinear().get(wi, bi, gate, None)
+    assert float((F_.linear(x, wg, bg) - F_.linear(x, wi, bi) * gate).abs().max()) <= 1e-14
+    wn, bn = FoldedLinear().get(wi, None, wo, bo)                      # an inner layer without bias
+    assert float((F_.linear(x, wn, bn) - F_.linear(F_.linear(x, wi), wo, bo)).abs().max()) <= 1e-13
+
+
+def test_blocks_without_gradients_equal_blocks_with(oracle_op):
+    """The folds the blocks take when no gradient is wanted (conv into output_proj, gate into output_proj) against the
+    same call with gradients enabled (nothing folded): fp64, to rounding."""
+    z = load_golden("block_sd_mmfs_net")
+    net = _tiny_net(z)
+    res = [T(z[f"res.{i}"]) for i in range(6)]
+    feats = [T(z[f"feat.{i}"]) for i in range(3)]
+    a = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    with torch.no_grad():
+        b = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+        assert net.mmfs_mid_block._conv_fold._kept is not None          # the fold was taken
+    close(b[0], a[0].detach().numpy(), 1e-11)
+    for x, y in zip(b[1], a[1]):
+        close(x, y.detach().numpy(), 1e-11)
+    layers = _llama_stack(2, seed=3)
+    h = torch.randn(2, 5, layers[0].hidden_size, dtype=torch.float64)
+    f = torch.randn(2, 1, 84, 32, dtype=torch.float64)
+    mask = torch.ones(2, 5, 1, dtype=torch.float64)
+    with torch.no_grad():
+        for l in layers:
+            l.gate.fill_(0.7)
+    want = layers[1](h, f, mask)
+    with torch.no_grad():
+        got = layers[1](h, f, mask)
+        assert layers[1]._gate_fold._kept is not None
+    close(got, want.detach().numpy(), 1e-12)
