@@ -47,3 +47,29 @@ def test_large_and_degenerate_extents(selfcheck):
 def test_levels_without_tiles_say_so(selfcheck):
     for h, w in ((0, 5), (5, 0), (-1, 3), (65536, 2), (2, 65536)):
         assert selfcheck(h, w, 1) == -1, (h, w)
+
+
+def test_token_rows_hands_over_column_ranges_only_when_the_vector_loads_allow():
+    """``mmfs_plan_func._token_rows`` (host logic of ``mmfs_sample_forward_heads``): a column range of a wider
+    row-major matrix is passed as it lies -- with the distance between two token rows -- when its rows start on the
+    kernel's vector boundary; anything else is copied (distance 0 = packed)."""
+    import torch
+    from mmfs_amd.functions.mmfs_plan_func import _token_rows
+    both = torch.zeros(3, 5, 64 + 128 + 16, dtype=torch.bfloat16)          # 416-byte rows: whole 32-byte vectors
+    off, att = both[..., :64], both[..., 64:192]
+    t, ld = _token_rows(off, 16)
+    assert t.data_ptr() == off.data_ptr() and ld == 208
+    t, ld = _token_rows(att, 8)
+    assert t.data_ptr() == att.data_ptr() and ld == 208
+    t, ld = _token_rows(both[..., 1:65], 16)                 # rows start 2 bytes off the 32-byte boundary: copied
+    assert ld == 0 and t.is_contiguous()
+    t, ld = _token_rows(torch.zeros(3, 5, 64, dtype=torch.bfloat16), 16)
+    assert ld == 0                                            # packed already
+    one = both[:, :1]                                         # one token per sequence: rows one batch stride apart
+    t, ld = _token_rows(one[..., :64], 16)
+    assert t.data_ptr() == one.data_ptr() and ld == 5 * 208
+    wide = torch.zeros(3, 5, 198, dtype=torch.float32)[..., :64]          # 792-byte rows: not a multiple of 64 bytes
+    t, ld = _token_rows(wide, 16)
+    assert ld == 0 and t.is_contiguous()
+    t, ld = _token_rows(both.transpose(0, 1)[..., :64], 16)   # token rows not one after the other: copied
+    assert ld == 0 and t.is_contiguous()
