@@ -470,6 +470,16 @@ int mmfs_query_prep(int dtype, const void *x, const void *gamma, const void *bet
                     float *mean, float *rstd, int64_t B, int64_t C, int64_t HW, float eps, void *stream);
 int mmfs_tokens_add(int dtype, const void *tok, const void *res, void *y, int64_t B, int64_t C, int64_t HW, void *stream);
 
+/* ---- a Linear layer for a handful of tokens (csrc/mmfs_linear.hip) -----------------------------------------------------
+ * y[m, :] = x[m, :] W^T + bias for M <= 8 token rows -- what an MMFS layer's Linear layers (mmfs.py:174-176, 274) are in a
+ * decode step: each weight row is read once and meets M activations.  x [M, K] with rows ``ldx`` elements apart, W [N, K]
+ * packed (nn.Linear's layout), bias [N] or NULL, y [M, N] with rows ``ldy`` apart; fp32 accumulation, bias added in fp32,
+ * one rounding to the storage type.  16-bit storage types, K % 8 == 0, M * K * 2 bytes <= 64 KB (rounded up to 4 or 8
+ * rows); else MMFS_E_UNSUPPORTED (mmfs_linear_small_supported) and the caller keeps its BLAS call. */
+int mmfs_linear_small_supported(int dtype, int64_t M, int64_t N, int64_t K);
+int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *bias, void *y,
+                      int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
+from ..functions.linear_func import small_linear
 from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
 from ..levels import host_shapes
 
@@ -222,7 +223,7 @@ class MMFS(nn.Module):
             # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
             off_tab, att_tab, aw_w, aw_b, cat_w, cat_b, fold_w, fold_b = self._plan_tables(True)
             if fold_w is not None and query.dtype == fold_w.dtype:            # (no gradients wanted: see _plan_tables)
-                both = F.linear(query, fold_w, fold_b)                        # [N, Lq, H*P*2 + H*L*P], straight from the query
+                both = small_linear(query, fold_w, fold_b)                    # [N, Lq, H*P*2 + H*L*P], straight from the query
                 off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
             else:
                 q = self.dynamic_offset_mask(query)                           # one GEMM, not n
@@ -277,6 +278,16 @@ class MMFS(nn.Module):
                 f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         return loc, attn, sink_w
 
+    def _project_out(self, out, output_weights):
+        """``output_proj`` (or the caller's folded weights in its place); a handful of token rows without gradients: the
+        weight-streaming kernel (functions/linear_func.py)."""
+        if output_weights is None:
+            proj = self.output_proj
+            if type(proj) is not nn.Linear or proj._forward_hooks or proj._forward_pre_hooks:
+                return proj(out)                  # (someone wrapped or hooked the layer: it is theirs to call)
+            output_weights = (proj.weight, proj.bias)
+        return small_linear(out, *output_weights)
+
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None,
@@ -318,7 +329,7 @@ class MMFS(nn.Module):
         if loc is None:
             out = attn                            # (the fused kernel's result)
             if sink_w is None:                    # ... the ignore token's term included
-                return self.output_proj(out) if output_weights is None else F.linear(out, *output_weights)
+                return self._project_out(out, output_weights)
         else:
             # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
             # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
@@ -327,4 +338,4 @@ class MMFS(nn.Module):
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
-        return self.output_proj(out) if output_weights is None else F.linear(out, *output_weights)
+        return self._project_out(out, output_weights)

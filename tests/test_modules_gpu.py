@@ -779,3 +779,45 @@ def test_fused_sampler_takes_the_query_heads_as_columns_of_one_matrix(dtype, Lq)
     want2 = mmfs_sample_forward(value, sh, st, odd.contiguous(), views[1].contiguous(), off_tab, att_tab, relpos, ref,
                                 ratios, H, L, P, token=tok)
     assert torch.equal(got2[0], want2[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("shape", [(4, 640, 4096), (1, 4096, 1024), (8, 640, 4096), (3, 37, 72), (5, 1, 8), (2, 1000, 2048)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_small_linear_kernel_matches_the_library(dtype, tol, shape, with_bias):
+    """csrc/mmfs_linear.hip: y = x W^T + b for at most 8 token rows, against fp64 on the same 16-bit operands (bar: a
+    16-bit rounding of the result + fp32 accumulation noise) and against the library call; more rows, gradients wanted
+    or fp32 storage stay on ``F.linear``."""
+    import MultiScaleDeformableAttention as MSDA
+    from mmfs_amd.functions.linear_func import small_linear
+    M, N, K = shape
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g).to(DEV, dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV, dtype)
+    b = torch.randn(N, generator=g).to(DEV, dtype) if with_bias else None
+    log = []
+    MSDA._event_log = log
+    try:
+        with torch.no_grad():
+            got = small_linear(x.view(1, M, K), w, b)
+    finally:
+        MSDA._event_log = None
+    assert [n for n, _, _ in log] == ["mmfs_linear_small"] and got.shape == (1, M, N) and got.dtype == dtype
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double() if with_bias else None)
+    lib = torch.nn.functional.linear(x, w, b)
+    scale = want.abs().clamp_min(1.0)
+    err = float(((got[0].double() - want).abs() / scale).max())
+    lib_err = float(((lib.double() - want).abs() / scale).max())
+    assert err <= max(tol, 1.5 * lib_err), (err, lib_err)
+    # not taken: more than 8 rows, a gradient wanted, fp32 storage
+    log2 = []
+    MSDA._event_log = log2
+    try:
+        with torch.no_grad():
+            small_linear(torch.cat((x, x, x))[:9] if M >= 3 else x.repeat(9, 1)[:9], w, b)
+            small_linear(x.float(), w.float(), b.float() if with_bias else None)
+        small_linear(x, w, b)
+    finally:
+        MSDA._event_log = None
+    assert log2 == []
