@@ -44,7 +44,9 @@ class FoldedLinear:
 
     def get(self, inner_w, inner_b, outer_w, outer_b):
         ps = tuple(t for t in (inner_w, inner_b, outer_w, outer_b) if t is not None)
-        sig = (torch.is_inference_mode_enabled(),) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps)
+        # (an operand made inside inference mode -- a kept tanh(gate) -- has no version counter: it cannot change either)
+        sig = (torch.is_inference_mode_enabled(),) + tuple(
+            (t.data_ptr(), -1 if t.is_inference() else t._version, t.dtype) for t in ps)
         if self._kept is not None and self._kept[0] == sig:
             return self._kept[1]
         dt = inner_w.dtype

@@ -627,3 +627,53 @@ def test_blocks_without_gradients_equal_blocks_with(oracle_op):
         got = layers[1](h, f, mask)
         assert layers[1]._gate_fold._kept is not None
     close(got, want.detach().numpy(), 1e-12)
+
+
+def test_llama_layer_in_inference_mode_then_no_grad_then_training(oracle_op):
+    """The folds and kept tensors of a layer's no-grad path under ``torch.inference_mode()`` (where the kept tanh(gate)
+    is an inference tensor: no version counter), then under ``no_grad``, then with gradients: the same output each time,
+    and a gate that moves in place afterwards is seen."""
+    layers = _llama_stack(1, seed=5)
+    l = layers[0]
+    h = torch.randn(2, 3, l.hidden_size, dtype=torch.float64)
+    f = torch.randn(2, 1, 84, 32, dtype=torch.float64)
+    mask = torch.ones(2, 3, 1, dtype=torch.float64)
+    with torch.no_grad():
+        l.gate.fill_(0.4)
+    with torch.inference_mode():
+        a = l(h, f, mask).clone()
+        a2 = l(h, f, mask)                                  # second call: everything kept
+        assert torch.equal(a, a2)
+    with torch.no_grad():
+        b = l(h, f, mask)
+    c = l(h, f, mask)
+    close(b, a.numpy(), 1e-12)
+    close(c.detach(), a.numpy(), 1e-12)
+    c.sum().backward()
+    assert l.gate.grad is not None and float(l.gate.grad.abs().sum()) > 0
+    with torch.no_grad():
+        l.gate.fill_(0.8)
+        d = l(h, f, mask)
+    assert float((d - b).abs().max()) > 1e-6
+    close(d, (l(h, f, mask)).detach().numpy(), 1e-12)
+
+
+def test_mmfs_net_in_inference_mode_then_training(oracle_op):
+    """The same for the image decoder's net: a first call inside ``torch.inference_mode()`` (kept projections, folded
+    convolutions, position tables made there) must not poison a later ``no_grad`` call or a training step."""
+    z = load_golden("block_sd_mmfs_net")
+    net = _tiny_net(z)
+    res = [T(z[f"res.{i}"]) for i in range(6)]
+    feats = [T(z[f"feat.{i}"]) for i in range(3)]
+    with torch.inference_mode():
+        a = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+        a = (a[0].clone(), [r.clone() for r in a[1]])
+    with torch.no_grad():
+        b = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    mid = T(z["mid"]).requires_grad_(True)
+    c = net(mid, res, feats, T(z["ms_mask"]))
+    c[0].sum().backward()
+    assert mid.grad is not None
+    for x, y, w in zip([a[0]] + a[1], [b[0]] + list(b[1]), [c[0]] + list(c[1])):
+        close(y, x.numpy(), 1e-11)
+        close(w.detach(), x.numpy(), 1e-11)
