@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions.norm_func import RMSNormFunction, rmsnorm_supported
-from ..levels import make_level_tables
+from ..levels import make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
 
 
@@ -128,7 +128,7 @@ class LlamaMMFSAttention(nn.Module):
         kept until the parameter moves."""
         if torch.is_grad_enabled():
             return self.gate.tanh()
-        sig = (self.gate.data_ptr(), self.gate._version, self.gate.dtype, torch.is_inference_mode_enabled())
+        sig = (self.gate.data_ptr(), tensor_version(self.gate), self.gate.dtype, torch.is_inference_mode_enabled())
         hit = getattr(self, "_gate_tanh", None)
         if hit is None or hit[0] != sig:
             hit = self._gate_tanh = (sig, self.gate.tanh())
@@ -144,7 +144,7 @@ class ProjectedBank:
         self.source, self.weights = source, weights      # identity cache: (tensor, version), parameter signature
 
     def matches(self, bank, weights):
-        return (self.source is not None and bank is self.source[0] and bank._version == self.source[1]
+        return (self.source is not None and bank is self.source[0] and tensor_version(bank) == self.source[1]
                 and weights == self.weights)
 
 
@@ -188,7 +188,7 @@ class LlamaMMFSSchedule:
                    and (l.attn.value_proj.bias is None) == (v0.bias is None) for l in self.layers)
 
     def _weights(self):
-        return tuple((p.data_ptr(), p._version) for l in self.layers
+        return tuple((p.data_ptr(), tensor_version(p)) for l in self.layers
                      for p in (l.norm2.weight, l.attn.value_proj.weight, l.attn.value_proj.bias) if p is not None)
 
     def _project(self, bank):
@@ -214,7 +214,7 @@ class LlamaMMFSSchedule:
         if keep and self._projected is not None and self._projected.matches(vision_hidden_states, sig):
             return self._projected
         proj = ProjectedBank(self._project(vision_hidden_states), vision_hidden_states,
-                             (vision_hidden_states, vision_hidden_states._version), sig)
+                             (vision_hidden_states, tensor_version(vision_hidden_states)), sig)
         self._projected = proj if keep else None
         return proj
 

@@ -20,7 +20,7 @@ from torch import nn
 
 from ..bank import gather_bank
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
-from ..levels import make_level_tables
+from ..levels import make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
 
 
@@ -115,7 +115,7 @@ class MMFSBlock(nn.Module):
         pe = self.pos_embed
         if pe.requires_grad:                      # someone is training it: stay in the graph
             return resize_pos_embed(pe, n_tokens)
-        key = (n_tokens, pe.data_ptr(), pe._version, pe.dtype, pe.device)
+        key = (n_tokens, pe.data_ptr(), tensor_version(pe), pe.dtype, pe.device)
         hit = self.__dict__.get("_pos_cache")
         if hit is None or hit[0] != key:
             # (kept across calls: a table made during an inference_mode() pass must still be usable
@@ -216,7 +216,7 @@ class ProjectedFeatures:
 
     def matches(self, feats, weights):
         return (self.sources is not None and len(feats) == len(self.sources) and weights == self.weights
-                and all(f is s and f._version == v for f, (s, v) in zip(feats, self.sources)))
+                and all(f is s and tensor_version(f) == v for f, (s, v) in zip(feats, self.sources)))
 
 
 class MMFSNet(nn.Module):
@@ -289,11 +289,11 @@ class MMFSNet(nn.Module):
             proj, ln = blk.mmfs.value_proj, blk.feat_norm
             bias = F.linear(ln.bias, proj.weight, proj.bias)
             values.append(F.linear(xhat, proj.weight * ln.weight, bias))
-        return ProjectedFeatures(values, bank, shapes, [(f, f._version) for f in mmfs_features],
+        return ProjectedFeatures(values, bank, shapes, [(f, tensor_version(f)) for f in mmfs_features],
                                  self._projection_weights())
 
     def _projection_weights(self):
-        return tuple((p.data_ptr(), p._version) for b in self._blocks()
+        return tuple((p.data_ptr(), tensor_version(p)) for b in self._blocks()
                      for p in (b.feat_norm.weight, b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias))
 
     @staticmethod

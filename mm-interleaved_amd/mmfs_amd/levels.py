@@ -44,3 +44,12 @@ def make_level_tables(shapes_per_image, n_images, device):
 def host_shapes(spatial_shapes):
     """Host copy of a level table if it was built here, else None (no sync is forced)."""
     return getattr(spatial_shapes, "_mmfs_host", None)
+
+
+def tensor_version(t):
+    """The in-place version counter of ``t`` for identity caches (kept projections of a feature bank), or -1 for a tensor
+    made inside ``torch.inference_mode()``: those have no counter (reading it raises).  Outside inference mode they
+    cannot be modified at all; inside it an in-place change goes unseen -- a caller who does that clears the cache
+    (``MMFSNet.clear_feature_cache`` / ``LlamaMMFSSchedule.clear_cache``)."""
+    return -1 if t.is_inference() else t._version
+

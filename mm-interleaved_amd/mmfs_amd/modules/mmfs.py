@@ -29,7 +29,7 @@ from torch import nn
 from ..functions import MSDeformAttnFunction
 from ..functions.linear_func import small_linear
 from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
-from ..levels import host_shapes
+from ..levels import host_shapes, tensor_version
 
 
 class FoldedLinear:
@@ -46,7 +46,7 @@ class FoldedLinear:
         ps = tuple(t for t in (inner_w, inner_b, outer_w, outer_b) if t is not None)
         # (an operand made inside inference mode -- a kept tanh(gate) -- has no version counter: it cannot change either)
         sig = (torch.is_inference_mode_enabled(),) + tuple(
-            (t.data_ptr(), -1 if t.is_inference() else t._version, t.dtype) for t in ps)
+            (t.data_ptr(), tensor_version(t), t.dtype) for t in ps)
         if self._kept is not None and self._kept[0] == sig:
             return self._kept[1]
         dt = inner_w.dtype
@@ -165,7 +165,7 @@ class MMFS(nn.Module):
                   self.attention_weights.weight, self.attention_weights.bias,
                   self.dynamic_offset_mask.weight, self.dynamic_offset_mask.bias)
             sig = (self.fold_query_projection,)
-            sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), t._version, t.dtype) for t in ps if t is not None)
+            sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), tensor_version(t), t.dtype) for t in ps if t is not None)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
         table = self.query_relpos.weight                                      # [max_img, d_query]

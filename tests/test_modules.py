@@ -677,3 +677,29 @@ def test_mmfs_net_in_inference_mode_then_training(oracle_op):
     for x, y, w in zip([a[0]] + a[1], [b[0]] + list(b[1]), [c[0]] + list(c[1])):
         close(y, x.numpy(), 1e-11)
         close(w.detach(), x.numpy(), 1e-11)
+
+
+def test_feature_tensors_made_in_inference_mode_are_accepted(oracle_op):
+    """A pipeline that runs wholly inside ``torch.inference_mode()`` hands over feature tensors that have no version
+    counter (reading it raises): the identity caches of the kept projections take them (same object = same bank), for
+    the image decoder's net and for the LLM-side schedule."""
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    z = load_golden("block_sd_mmfs_net")
+    net = _tiny_net(z)
+    layers = _llama_stack(2, seed=3)
+    with torch.inference_mode():
+        res = [T(z[f"res.{i}"]) * 1.0 for i in range(6)]               # inference tensors
+        feats = [T(z[f"feat.{i}"]) * 1.0 for i in range(3)]
+        assert feats[0].is_inference()
+        a = net(T(z["mid"]) * 1.0, res, feats, T(z["ms_mask"]))
+        kept = net.__dict__.get("_projected")
+        b = net(T(z["mid"]) * 1.0, res, feats, T(z["ms_mask"]))
+        assert kept is not None and net.__dict__.get("_projected") is kept      # the same feature objects: kept
+        assert torch.equal(a[0], b[0])
+        net(T(z["mid"]) * 1.0, res, [f.clone() for f in feats], T(z["ms_mask"]))
+        assert net.__dict__.get("_projected") is not kept                        # other objects: recomputed
+        sched = LlamaMMFSSchedule(layers)
+        bank = torch.randn(1, 1, 84, 32, dtype=torch.float64) * 1.0
+        p1 = sched.project(bank)
+        assert sched.project(bank) is p1 and sched.project(bank.clone()) is not p1
+
