@@ -821,3 +821,71 @@ def test_small_linear_kernel_matches_the_library(dtype, tol, shape, with_bias):
     finally:
         MSDA._event_log = None
     assert log2 == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_device_paths_inside_inference_mode(dtype):
+    """A pipeline wholly inside ``torch.inference_mode()``: inputs, features and everything the modules keep (tables,
+    folded weights, projected banks, tanh(gate)) are inference tensors there.  The LLM layer through its schedule
+    (decode-sized: the small-token Linear kernel, the fused sampler) and the image decoder's net give, bit for bit,
+    what the same calls give under ``no_grad`` -- twice (second call: everything kept) -- and a training step
+    afterwards still works."""
+    from mmfs_amd.blocks import LlamaMMFSAttention, LlamaMMFSSchedule, MMFSNet
+    cfg = types.SimpleNamespace(hidden_size=256, num_attention_heads=8, rms_norm_eps=1e-6,
+                                max_position_embeddings=2048, image_embed_dim=64, spatial_shapes=[8, 4])
+    torch.manual_seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        layers = [LlamaMMFSAttention(cfg, i).to(DEV, dtype) for i in range(2)]
+    with torch.no_grad():
+        for l in layers:
+            l.gate.fill_(0.6)
+            l.attn.sampling_offsets.weight.normal_(0, 0.02)
+    sched = LlamaMMFSSchedule(layers)
+    B, Lq, n, S = 4, 1, 2, 8 * 8 + 4 * 4
+    g = torch.Generator().manual_seed(3)
+    hidden = torch.randn(B, Lq, 256, generator=g).to(DEV, dtype)
+    feats = torch.randn(B, n, S, 64, generator=g).to(DEV, dtype)
+    mask = torch.ones(B, Lq, n, device=DEV)
+
+    def llm(h, f):
+        bank = sched.project(f)
+        ranks = sched.image_ranks(mask, Lq)
+        for k, l in enumerate(layers):
+            h = h + l(h, f, mask, value=bank.values[k], image_ranks=ranks)
+        return h
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=False,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV, dtype).eval()
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    mid = T(z["mid"], dtype)
+    res = [T(z[f"res.{i}"], dtype) for i in range(6)]
+    nfeats = [T(z[f"feat.{i}"], dtype) for i in range(3)]
+    nmask = T(z["ms_mask"], None)
+    with torch.inference_mode():
+        h_i, f_i = hidden * 1.0, feats * 1.0                          # inference tensors
+        assert f_i.is_inference()
+        a1 = llm(h_i, f_i).clone()
+        a2 = llm(h_i, f_i)
+        assert torch.equal(a1, a2)
+        nf_i = [f * 1.0 for f in nfeats]
+        s1 = net(mid * 1.0, [r * 1.0 for r in res], nf_i, nmask)
+        s2 = net(mid * 1.0, [r * 1.0 for r in res], nf_i, nmask)
+        assert torch.equal(s1[0], s2[0]) and all(torch.equal(x, y) for x, y in zip(s1[1], s2[1]))
+        s1 = (s1[0].clone(), [r.clone() for r in s1[1]])
+    with torch.no_grad():
+        b = llm(hidden, feats)
+        t = net(mid, res, nfeats, nmask)
+    assert torch.equal(a1, b)
+    assert torch.equal(s1[0], t[0]) and all(torch.equal(x, y) for x, y in zip(s1[1], t[1]))
+    h = hidden.clone().requires_grad_(True)                            # a training step after all that
+    llm(h, feats).float().sum().backward()
+    assert h.grad is not None and bool(torch.isfinite(h.grad).all())
+    m = mid.clone().requires_grad_(True)
+    net.train()
+    net(m, res, nfeats, nmask)[0].float().sum().backward()
+    assert m.grad is not None and bool(torch.isfinite(m.grad).all())
