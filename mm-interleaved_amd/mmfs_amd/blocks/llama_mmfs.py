@@ -109,10 +109,12 @@ class LlamaMMFSAttention(nn.Module):
         if value is None:
             vision_hidden_states = self.norm2(vision_hidden_states)
         ref, shapes, start = deform_inputs(hidden_states, vision_hidden_states, self.spatial_shapes)
-        if self.fold_gate and not torch.is_grad_enabled():
+        # (not under autocast: there ``out * tanh(gate)`` is a bf16 x fp32 product with an fp32 result, modeling_llama_mmfs.py:356)
+        proj = self.attn.output_proj
+        if (self.fold_gate and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and type(proj) is nn.Linear
+                and not proj._forward_hooks and not proj._forward_pre_hooks):
             # tanh(gate) * output_proj(x) = ((tanh(gate) W) x + tanh(gate) b): without gradients the gate rides in the
             # output projection's weights (kept until a parameter moves) -- one full-size multiply per layer less
-            proj = self.attn.output_proj
             folded = self._gate_fold.get(proj.weight, proj.bias, self._gate(), None)
             return self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                              input_spatial_shapes=shapes, input_level_start_index=start, input_padding_mask=None,

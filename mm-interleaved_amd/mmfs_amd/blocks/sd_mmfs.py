@@ -126,6 +126,14 @@ class MMFSBlock(nn.Module):
             self.__dict__["_pos_cache"] = hit
         return hit[1]
 
+    def _conv_is_pointwise(self):
+        """The block's convolution as the reference builds it (sd_mmfs.py:88-94: 1x1, stride 1, dense): a per-token
+        linear map.  Anything else a caller put there is called as the convolution it is."""
+        c = self.conv
+        return (type(c) is nn.Conv2d and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)
+                and c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros"
+                and not c._forward_hooks and not c._forward_pre_hooks)
+
     def _layout_kernels(self, sample):
         """Whether the two layout changes around the block run as one kernel each (csrc/mmfs_query.hip): a plain affine
         LayerNorm over the channels, one 16-bit storage type throughout, no autocast.  (With gradients the same kernels
@@ -137,7 +145,7 @@ class MMFSBlock(nn.Module):
         return (not torch.is_autocast_enabled() and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None
                 and tuple(n.normalized_shape) == (sample.shape[1],) and n.weight.dtype == sample.dtype
                 and n.bias.dtype == sample.dtype and self.pos_embed.dtype == sample.dtype
-                and self.conv.kernel_size == (1, 1) and layout_supported(sample))
+                and self._conv_is_pointwise() and layout_supported(sample))
 
     def _inner(self, sample, ms_feat, ms_feat_mask, spatial_shapes, value=None, image_ranks=None, residual=None, normed=None):
         B, C, H, W = sample.shape
@@ -161,10 +169,13 @@ class MMFSBlock(nn.Module):
             query = query + self._pos_table(H * W)
         # the zero-initialised 1x1 convolution follows the output projection with nothing non-linear between them: without
         # gradients the two are ONE GEMM on kept product weights (FoldedLinear; ``fold_conv = False``: two)
-        one_gemm = self.fold_conv and not torch.is_grad_enabled() and self.conv.kernel_size == (1, 1)
+        # (not under autocast: the two layers then round to the autocast type between them, as the reference's do)
+        proj = self.mmfs.output_proj
+        one_gemm = (self.fold_conv and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                    and self._conv_is_pointwise() and type(proj) is nn.Linear and not proj._forward_hooks
+                    and not proj._forward_pre_hooks)
         folded = None
         if one_gemm:
-            proj = self.mmfs.output_proj
             folded = self._conv_fold.get(proj.weight, proj.bias, self.conv.weight.view(C, C), self.conv.bias)
         out = self.mmfs(query, ref, self.feat_norm(ms_feat) if value is None else ms_feat, shapes, start,
                         input_padding_mask=None, attention_mask=ms_feat_mask, value=value, image_ranks=image_ranks,
@@ -172,7 +183,7 @@ class MMFSBlock(nn.Module):
         # the zero-initialised 1x1 convolution (sd_mmfs.py:88-94, 146) is a per-token linear map:
         # applied on the token-major tensor it is one GEMM each way (the convolution library's 1x1
         # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
-        if self.conv.kernel_size == (1, 1):
+        if self._conv_is_pointwise():
             if not one_gemm:
                 out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
             if fast and residual is not None and residual.shape == sample.shape and residual.dtype == out.dtype:

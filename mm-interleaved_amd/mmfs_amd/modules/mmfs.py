@@ -164,7 +164,7 @@ class MMFS(nn.Module):
             ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.sampling_offsets.bias,
                   self.attention_weights.weight, self.attention_weights.bias,
                   self.dynamic_offset_mask.weight, self.dynamic_offset_mask.bias)
-            sig = (self.fold_query_projection,)
+            sig = (self.fold_query_projection, torch.is_autocast_enabled())
             sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), tensor_version(t), t.dtype) for t in ps if t is not None)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
@@ -189,7 +189,8 @@ class MMFS(nn.Module):
             # (the intermediate is not rounded to 16 bits, the folded weights are): ``fold_query_projection = False``
             # keeps the two GEMMs.
             dom = self.dynamic_offset_mask
-            fold = stack and self.fold_query_projection and dom.weight.dtype == cat_w.dtype
+            fold = (stack and self.fold_query_projection and dom.weight.dtype == cat_w.dtype and not torch.is_autocast_enabled()
+                    and type(dom) is nn.Linear and not dom._forward_hooks and not dom._forward_pre_hooks)
             fold_w = fold_b = None
             if fold:
                 ft = torch.promote_types(cat_w.dtype, torch.float32)           # (fp32 for 16-bit storage)
