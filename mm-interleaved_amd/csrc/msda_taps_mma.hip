@@ -317,8 +317,10 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         }
     }
     }   // runs
-    // ---- the opening launch of the grad_value half, hosted here (one launch less per backward): the FIRST workgroup --
-    // done long before the kernel is -- clears the sort's cursors and plans it; its LDS is free by now
+    // ---- the opening launch of the grad_value half, hosted here (one launch less per backward): the FIRST workgroup
+    // clears the sort's cursors and plans it; its LDS is free by now.  (One workgroup per run: it is done long before the
+    // kernel is.  Persistent workgroups all end together and the plan is 4 us of one of them: a workgroup of its own
+    // for it measured no different, profiles/r03_experiments.md r03bm.)
     if (job.cursor_words > 0 && blockIdx.x == 0) {
         __syncthreads();
         blk::prepare_tail(job, smem);
