@@ -136,10 +136,12 @@ int mmfs_msda_forward_flags(int dtype,
  * device->host copy per backward to find out whether MMFS_BWD_CANONICAL_LEVELS holds.  The sorted
  * backward is taken and the table is checked ON THE DEVICE: any table whose levels do not overlap is
  * served (rows that belong to no level are zero-filled, like the reference's zero-initialised output).
- * Overlapping, out-of-range or >= 65536-wide levels cannot be served by the sorted backward: the call then
- * zero-fills grad_value (grad_loc / grad_attn are still exact) and ORs 1 into the caller's status word
- * (mmfs_msda_backward_checked; the HIP context stays usable -- a caller that builds such tables registers them
- * on the host and gets the float-atomic path, which serves any table as the reference does, cuh:128-155).
+ * Overlapping, out-of-range or >= 65536-wide levels cannot be served by the sorted backward: the SAME call then
+ * computes grad_value as the reference does, with float atomics into a zero-filled fp32 image and a cast
+ * (cuh:128-155, .cu:122-165; csrc/msda_bwd_refused.hip -- three launches that read the plan's verdict on the
+ * device and return at once for any table the sorted backward served), and ORs 1 into the caller's status word
+ * (mmfs_msda_backward_checked) so that the caller can learn it took the slow path.  The workspace of such a call
+ * is larger by that image for 16-bit storage (mmfs_msda_backward_workspace_bytes with this flag says how much).
  * Only mmfs_msda_backward_checked takes this flag. */
 #define MMFS_BWD_DEVICE_CHECKED_LEVELS 32u
 /* grad_loc / grad_attn have two formulations (tests, measurements; default: the library chooses):
@@ -208,9 +210,10 @@ int mmfs_msda_backward(int dtype,
 /*
  * The same backward for callers that pass MMFS_BWD_DEVICE_CHECKED_LEVELS: ``table_status`` points at an int32
  * the device can write (device memory or mapped host memory), owned and zero-initialised by the caller.  When
- * the device-side check finds a table the sorted backward cannot serve, the launch sequence completes without
- * touching anything it should not, grad_value is all zeros, and bit 0 of *table_status is set (the reference
- * would have accumulated overlapping levels with atomics: take MMFS_BWD_FORCE_ATOMIC, or no flag, for those).
+ * the device-side check finds a table the sorted backward cannot serve, the sorted launches find nothing to do,
+ * the float-atomic fallback at the end of the sequence computes grad_value as the reference does, and bit 0 of
+ * *table_status is set (information only: every output of the call is correct; MMFS_BWD_FORCE_ATOMIC, or no flag,
+ * takes the float-atomic path directly and faster).
  * Without the flag ``table_status`` is ignored (may be NULL) and the call is mmfs_msda_backward.
  */
 int mmfs_msda_backward_checked(int dtype,

@@ -207,15 +207,18 @@ def _launch(name, device, fn, *args):
 
 
 # ---- level tables the shim has never seen are checked ON THE DEVICE by the backward (no device->host copy per
-# call).  A table the sorted backward cannot serve (overlapping / out-of-range / >= 65536-wide levels) is reported
-# through this word -- one int32 of pinned, device-visible host memory per device, written by the plan kernel -- and
-# raised as a RuntimeError by the next call into the shim (or by check_level_table_status()): no device trap, the
-# HIP context stays usable.  The call that found the table has returned zeros for grad_value by then.
+# call).  A table the sorted backward cannot serve (overlapping / out-of-range / >= 65536-wide levels) gets the
+# reference's float-atomic scatter IN THE SAME CALL (csrc/msda_bwd_refused.hip: three launches that read the plan's
+# verdict on the device and return at once for every ordinary table), so grad_value is what the reference computes
+# either way.  The plan also reports such a table through this word -- one int32 of pinned, device-visible host
+# memory per device -- and the next call into the shim (or check_level_table_status()) turns it into ONE warning:
+# the fallback is slow, and a caller that builds such tables should register them.  No device trap, no exception.
 _status_words = {}
 _BAD_TABLE_MSG = ("ms_deform_attn_backward: an earlier call on this device was handed a level table with overlapping, "
-                  "out-of-range or >= 65536-wide levels that the shim had never seen; that call returned zeros for "
-                  "grad_value.  Register such tables (MultiScaleDeformableAttention.register_level_tables): they then "
-                  "take the float-atomic path, which serves any table as the reference does")
+                  "out-of-range or >= 65536-wide levels that the shim had never seen; its grad_value came from the "
+                  "float-atomic fallback (correct, as the reference computes it, but slow).  Register such tables "
+                  "(MultiScaleDeformableAttention.register_level_tables): they then take the float-atomic path directly")
+_bad_table_warned = False
 
 
 def _status_word(device):
@@ -228,16 +231,24 @@ def _status_word(device):
 
 
 def check_level_table_status(device=None, synchronize=False):
-    """Raises RuntimeError if a backward on ``device`` (default: every device used so far) met a level table the
-    device-side check refused.  ``synchronize=True`` waits for the device first (a test's use; the op itself
-    only looks at what has already arrived)."""
+    """True (and, once per process, a RuntimeWarning) if a backward on ``device`` (default: every device used so far)
+    met a level table the device-side check refused since the last time this was asked; the flag is consumed.
+    ``synchronize=True`` waits for the device first (a test's use; the op itself only looks at what has already
+    arrived).  The gradients of such a call are correct: it took the float-atomic fallback."""
+    global _bad_table_warned
     if synchronize:
         torch.cuda.synchronize(device)
     words = _status_words.values() if device is None else [_status_word(torch.device(device))]
+    seen = False
     for _, flag in words:
         if flag[0]:
             flag[0] = 0
-            raise RuntimeError(_BAD_TABLE_MSG)
+            seen = True
+    if seen and not _bad_table_warned:
+        _bad_table_warned = True
+        import warnings
+        warnings.warn(_BAD_TABLE_MSG, RuntimeWarning, stacklevel=2)
+    return seen
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,

@@ -1267,6 +1267,13 @@ int64_t bwd_value_block_workspace_bytes(int dtype, const Dims &d)
     return carve(nullptr, dtype, d).total;
 }
 
+// Where the plan's verdict on the level table lives (CellHeader::pad[2]: the device-side check refused it), for the
+// float-atomic fallback of msda_bwd_refused.hip.
+const int *value_table_refused_flag(void *workspace, int dtype, const Dims &d)
+{
+    return &carve(workspace, dtype, d).hdr->pad[2];
+}
+
 // (the workspace starts with the same three pieces as the pixel-stationary layout -- re-packed
 // loc, re-packed attn, level cursors -- so backward_value_prepare serves both)
 

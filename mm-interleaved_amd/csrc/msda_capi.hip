@@ -130,7 +130,13 @@ int64_t mmfs_msda_backward_workspace_bytes(int dtype, int64_t B, int64_t S, int6
 {
     mmfs::Dims d;
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
-    if (use_tiled(dtype, d, flags)) return mmfs::bwd_value_tiled_workspace_bytes(dtype, d);
+    if (use_tiled(dtype, d, flags)) {
+        const int64_t tiled = mmfs::bwd_value_tiled_workspace_bytes(dtype, d);
+        // a table nobody has looked at may be one the sorted backward refuses: room for the float-atomic fallback's
+        // fp32 image behind the sorted backward's pieces (msda_bwd_refused.hip)
+        if (!(flags & MMFS_BWD_CANONICAL_LEVELS)) return (tiled + 255) / 256 * 256 + mmfs::refused_table_scratch_bytes(dtype, d);
+        return tiled;
+    }
     // atomic path: 16-bit storage accumulates into an fp32 image of grad_value
     if (dtype == MMFS_F16 || dtype == MMFS_BF16) return B * S * H * D * 4;
     return 0;
@@ -188,21 +194,31 @@ int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shap
         return MMFS_E_ALIGN;
 
     if (use_tiled(dtype, d, flags)) {
-        if (!workspace || workspace_bytes < mmfs::bwd_value_tiled_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
-        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
         const bool canonical = (flags & MMFS_BWD_CANONICAL_LEVELS) != 0;
+        const int64_t tiled_bytes = mmfs::bwd_value_tiled_workspace_bytes(dtype, d);
+        const int64_t acc_off = (tiled_bytes + 255) / 256 * 256;
+        if (!workspace || workspace_bytes < (canonical ? tiled_bytes : acc_off + mmfs::refused_table_scratch_bytes(dtype, d)))
+            return MMFS_E_NULLPTR;
+        if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+        // a table the device-side check refuses gets the reference's float-atomic scatter IN THIS CALL (three launches
+        // that return at once otherwise): grad_value is right either way, the status word only says which path ran
+        auto finish = [&](hipError_t e) {
+            if (e != hipSuccess || canonical) return (int)e;
+            return (int)mmfs::backward_value_refused_table(dtype, shapes, start, loc, attn, grad_out, grad_value, workspace,
+                                                           reinterpret_cast<float *>((char *)workspace + acc_off), d, st);
+        };
         // (the grad_value half's opening launch hosted by the LDS-levels taps kernel where that one runs: msda_plan.h)
         mmfs::blk::PrepareJob job;
         if (mmfs::taps_mma_applies(dtype, d) && mmfs::value_prepare_job(dtype, loc, attn, shapes, start, workspace, d, &job)) {
             hipError_t e = mmfs::backward_taps_mma(dtype, value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, &job);
             if (e != hipSuccess) return (int)e;
-            return (int)mmfs::backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st, true, canonical);
+            return finish(mmfs::backward_value_run(dtype, shapes, start, grad_out, grad_value, workspace, d, st, true, canonical));
         }
         hipError_t e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out,
                                            nullptr, grad_loc, grad_attn, d, false, st);
         if (e != hipSuccess) return (int)e;
-        return (int)mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value,
-                                               workspace, d, st, canonical);
+        return finish(mmfs::backward_value_tiled(dtype, shapes, start, loc, attn, grad_out, grad_value,
+                                                 workspace, d, st, canonical));
     }
     // ---- float-atomic path
     const bool narrow = (dtype == MMFS_F16 || dtype == MMFS_BF16);

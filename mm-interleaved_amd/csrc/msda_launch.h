@@ -93,4 +93,12 @@ hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, c
 
 hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st);
 
+// grad_value for a level table the device-side check of the sorted backward refused (its plan's verdict is read on the
+// device from the workspace; nothing happens for a table it served): the reference's float-atomic scatter.
+// acc: refused_table_scratch_bytes of fp32 image for 16-bit storage (ignored for fp32).          [msda_bwd_refused.hip]
+int64_t refused_table_scratch_bytes(int dtype, const Dims &d);
+hipError_t backward_value_refused_table(int dtype, const int64_t *shapes, const int64_t *start, const void *loc,
+                                        const void *attn, const void *grad_out, void *grad_value, void *workspace,
+                                        float *acc, const Dims &d, hipStream_t st);
+
 }  // namespace mmfs

@@ -644,43 +644,58 @@ def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def test_unverified_overlapping_table_raises_and_the_context_survives():
-    """VERDICT r2 / ADVICE r2: a table nobody registered whose levels OVERLAP cannot be served by the sorted
-    backward (two levels would own the same grad_value rows).  It used to end in a device-side trap -- the whole HIP
-    context gone, asynchronously.  Now the plan reports it through a status word: that call's grad_value is all
-    zeros, the NEXT call into the shim (or check_level_table_status) raises a RuntimeError, and the context
-    keeps working.  Registered, the same table takes the float-atomic path and matches the oracle."""
-    import MultiScaleDeformableAttention as MSDA
-    g = torch.Generator().manual_seed(8)
+def _overlapping_case(dtype, seed=8):
+    g = torch.Generator().manual_seed(seed)
     B, H, D, Nq, P = 2, 4, 64, 40, 4
     shapes = torch.tensor([(4, 6), (3, 3)], dtype=torch.long)
     start = torch.tensor([0, 20], dtype=torch.long)            # level 1 starts inside level 0 (rows 20..23 shared)
     S = 29
-    rt = lambda t: t.to(torch.bfloat16).double()
-    x = dict(value=rt(torch.rand(B, S, H, D, generator=g)), shapes=shapes, start=start,
-             loc=rt(torch.rand(B, Nq, H, 2, P, 2, generator=g)), attn=rt(torch.rand(B, Nq, H, 2, P, generator=g)),
-             grad=rt(torch.randn(B, Nq, H * D, generator=g)))
-    dev = lambda t: t.to(DEV, torch.bfloat16) if t.is_floating_point() else t.to(DEV)
+    rt = (lambda t: t.to(dtype).double()) if dtype != torch.float32 else (lambda t: t.float().double())
+    return dict(value=rt(torch.rand(B, S, H, D, generator=g)), shapes=shapes, start=start,
+                loc=rt(torch.rand(B, Nq, H, 2, P, 2, generator=g) * 1.2 - 0.1), attn=rt(torch.rand(B, Nq, H, 2, P, generator=g)),
+                grad=rt(torch.randn(B, Nq, H * D, generator=g)))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_unverified_overlapping_table_is_served_by_the_atomic_fallback(dtype):
+    """VERDICT r2 / ADVICE r2: a table nobody registered whose levels OVERLAP cannot be served by the sorted
+    backward (two levels would own the same grad_value rows); it used to end in a device-side trap.  VERDICT r3 /
+    ADVICE r3: round 3's answer -- zeros for grad_value behind a call that reported success, an exception at the
+    NEXT call -- was a wrong result.  Now the same call ends with the reference's float-atomic scatter
+    (csrc/msda_bwd_refused.hip): every gradient matches the oracle, nothing raises, the shim warns once."""
+    import warnings
+    import MultiScaleDeformableAttention as MSDA
+    x = _overlapping_case(dtype)
+    dev = lambda t: t.to(DEV, dtype) if t.is_floating_point() else t.to(DEV)
     v, l, a, gr = dev(x["value"]), dev(x["loc"]), dev(x["attn"]), dev(x["grad"])
     sh, st = x["shapes"].to(DEV), x["start"].to(DEV)           # never registered
     MSDA.check_level_table_status(synchronize=True)             # (clean slate)
-    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, st, l, a, gr, 1)
-    with pytest.raises(RuntimeError, match="overlapping"):
-        MSDA.check_level_table_status(synchronize=True)
-    assert not gv.any()                                          # zero-filled, not garbage
+    MSDA._bad_table_warned = False
     want = run_oracle(x)
-    assert max_abs(gl.double().cpu().numpy(), want[2]) <= TOL[torch.bfloat16] * max(1.0, float(np.abs(want[2]).max()))
-    # the flag is consumed; the context is alive and the next calls are ordinary
-    MSDA.check_level_table_status(synchronize=True)
-    x2 = make_inputs(2, 4, 64, 50, 4, [(12, 9), (6, 5), (3, 3)], seed=31, dtype=torch.bfloat16)
-    check(run_hip(x2, torch.bfloat16), run_oracle(x2), torch.bfloat16, "after a refused table")
-    # a raised flag is also what the NEXT op call reports
-    MSDA.ms_deform_attn_backward(v, sh, st, l, a, gr, 1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for rep in range(2):                                    # (a recycled workspace must not remember the first verdict)
+            gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, st, l, a, gr, 1)
+            for name, got, ref in (("grad_value", gv, want[1]), ("grad_loc", gl, want[2]), ("grad_attn", ga, want[3])):
+                err = max_abs(got.double().cpu().numpy(), ref)
+                assert err <= TOL[dtype] * max(1.0, float(np.abs(ref).max())), (name, rep, err)
+        assert MSDA.check_level_table_status(synchronize=True) is True      # the slow path was taken ...
+        assert MSDA.check_level_table_status(synchronize=True) is False     # (the flag is consumed)
+    said = [m for m in w if "register_level_tables" in str(m.message)]
+    assert len(said) == 1 and said[0].category is RuntimeWarning            # ... and the shim says so, once
+    # an ordinary fresh table right after it, through the same (recycled) workspace: the fallback stays out of the way
+    x2 = make_inputs(2, 4, 64, 50, 4, [(12, 9), (6, 5), (3, 3)], seed=31, dtype=dtype)
+    check(run_hip(x2, dtype), run_oracle(x2), dtype, "after a refused table")
+    assert MSDA.check_level_table_status(synchronize=True) is False
+    # out-of-range: level 1 points past the end of value -- the reference would write out of bounds; here the rows
+    # that exist get their gradients, the others are skipped, nothing faults
+    st_bad = torch.tensor([0, 26], dtype=torch.long).to(DEV)
+    gv2, _, _ = MSDA.ms_deform_attn_backward(v, sh, st_bad, l, a, gr, 1)
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match="register_level_tables"):
-        MSDA.ms_deform_attn_forward(v, sh, st, l, a, 1)
-    # registered (the shim then knows it is not canonical): the float-atomic path serves it, as the reference does
-    check(run_hip(x, torch.bfloat16, use_autograd=False, register=True), want, torch.bfloat16, "overlapping, registered")
+    assert bool(torch.isfinite(gv2.float()).all())
+    assert MSDA.check_level_table_status(synchronize=True) is True
+    # registered (the shim then knows it is not canonical): the float-atomic path serves it directly
+    check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, "overlapping, registered")
 
 
 # ---------------------------------------------------------------------------------------------------------
