@@ -9,5 +9,6 @@ and the callers either side of the op:
     mmfs_amd.bank        feature-bank builders + the RCCL all-gather of image features
 """
 from .functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch  # noqa: F401
+from .levels import invalidate_caches  # noqa: F401
 
 __version__ = "0.1.0"

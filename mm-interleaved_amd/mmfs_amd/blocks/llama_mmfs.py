@@ -15,8 +15,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions.norm_func import RMSNormFunction, rmsnorm_supported
-from ..levels import make_level_tables, tensor_version
+from ..functions.norm_func import rmsnorm, rmsnorm_supported
+from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
 
 
@@ -33,7 +33,7 @@ class MMFSRMSNorm(nn.Module):
 
     def forward(self, x):
         if self.fused and rmsnorm_supported(x, self.weight):
-            return RMSNormFunction.apply(x, self.weight, self.variance_epsilon)
+            return rmsnorm(x, self.weight, self.variance_epsilon)
         var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
         x = x * torch.rsqrt(var + self.variance_epsilon)
         if self.weight.dtype in (torch.float16, torch.bfloat16):
@@ -66,7 +66,7 @@ def deform_inputs(hidden_states, vision_hidden_states, spatial_shapes=((16, 16),
     return centre_reference_points(hidden_states.size(1), hidden_states.device), shapes, start
 
 
-class LlamaMMFSAttention(nn.Module):
+class LlamaMMFSAttention(CacheInvalidation, nn.Module):
     def __init__(self, config, layer_idx):
         super().__init__()
         self.layer_idx = layer_idx
@@ -111,8 +111,8 @@ class LlamaMMFSAttention(nn.Module):
         ref, shapes, start = deform_inputs(hidden_states, vision_hidden_states, self.spatial_shapes)
         # (not under autocast: there ``out * tanh(gate)`` is a bf16 x fp32 product with an fp32 result, modeling_llama_mmfs.py:356)
         proj = self.attn.output_proj
-        if (self.fold_gate and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and type(proj) is nn.Linear
-                and not proj._forward_hooks and not proj._forward_pre_hooks):
+        if (self.fold_gate and not self.training and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and type(proj) is nn.Linear and hook_free(proj)):
             # tanh(gate) * output_proj(x) = ((tanh(gate) W) x + tanh(gate) b): without gradients the gate rides in the
             # output projection's weights (kept until a parameter moves) -- one full-size multiply per layer less
             folded = self._gate_fold.get(proj.weight, proj.bias, self._gate(), None)
@@ -128,9 +128,9 @@ class LlamaMMFSAttention(nn.Module):
     def _gate(self):
         """tanh(gate) (modeling_llama_mmfs.py:356): a one-element kernel per layer and step; without gradients it is
         kept until the parameter moves."""
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() or self.training:
             return self.gate.tanh()
-        sig = (self.gate.data_ptr(), tensor_version(self.gate), self.gate.dtype, torch.is_inference_mode_enabled())
+        sig = (cache_epoch(), self.gate.data_ptr(), tensor_version(self.gate), self.gate.dtype, torch.is_inference_mode_enabled())
         hit = getattr(self, "_gate_tanh", None)
         if hit is None or hit[0] != sig:
             hit = self._gate_tanh = (sig, self.gate.tanh())
@@ -190,8 +190,8 @@ class LlamaMMFSSchedule:
                    and (l.attn.value_proj.bias is None) == (v0.bias is None) for l in self.layers)
 
     def _weights(self):
-        return tuple((p.data_ptr(), tensor_version(p)) for l in self.layers
-                     for p in (l.norm2.weight, l.attn.value_proj.weight, l.attn.value_proj.bias) if p is not None)
+        return (cache_epoch(),) + tuple((p.data_ptr(), tensor_version(p)) for l in self.layers
+                                        for p in (l.norm2.weight, l.attn.value_proj.weight, l.attn.value_proj.bias) if p is not None)
 
     def _project(self, bank):
         norm = self.layers[0].norm2
@@ -211,7 +211,7 @@ class LlamaMMFSSchedule:
         if not self.can_fuse():         # the reference's schedule, layer by layer
             return ProjectedBank([l.attn.value_proj(l.norm2(vision_hidden_states)) for l in self.layers],
                                  vision_hidden_states)
-        keep = self.cache_projected_bank and not torch.is_grad_enabled()
+        keep = self.cache_projected_bank and not torch.is_grad_enabled() and not any(l.training for l in self.layers)
         sig = self._weights()
         if keep and self._projected is not None and self._projected.matches(vision_hidden_states, sig):
             return self._projected
@@ -221,4 +221,7 @@ class LlamaMMFSSchedule:
         return proj
 
     def clear_cache(self):
+        """Forget the projected bank -- and every fold / table the layers keep (``levels.invalidate_caches``)."""
         self._projected = None
+        for l in self.layers:
+            l.clear_caches()

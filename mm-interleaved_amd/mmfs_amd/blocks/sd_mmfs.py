@@ -20,7 +20,7 @@ from torch import nn
 
 from ..bank import gather_bank
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
-from ..levels import make_level_tables, tensor_version
+from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
 
 
@@ -81,7 +81,7 @@ def deform_inputs(sample, spatial_shapes=((8, 8),), n_images=1):
 
 
 # ------------------------------------------------------------------ blocks
-class MMFSBlock(nn.Module):
+class MMFSBlock(CacheInvalidation, nn.Module):
     layout_kernels_in_training = True
     fold_conv = True
 
@@ -115,7 +115,7 @@ class MMFSBlock(nn.Module):
         pe = self.pos_embed
         if pe.requires_grad:                      # someone is training it: stay in the graph
             return resize_pos_embed(pe, n_tokens)
-        key = (n_tokens, pe.data_ptr(), tensor_version(pe), pe.dtype, pe.device)
+        key = (cache_epoch(), n_tokens, pe.data_ptr(), tensor_version(pe), pe.dtype, pe.device)
         hit = self.__dict__.get("_pos_cache")
         if hit is None or hit[0] != key:
             # (kept across calls: a table made during an inference_mode() pass must still be usable
@@ -132,7 +132,7 @@ class MMFSBlock(nn.Module):
         c = self.conv
         return (type(c) is nn.Conv2d and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)
                 and c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros"
-                and not c._forward_hooks and not c._forward_pre_hooks)
+                and hook_free(c))
 
     def _layout_kernels(self, sample):
         """Whether the two layout changes around the block run as one kernel each (csrc/mmfs_query.hip): a plain affine
@@ -171,9 +171,8 @@ class MMFSBlock(nn.Module):
         # gradients the two are ONE GEMM on kept product weights (FoldedLinear; ``fold_conv = False``: two)
         # (not under autocast: the two layers then round to the autocast type between them, as the reference's do)
         proj = self.mmfs.output_proj
-        one_gemm = (self.fold_conv and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
-                    and self._conv_is_pointwise() and type(proj) is nn.Linear and not proj._forward_hooks
-                    and not proj._forward_pre_hooks)
+        one_gemm = (self.fold_conv and not self.training and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                    and self._conv_is_pointwise() and type(proj) is nn.Linear and hook_free(proj))
         folded = None
         if one_gemm:
             folded = self._conv_fold.get(proj.weight, proj.bias, self.conv.weight.view(C, C), self.conv.bias)
@@ -230,7 +229,7 @@ class ProjectedFeatures:
                 and all(f is s and tensor_version(f) == v for f, (s, v) in zip(feats, self.sources)))
 
 
-class MMFSNet(nn.Module):
+class MMFSNet(CacheInvalidation, nn.Module):
     # The 13 blocks read the SAME feature bank (sd_mmfs.py:247-270).  With ``fused_schedule`` the
     # bank is normalised once -- LayerNorm statistics do not depend on the block, only the affine
     # does, and that folds into the projection:
@@ -304,8 +303,8 @@ class MMFSNet(nn.Module):
                                  self._projection_weights())
 
     def _projection_weights(self):
-        return tuple((p.data_ptr(), tensor_version(p)) for b in self._blocks()
-                     for p in (b.feat_norm.weight, b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias))
+        return (cache_epoch(),) + tuple((p.data_ptr(), tensor_version(p)) for b in self._blocks()
+                                        for p in (b.feat_norm.weight, b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias))
 
     @staticmethod
     def _pack(mmfs_features):
@@ -319,7 +318,9 @@ class MMFSNet(nn.Module):
         return torch.cat([f.flatten(3).transpose(2, 3) for f in mmfs_features], dim=2)
 
     def clear_feature_cache(self):
+        """Forget the projected features -- and every fold / table the blocks keep (``levels.invalidate_caches``)."""
         self.__dict__.pop("_projected", None)
+        self.clear_caches()
 
     def forward(self, sample, down_block_res_samples, mmfs_features, mmfs_mask):
         """sample: mid-block input; down_block_res_samples: the UNet's down residuals;
@@ -334,14 +335,14 @@ class MMFSNet(nn.Module):
         # the reference does (the un-affined normalisation alone is shared: below).
         ckpt = self.training and torch.is_grad_enabled() and any(b.gradient_checkpointing for b in self._blocks())
         if proj is None and self.fused_schedule and self._can_fuse() and not ckpt:
-            keep = self.cache_projected_features and not torch.is_grad_enabled()
+            keep = self.cache_projected_features and not torch.is_grad_enabled() and not self.training
             proj = self.__dict__.get("_projected") if keep else None
             if proj is None or not proj.matches(mmfs_features, self._projection_weights()):
                 proj = self.project_features(mmfs_features)
             if keep:
                 self.__dict__["_projected"] = proj
             else:
-                self.clear_feature_cache()
+                self.__dict__.pop("_projected", None)
         normed = None
         if proj is not None:
             bank, shapes, values = proj.bank, proj.shapes, proj.values

@@ -42,23 +42,37 @@ def rmsnorm_supported(x, weight):
     return ok
 
 
+def _rmsnorm_launch(x, weight, eps, keep):
+    C = x.shape[-1]
+    xc = MSDA._aligned(x.contiguous())
+    wc = MSDA._aligned(weight.contiguous())
+    rows = xc.numel() // C if C else 0
+    y = torch.empty_like(xc)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if keep else None
+    with MSDA._on_device(x.device):
+        rc = MSDA._launch("mmfs_rmsnorm_fwd", x.device, _lib.mmfs_rmsnorm_forward, _CODE[x.dtype], xc.data_ptr(),
+                          wc.data_ptr(), y.data_ptr(), rstd.data_ptr() if keep else None, rows, C, float(eps),
+                          MSDA._stream(x.device))
+    MSDA._check(rc, "mmfs_rmsnorm_forward")
+    return y, xc, wc, rstd
+
+
+def rmsnorm(x, weight, eps):
+    """The kernel behind ``RMSNormFunction``.  Whether a backward will ever ask for the statistics is decided HERE:
+    inside ``Function.forward`` ``needs_input_grad`` says "yes" for a Parameter even under ``no_grad``, and
+    every decode / sampling step then allocated, wrote and saved ``rstd`` for nothing."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return RMSNormFunction.apply(x, weight, eps)
+    return _rmsnorm_launch(x, weight, eps, False)[0]
+
+
 class RMSNormFunction(Function):
     """(x [..., C], weight [C], eps) -> weight * round(x * rsqrt(mean(x^2, -1) + eps)), statistics in fp32."""
 
     @staticmethod
     def forward(ctx, x, weight, eps):
-        C = x.shape[-1]
-        xc = MSDA._aligned(x.contiguous())
-        wc = MSDA._aligned(weight.contiguous())
-        rows = xc.numel() // C if C else 0
-        y = torch.empty_like(xc)
         keep = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if keep else None
-        with MSDA._on_device(x.device):
-            rc = MSDA._launch("mmfs_rmsnorm_fwd", x.device, _lib.mmfs_rmsnorm_forward, _CODE[x.dtype], xc.data_ptr(),
-                              wc.data_ptr(), y.data_ptr(), rstd.data_ptr() if keep else None, rows, C, float(eps),
-                              MSDA._stream(x.device))
-        MSDA._check(rc, "mmfs_rmsnorm_forward")
+        y, xc, wc, rstd = _rmsnorm_launch(x, weight, eps, keep)
         if keep:
             ctx.save_for_backward(xc, wc, rstd)
         return y

@@ -25,6 +25,7 @@ class GraphedMMFSNet:
 
     def __init__(self, net, sample, down_block_res_samples, mmfs_features, mmfs_mask, warmup=2):
         assert isinstance(net, MMFSNet) and sample.is_cuda
+        assert not net.training, "GraphedMMFSNet is inference only: net.eval() first (nothing is folded or kept in training mode)"
         self.net = net
         with torch.no_grad():
             proj = mmfs_features if isinstance(mmfs_features, ProjectedFeatures) \
@@ -41,6 +42,11 @@ class GraphedMMFSNet:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._out = net(self._sample, self._res, proj, self._mask)
+            # The recorded kernels read the blocks' kept artefacts (folded weights, parameter-only tables, position
+            # tables) at the addresses they had during the capture: hold them, so that an invalidation of the modules'
+            # caches (a mode change, a state-dict load, ``invalidate_caches()``) cannot free what the graph replays.
+            # A graph bakes the parameters of its capture in: re-capture after they change.
+            self._pinned = [(b.mmfs._tables, b._conv_fold._kept, b.__dict__.get("_pos_cache")) for b in net._blocks()]
 
     @torch.no_grad()
     def __call__(self, sample, down_block_res_samples):
@@ -66,6 +72,8 @@ class GraphedLlamaMMFSStack:
     def __init__(self, layers, hidden, vision_hidden_states, cross_attention_mask, warmup=2):
         assert hidden.is_cuda
         self.layers = list(layers)
+        assert not any(l.training for l in self.layers), \
+            "GraphedLlamaMMFSStack is inference only: layer.eval() first (nothing is folded or kept in training mode)"
         with torch.no_grad():
             bank = vision_hidden_states if isinstance(vision_hidden_states, ProjectedBank) \
                 else LlamaMMFSSchedule(self.layers).project(vision_hidden_states)
@@ -82,6 +90,8 @@ class GraphedLlamaMMFSStack:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._out = self._run()
+            # (as GraphedMMFSNet: what the recorded kernels read stays alive with the graph)
+            self._pinned = [(l.attn._tables, l._gate_fold._kept, getattr(l, "_gate_tanh", None)) for l in self.layers]
 
     def _run(self):
         h = self._hidden

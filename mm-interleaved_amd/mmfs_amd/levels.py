@@ -53,3 +53,58 @@ def tensor_version(t):
     (``MMFSNet.clear_feature_cache`` / ``LlamaMMFSSchedule.clear_cache``)."""
     return -1 if t.is_inference() else t._version
 
+
+
+# ---- kept no-grad artefacts (folded weights, parameter-only tables, projected banks) ------------------------------
+# They are keyed on (data pointer, version counter) of the parameters they were made from -- and an in-place write
+# through ``param.data`` (DeepSpeed's bit16 update into its flat buffer, ``EMAModel.copy_to``, a checkpoint loaded
+# with ``param.data.copy_``) moves neither (ADVICE r3).  So every cache signature also carries this EPOCH, which
+# moves whenever one of this package's modules changes mode (``train()`` / ``eval()``: DeepSpeed's periodic
+# evaluation does), loads a state dict, or is told to (``clear_caches()`` on the modules, ``invalidate_caches()``
+# here); and nothing is kept while a module is in training mode.  What is left to the caller: parameters written
+# through ``.data`` while the modules STAY in eval mode -- call ``mmfs_amd.invalidate_caches()`` after such a write
+# (INTEGRATION.md 3).
+_epoch = 0
+
+
+def cache_epoch():
+    return _epoch
+
+
+def invalidate_caches():
+    """Forget every kept fold / table / projected bank of every mmfs_amd module (they are rebuilt on the next no-grad
+    call).  Cheap: one counter."""
+    global _epoch
+    _epoch += 1
+
+
+class CacheInvalidation:
+    """Mixin for the modules that keep something: mode changes and state-dict loads move the epoch."""
+
+    def train(self, mode=True):
+        invalidate_caches()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        invalidate_caches()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def clear_caches(self):
+        """Public invalidation (also ``mmfs_amd.invalidate_caches()``): call after writing parameters through ``.data``
+        in eval mode."""
+        invalidate_caches()
+
+
+def hook_free(layer):
+    """No hook of any kind could observe a call of ``layer``: only then may a no-grad path evaluate the layer's
+    mathematics without calling the module (folded weights, the small-token Linear kernel).  Forward AND backward
+    hooks, the layer's own and the process-wide ones (profilers, activation capture) -- ADVICE r3."""
+    from torch.nn.modules import module as _m
+    if (layer._forward_hooks or layer._forward_pre_hooks or layer._backward_hooks
+            or getattr(layer, "_backward_pre_hooks", None)):
+        return False
+    for name in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks",
+                 "_global_backward_pre_hooks"):
+        if getattr(_m, name, None):
+            return False
+    return True

@@ -29,14 +29,16 @@ from torch import nn
 from ..functions import MSDeformAttnFunction
 from ..functions.linear_func import small_linear
 from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
-from ..levels import host_shapes, tensor_version
+from ..levels import CacheInvalidation, cache_epoch, hook_free, host_shapes, tensor_version
 
 
 class FoldedLinear:
     """``outer(inner(x))`` of two Linear layers with nothing non-linear between them as ONE Linear layer, for calls that
     want no gradients: W = W_outer W_inner, b = W_outer b_inner + b_outer (``outer`` may also be a scalar tensor: a gate).
     Formed once in fp32 (fp64 for fp64 parameters), rounded once to the storage type, kept until one of the parameters
-    moves (data pointer + version counter, as ``MMFS._plan_tables``); made in inference mode it is not used outside it.
+    moves (data pointer + version counter, as ``MMFS._plan_tables``) or the package's cache epoch does (mode changes,
+    state-dict loads, ``clear_caches()``: ``levels.invalidate_caches`` -- writes through ``.data`` move no counter); made
+    in inference mode it is not used outside it.
     Same mathematics as the two layers, other rounding points: the intermediate is not rounded, the product is."""
 
     def __init__(self):
@@ -45,7 +47,7 @@ class FoldedLinear:
     def get(self, inner_w, inner_b, outer_w, outer_b):
         ps = tuple(t for t in (inner_w, inner_b, outer_w, outer_b) if t is not None)
         # (an operand made inside inference mode -- a kept tanh(gate) -- has no version counter: it cannot change either)
-        sig = (torch.is_inference_mode_enabled(),) + tuple(
+        sig = (cache_epoch(), torch.is_inference_mode_enabled()) + tuple(
             (t.data_ptr(), tensor_version(t), t.dtype) for t in ps)
         if self._kept is not None and self._kept[0] == sig:
             return self._kept[1]
@@ -67,7 +69,7 @@ class FoldedLinear:
         return res
 
 
-class MMFS(nn.Module):
+class MMFS(CacheInvalidation, nn.Module):
     def __init__(
         self,
         layer_idx=0,
@@ -158,13 +160,14 @@ class MMFS(nn.Module):
         itself.  With gradients they are part of the graph and made per call (mmfs.py:174-176 evaluates them inside
         head(q + table[relpos])); without (sampling, decoding) they are kept until a parameter moves -- three of a
         layer's six small GEMMs and two weight-slicing copies per decode step."""
-        keep = not torch.is_grad_enabled()
+        # (kept in eval mode only: a training run updates parameters in ways no counter sees -- levels.invalidate_caches)
+        keep = not torch.is_grad_enabled() and not self.training
         sig = None
         if keep:
             ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.sampling_offsets.bias,
                   self.attention_weights.weight, self.attention_weights.bias,
                   self.dynamic_offset_mask.weight, self.dynamic_offset_mask.bias)
-            sig = (self.fold_query_projection, torch.is_autocast_enabled())
+            sig = (cache_epoch(), self.fold_query_projection, torch.is_autocast_enabled())
             sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), tensor_version(t), t.dtype) for t in ps if t is not None)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
@@ -190,7 +193,7 @@ class MMFS(nn.Module):
             # keeps the two GEMMs.
             dom = self.dynamic_offset_mask
             fold = (stack and self.fold_query_projection and dom.weight.dtype == cat_w.dtype and not torch.is_autocast_enabled()
-                    and type(dom) is nn.Linear and not dom._forward_hooks and not dom._forward_pre_hooks)
+                    and type(dom) is nn.Linear and hook_free(dom))
             fold_w = fold_b = None
             if fold:
                 ft = torch.promote_types(cat_w.dtype, torch.float32)           # (fp32 for 16-bit storage)
@@ -286,8 +289,8 @@ class MMFS(nn.Module):
         weight-streaming kernel (functions/linear_func.py)."""
         if output_weights is None:
             proj = self.output_proj
-            if type(proj) is not nn.Linear or proj._forward_hooks or proj._forward_pre_hooks:
-                return proj(out)                  # (someone wrapped or hooked the layer: it is theirs to call)
+            if torch.is_grad_enabled() or type(proj) is not nn.Linear or not hook_free(proj):
+                return proj(out)                  # (with gradients, or wrapped / hooked: the layer is called as a layer)
             output_weights = (proj.weight, proj.bias)
         return small_linear(out, *output_weights)
 

@@ -474,6 +474,8 @@ def test_llama_schedule_keeps_the_projected_bank_only_while_nothing_moves():
     projections are kept for the same, unmodified bank tensor and parameters; anything else recomputes."""
     from mmfs_amd.blocks import LlamaMMFSSchedule
     layers = _llama_stack(2, seed=3)
+    for l in layers:
+        l.eval()                                                           # (nothing is kept in training mode: ADVICE r3)
     sched = LlamaMMFSSchedule(layers)
     feats = torch.randn(1, 1, 84, 32, dtype=torch.float64)
     with torch.no_grad():
@@ -499,6 +501,8 @@ def test_decode_caches_follow_the_parameters_and_the_mask(oracle_op):
     nothing is kept); a parameter that moves in place is seen."""
     from mmfs_amd.blocks import LlamaMMFSSchedule
     layers = _llama_stack(2, seed=5)
+    for l in layers:
+        l.eval()
     g = torch.Generator().manual_seed(2)
     B, Lq, n, hw = 2, 3, 2, 64 + 16 + 4
     hidden = torch.randn(B, Lq, 64, generator=g, dtype=torch.float64)
@@ -547,7 +551,7 @@ def test_folded_query_projection_is_the_two_gemms():
     torch.manual_seed(4)
     with contextlib.redirect_stdout(io.StringIO()):
         m = MMFS(d_model=32, d_query=24, d_value=16, d_out=24, n_levels=2, n_heads=4, n_points=4, ratio=1.0,
-                 spatial_shapes=[8, 4], base_spatial_shape=4, max_num_image_per_seq=6).double()
+                 spatial_shapes=[8, 4], base_spatial_shape=4, max_num_image_per_seq=6).double().eval()
     with torch.no_grad():
         m.sampling_offsets.weight.normal_(0, 0.1)
         m.attention_weights.weight.normal_(0, 0.1)
@@ -605,7 +609,7 @@ def test_blocks_without_gradients_equal_blocks_with(oracle_op):
     """The folds the blocks take when no gradient is wanted (conv into output_proj, gate into output_proj) against the
     same call with gradients enabled (nothing folded): fp64, to rounding."""
     z = load_golden("block_sd_mmfs_net")
-    net = _tiny_net(z)
+    net = _tiny_net(z).eval()
     res = [T(z[f"res.{i}"]) for i in range(6)]
     feats = [T(z[f"feat.{i}"]) for i in range(3)]
     a = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
@@ -615,7 +619,7 @@ def test_blocks_without_gradients_equal_blocks_with(oracle_op):
     close(b[0], a[0].detach().numpy(), 1e-11)
     for x, y in zip(b[1], a[1]):
         close(x, y.detach().numpy(), 1e-11)
-    layers = _llama_stack(2, seed=3)
+    layers = [l.eval() for l in _llama_stack(2, seed=3)]
     h = torch.randn(2, 5, layers[0].hidden_size, dtype=torch.float64)
     f = torch.randn(2, 1, 84, 32, dtype=torch.float64)
     mask = torch.ones(2, 5, 1, dtype=torch.float64)
@@ -685,8 +689,8 @@ def test_feature_tensors_made_in_inference_mode_are_accepted(oracle_op):
     the image decoder's net and for the LLM-side schedule."""
     from mmfs_amd.blocks import LlamaMMFSSchedule
     z = load_golden("block_sd_mmfs_net")
-    net = _tiny_net(z)
-    layers = _llama_stack(2, seed=3)
+    net = _tiny_net(z).eval()
+    layers = [l.eval() for l in _llama_stack(2, seed=3)]
     with torch.inference_mode():
         res = [T(z[f"res.{i}"]) * 1.0 for i in range(6)]               # inference tensors
         feats = [T(z[f"feat.{i}"]) * 1.0 for i in range(3)]
@@ -703,3 +707,120 @@ def test_feature_tensors_made_in_inference_mode_are_accepted(oracle_op):
         p1 = sched.project(bank)
         assert sched.project(bank) is p1 and sched.project(bank.clone()) is not p1
 
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the kept no-grad artefacts were keyed on (data pointer, version counter) of their parameters
+# only, and a write through ``param.data`` moves neither -- DeepSpeed's bit16 update, EMAModel.copy_to.
+def test_kept_folds_do_not_survive_a_mode_change_a_state_dict_load_or_an_invalidation(oracle_op):
+    """The advisor's reproduction, and the three ways out: (1) nothing is kept in training mode, and train() / eval()
+    drop whatever was kept before (DeepSpeed's periodic evaluation switches modes around every update); (2) loading a
+    state dict drops it; (3) ``clear_caches()`` / ``mmfs_amd.invalidate_caches()`` for writes through ``.data`` while
+    the modules stay in eval mode.  After each, the no-grad output is the with-grad (nothing kept) output."""
+    import mmfs_amd
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    layers = [l.eval() for l in _llama_stack(2, seed=7)]
+    l = layers[0]
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(2, 4, l.hidden_size, generator=g, dtype=torch.float64)
+    f = torch.randn(2, 2, 84, 32, generator=g, dtype=torch.float64)
+    mask = torch.ones(2, 4, 2, dtype=torch.float64)
+
+    def nograd():
+        with torch.no_grad():
+            return l(h, f, mask)
+
+    def truth():
+        return l(h, f, mask).detach()                                     # with gradients nothing is kept or folded
+
+    a = nograd()
+    close(a, truth().numpy(), 1e-12)
+    assert l._gate_fold._kept is not None and l.attn._tables is not None          # (the folds were taken)
+    # --- the hazard itself: a write through .data is invisible to the counters ...
+    l.gate.data.fill_(1.0)
+    l.attn.query_relpos.weight.data.mul_(-2.0)
+    l.attn.output_proj.weight.data.mul_(0.5)
+    stale = nograd()
+    assert float((stale - truth()).abs().max()) > 1e-3                    # ... and eval-mode folds DO go stale (documented)
+    # (3) the public invalidation
+    l.clear_caches()
+    close(nograd(), truth().numpy(), 1e-12)
+    l.gate.data.fill_(0.3)
+    mmfs_amd.invalidate_caches()
+    close(nograd(), truth().numpy(), 1e-12)
+    # (1) a training step between two evaluations, parameters updated through .data as DeepSpeed does
+    l.train()
+    l.gate.data.fill_(-0.8)
+    l.attn.dynamic_offset_mask.weight.data.mul_(1.5)
+    in_train = nograd()                                                   # no_grad inside training mode: nothing kept
+    close(in_train, truth().numpy(), 1e-12)
+    l.eval()
+    close(nograd(), truth().numpy(), 1e-12)
+    l.train(); l.attn.sampling_offsets.bias.data.add_(0.25); l.eval()
+    close(nograd(), truth().numpy(), 1e-12)
+    # (2) a state dict loaded in eval mode (load_state_dict copies under no_grad; here through .data to be sure)
+    sd = {k: v.clone() * 0.5 for k, v in l.state_dict().items()}
+    nograd()
+    l.load_state_dict(sd)
+    close(nograd(), truth().numpy(), 1e-12)
+    # the schedule's projected bank and the image decoder's net follow the same rule
+    sched = LlamaMMFSSchedule(layers)
+    with torch.no_grad():
+        p1 = sched.project(f)
+        assert sched.project(f) is p1
+        layers[1].attn.value_proj.weight.data.mul_(2.0)
+        assert sched.project(f) is p1                                     # (the hazard)
+        sched.clear_cache()
+        p2 = sched.project(f)
+        assert p2 is not p1 and not torch.equal(p2.values[1], p1.values[1])
+        layers[1].train(); layers[1].eval()
+        assert sched.project(f) is not p2
+    z = load_golden("block_sd_mmfs_net")
+    net = _tiny_net(z).eval()
+    res = [T(z[f"res.{i}"]) for i in range(6)]
+    feats = [T(z[f"feat.{i}"]) for i in range(3)]
+    with torch.no_grad():
+        net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+        assert net.__dict__.get("_projected") is not None
+        net.mmfs_mid_block.conv.weight.data.mul_(3.0)
+        net.mmfs_mid_block.mmfs.value_proj.weight.data.mul_(0.5)
+        net.clear_feature_cache()
+        b = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    want = net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    close(b[0], want[0].detach().numpy(), 1e-11)
+    net.train()
+    with torch.no_grad():
+        net(T(z["mid"]), res, feats, T(z["ms_mask"]))
+    assert net.__dict__.get("_projected") is None                         # nothing kept in training mode
+    kept = net.mmfs_mid_block._conv_fold._kept
+    assert kept is None or kept[0][0] != mmfs_amd.levels.cache_epoch()    # ... and the fold of the eval pass is out of date
+
+
+def test_hooked_layers_are_called_as_layers(oracle_op):
+    """the no-grad paths evaluate ``output_proj`` / ``dynamic_offset_mask`` / the 1x1 convolution
+    without calling the modules only when NO hook could observe the call -- forward or backward, the layer's own or a
+    process-wide one -- and never with gradients enabled."""
+    from mmfs_amd.levels import hook_free
+    layers = [l.eval() for l in _llama_stack(1, seed=2)]
+    l = layers[0]
+    h = torch.randn(1, 3, l.hidden_size, dtype=torch.float64)
+    f = torch.randn(1, 1, 84, 32, dtype=torch.float64)
+    mask = torch.ones(1, 3, 1, dtype=torch.float64)
+    proj = l.attn.output_proj
+    assert hook_free(proj)
+    seen = []
+    hb = proj.register_full_backward_hook(lambda m, gi, go: seen.append("bwd"))
+    assert not hook_free(proj)
+    out = l(h.requires_grad_(True), f, mask)
+    out.sum().backward()
+    assert seen == ["bwd"]                                                # with gradients the layer is called as a layer
+    hb.remove()
+    hg = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: seen.append(type(m).__name__) if m is proj else None)
+    try:
+        assert not hook_free(proj)
+        with torch.no_grad():
+            l(h.detach(), f, mask)
+        assert "Linear" in seen                                           # a global hook sees output_proj's call
+    finally:
+        hg.remove()
+    assert hook_free(proj)

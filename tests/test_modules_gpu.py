@@ -574,7 +574,7 @@ def test_llama_layer_with_the_fused_norm_and_schedule_matches_the_layerwise_path
                                  max_position_embeddings=64, image_embed_dim=128, spatial_shapes=[8, 4, 2])
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        layers = [LlamaMMFSAttention(cfg, 4 * i).to(DEV, torch.bfloat16) for i in range(3)]
+        layers = [LlamaMMFSAttention(cfg, 4 * i).to(DEV, torch.bfloat16).eval() for i in range(3)]      # (eval: the no-grad folds are taken)
     with torch.no_grad():
         for l in layers:
             l.gate.fill_(0.7)
@@ -836,7 +836,7 @@ def test_device_paths_inside_inference_mode(dtype):
                                 max_position_embeddings=2048, image_embed_dim=64, spatial_shapes=[8, 4])
     torch.manual_seed(2)
     with contextlib.redirect_stdout(io.StringIO()):
-        layers = [LlamaMMFSAttention(cfg, i).to(DEV, dtype) for i in range(2)]
+        layers = [LlamaMMFSAttention(cfg, i).to(DEV, dtype).eval() for i in range(2)]
     with torch.no_grad():
         for l in layers:
             l.gate.fill_(0.6)

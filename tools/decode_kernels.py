@@ -12,7 +12,7 @@ cfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, rms_norm_e
                             max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
-    layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt) for i in range(8)]
+    layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt).eval() for i in range(8)]
 B, n, S, Lq = 4, 1, 1344, int(sys.argv[1]) if len(sys.argv) > 1 else 1
 feats = torch.randn(B, n, S, 1024, device=dev, dtype=dt)
 hidden = torch.randn(B, Lq, 4096, device=dev, dtype=dt)

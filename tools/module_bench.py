@@ -140,6 +140,8 @@ def cfg3():
                 x = x + l(x, feats, mask, value=bank.values[k])
             x.backward(torch.ones_like(x))
 
+        for l in layers:
+            l.eval()
         graphed = GraphedLlamaMMFSStack(layers, hidden, feats, mask)
         cases = [("forward", fwd, False), ("forward, shared normalisation + batched value projection", lambda: fwd_sched(False), False),
                  ("forward, projected bank kept across calls (decode / generation)", lambda: fwd_sched(True), False),
@@ -148,6 +150,8 @@ def cfg3():
         for label, fn, bwd in cases:
             if bwd and Lq == 1:
                 continue
+            for l in layers:            # (no-grad lines in eval mode -- folds and kept tables --, training lines in training mode)
+                l.train(bwd)
             ms = timed(fn)
             fam, launches = split(fn)
             flops = 8 * mmfs_linear_flops(B * Lq, B * n * S, 4096, 1024, 1024, 4096, 16, 3, 8, 50) * (3 if bwd else 1)
