@@ -66,6 +66,9 @@ WORKLOADS = {
                          shapes=[(64, 64), (32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
     "cfg5_llm_n4": dict(B=4, Nq=2048, H=16, D=64, P=8,
                         shapes=[(32, 32), (16, 16), (8, 8)], n=4, dtype="bf16"),
+    # BASELINE config 3's op: one image per sequence, the LLM layer's geometry (modeling_llama_mmfs.py:326-339), 2048 tokens
+    "cfg3_llm_n1": dict(B=4, Nq=2048, H=16, D=64, P=8,
+                        shapes=[(32, 32), (16, 16), (8, 8)], n=1, dtype="bf16"),
     # the ViT-Adapter's encoder-side calls at 224 px (vit_adapter_hf.py:112-133,
     # adapter_modules.py:30-49: ViT-L, deform_ratio 0.5 -> D=32, P=4), 32 images per GPU: the injector
     # (256 ViT tokens sample the 32^2/16^2/8^2 pyramid) and the extractor (the 1344 pyramid tokens

@@ -108,6 +108,11 @@ int mmfs_msda_forward(int dtype,
  */
 #define MMFS_FWD_ROW_GATHER 1u
 #define MMFS_FWD_LDS_LEVELS 2u
+/*   slices       csrc/msda_fwd_q8.hip (round 4): 16-bit storage, head widths that are multiples of 32 channels, L <= 64.
+ *                A workgroup owns a 32-channel SLICE of one (batch, head); every level whose slice fits in LDS (32x32 +
+ *                16x16 + 8x8: 101 KB) is sampled by the matrix cores in tiles of 8 queries, the rest by row gather.
+ * MMFS_FWD_SLICES on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
+#define MMFS_FWD_SLICES 4u
 int mmfs_msda_forward_flags(int dtype,
                             const void *value, const int64_t *shapes, const int64_t *start,
                             const void *loc, const void *attn, void *out,

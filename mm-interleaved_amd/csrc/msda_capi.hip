@@ -103,7 +103,8 @@ int mmfs_msda_forward_flags(int dtype, const void *value, const int64_t *shapes,
     if (misaligned(value, al) || misaligned(out, al) || misaligned(loc, es) || misaligned(attn, es))
         return MMFS_E_ALIGN;
     if ((flags & MMFS_FWD_LDS_LEVELS) && !mmfs::fwd_mma_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
-    const int algo = (flags & MMFS_FWD_LDS_LEVELS) ? 2 : (flags & MMFS_FWD_ROW_GATHER) ? 1 : 0;
+    if ((flags & MMFS_FWD_SLICES) && !mmfs::fwd_q8_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    const int algo = (flags & MMFS_FWD_SLICES) ? 3 : (flags & MMFS_FWD_LDS_LEVELS) ? 2 : (flags & MMFS_FWD_ROW_GATHER) ? 1 : 0;
     return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st, algo);
 }
 

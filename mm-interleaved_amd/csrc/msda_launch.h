@@ -10,7 +10,7 @@ namespace mmfs {
 
 // dtype codes are enum mmfs_dtype of include/mmfs_msda.h
 // algo: 0 the library chooses, 1 row gather (msda_fwd.hip), 2 LDS-resident levels (msda_fwd_mma.hip; the
-// caller has checked fwd_mma_supported)
+// caller has checked fwd_mma_supported), 3 slices of 32 channels (msda_fwd_q8.hip; fwd_q8_supported)
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st, int algo = 0);
 
@@ -20,6 +20,13 @@ bool fwd_mma_supported(int dtype, const Dims &d);        // the shape allows it
 bool fwd_mma_applies(int dtype, const Dims &d);          // ... and it is expected to pay (the default routing)
 hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                        const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
+
+// Third formulation of the forward for 16-bit storage, head widths that are multiples of 32 channels: slices of 32
+// channels, every level whose slice fits in LDS sampled by the matrix cores in tiles of 8 queries.  [msda_fwd_q8.hip]
+bool fwd_q8_supported(int dtype, const Dims &d);
+bool fwd_q8_applies(int dtype, const Dims &d);
+hipError_t forward_q8(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                      const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
 
 // Location / attention-weight gradients (always) and, when scatter is true, grad_value
 // accumulated with global float atomics into the fp32 (fp64 for dtype 3) buffer gv_acc,

@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): fp32 <= 1e-5, fp16 <= 1e-3 (bf16 reported with 
 same protocol: fp64 oracle on storage-rounded inputs)."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ from oracle import msda_oracle
 pytestmark = pytest.mark.gpu
 OP_GOLDENS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "op_*.npz")))
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # absolute tolerance on outputs whose magnitude is O(1); gradients use a relative bar
 TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}
@@ -593,6 +595,87 @@ def test_lds_levels_forward_non_finite_rows_stay_with_their_queries(D):
     same = ~want_bad
     same[9, 0] = False                                     # (the query with the zeroed weight sums to less)
     assert np.allclose(got[same], got[0, 0, 0]) and got[9, 0, 0] < got[0, 0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The forward's third formulation (csrc/msda_fwd_q8.hip, round 4): a workgroup owns a 32-channel SLICE of a (b, h); every
+# level whose slice fits in LDS is sampled by the matrix cores in tiles of 8 queries (one product per sample index of
+# the 8 queries and 16 channels, block-diagonal weights), the others by row gather inside the same kernel.
+SLICE_CASES = LDS_CASES + [
+    # B, H, D, Nq, P, shapes                                           what it exercises
+    (2, 16, 64, 130, 8, [(32, 32), (16, 16), (8, 8)]),                  # the LLM's real geometry, one image: everything resident, two slices
+    (1, 8, 128, 700, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),        # north star, four slices, two runs of 512 queries (the second ragged)
+    (2, 16, 32, 97, 4, [(32, 32), (16, 16), (8, 8)]),                   # the encoder's head width: ONE slice
+    (1, 3, 96, 45, 5, [(7, 9), (13, 4), (2, 2)]),                       # three slices; widths that need 1, 2, 3 pad pixels per line; P = 5
+    (1, 2, 256, 20, 2, [(6, 6), (3, 3)]),                               # eight slices
+    (1, 4, 64, 9, 8, [(33, 31), (40, 40), (16, 16)]),                   # 33 x 31 + 16 x 16 fit next to each other, 40 x 40 does not: mixed passes
+]
+
+
+@pytest.mark.parametrize("case", SLICE_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in SLICE_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sliced_forward_matches_oracle(case, dtype):
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=21, loc_range=(-0.15, 1.15), dtype=dtype)
+    x["loc"][0, 0, 0, 0, 0, 0] = float("nan")            # non-finite locations contribute nothing
+    x["loc"][0, Nq // 2, 1 % H, -1, 0, 1] = float("inf")
+    x["attn"][0, Nq - 1, 0, -1] = 0.0                     # zero weights read nothing
+    x["loc"][0, Nq // 3, 0, 0, -1] = torch.tensor([0.0, 1.0])            # a corner of the map: three of four corners outside
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    got = run_fwd(x, dtype, "slices")
+    scale = max(1.0, float(np.abs(want).max()))
+    assert max_abs(got, want) <= TOL[dtype] * scale, f"{case[:5]}: {max_abs(got, want):.3e}"
+    ref = run_fwd(x, dtype, "gather")
+    assert max_abs(got, ref) <= 0.5 * TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("kb", [60, 80, 130])
+def test_sliced_forward_with_less_lds_moves_levels_to_the_row_gather(kb, monkeypatch):
+    """Which levels are resident is decided on the device from the LDS the launch was given (MMFS_FWD_Q8_LDS_KB: a test
+    knob): with 60 KB none of the north-star pyramid's levels, with 80 KB 16x16 + 8x8, with 130 KB 32x32 too --
+    the same outputs to the rounding of the weights' hi + lo parts."""
+    x = make_inputs(1, 4, 128, 150, 4, [(64, 64), (32, 32), (16, 16), (8, 8)], seed=3, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    code = ("import os, sys, numpy as np, torch; sys.path[:0] = [%r, %r]; os.environ['MMFS_FWD_Q8_LDS_KB'] = '%d';"
+            "import MultiScaleDeformableAttention as MSDA; MSDA._fwd_algo = 'slices';"
+            "z = np.load(sys.argv[1]); dev = lambda a: torch.from_numpy(a).cuda();"
+            "f = lambda a: dev(a).to(torch.bfloat16);"
+            "o = MSDA.ms_deform_attn_forward(f(z['value']), dev(z['shapes']), dev(z['start']), f(z['loc']), f(z['attn']), 1);"
+            "np.save(sys.argv[2], o.double().cpu().numpy())") % (ROOT, os.path.join(ROOT, "mm-interleaved_amd"), kb)
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:              # (the knob is read once per process)
+        np.savez(os.path.join(td, "in.npz"), **{k: v.numpy() for k, v in x.items() if k != "grad"})
+        subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npy")], check=True)
+        got = np.load(os.path.join(td, "out.npy"))
+    assert max_abs(got, want) <= TOL[torch.bfloat16] * max(1.0, float(np.abs(want).max()))
+
+
+def test_sliced_forward_non_finite_rows_stay_inside_their_tile():
+    """A product of the sliced forward multiplies the rows of EIGHT queries with a block-diagonal weight tile: a
+    non-finite value row turns the zeros of the other queries' weights into NaN, so it reaches the queries of its
+    8-query tile (documented deviation: the reference, and the other two formulations, keep it with the queries that
+    sample it, cuh:58-81) -- and no query of another tile, no other head, and nothing at all through corners outside
+    the map, zero weights or samples that fail the range test."""
+    sh, start = level_tables([(4, 4), (2, 2)])
+    H, Nq, D = 2, 24, 64
+    value = torch.ones(1, 20, H, D, dtype=torch.float64)
+    value[0, 5, 0] = float("inf")                         # pixel (1, 1) of level 0, head 0
+    value[0, 16, 1] = float("nan")                        # pixel (0, 0) of level 1, head 1
+    loc = torch.full((1, Nq, H, 2, 2, 2), 0.875, dtype=torch.float64)
+    attn = torch.full((1, Nq, H, 2, 2), 0.25, dtype=torch.float64)
+    loc[0, 3, 0, 0, 0] = torch.tensor([0.375, 0.375])     # query 3, head 0 touches pixel (1, 1) of level 0
+    loc[0, 15, 1, 1, 1] = torch.tensor([0.25, 0.25])      # query 15, head 1 touches pixel (0, 0) of level 1
+    loc[0, 17, 0, 0, 1] = torch.tensor([0.375, 0.375]); attn[0, 17, 0, 0, 1] = 0.0    # zero weight: reads nothing
+    loc[0, 18, 0, 0, 1] = torch.tensor([0.375, 1.5])      # fails the range test: reads nothing
+    x = dict(value=value, shapes=sh, start=start, loc=loc, attn=attn)
+    got = run_fwd(x, torch.bfloat16, "slices").reshape(Nq, H, D)
+    bad = ~np.isfinite(got).all(-1)
+    assert bad[3, 0] and bad[15, 1]
+    allowed = np.zeros((Nq, H), dtype=bool)
+    allowed[0:8, 0] = True; allowed[8:16, 1] = True       # the tiles of queries 3 (head 0) and 15 (head 1)
+    assert not (bad & ~allowed).any(), np.argwhere(bad & ~allowed)
+    fine = got[~bad]
+    assert np.isfinite(fine).all()
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8192), (1, 16, 4096 * 3 + 77), (3, 4, 300)])
