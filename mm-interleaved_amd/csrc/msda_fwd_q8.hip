@@ -607,6 +607,13 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
     QPROF_FLUSH();
 }
 
+// The host sees no level table (device pointers only): "every level's slice fits in the image" is judged from S -- a
+// pyramid of S pixels takes S * 64 bytes plus its zero borders (32x32 + 16x16 + 8x8: 86 KB of pixels, 101 KB with them).
+static bool q8_all_resident_likely(const Dims &d)
+{
+    return (int64_t)d.S * q8::kRB * 5 / 4 <= (int64_t)(kLdsTotal - q8::kImg0);
+}
+
 // ---------------------------------------------------------------- launcher
 template <typename T>
 static hipError_t launch_q8(const void *value, const int64_t *shapes, const int64_t *start,
@@ -618,14 +625,25 @@ static hipError_t launch_q8(const void *value, const int64_t *shapes, const int6
     if (once != hipSuccess) return once;
     static const int env_kb = getenv("MMFS_FWD_Q8_LDS_KB") ? atoi(getenv("MMFS_FWD_Q8_LDS_KB")) : 0;      // tuning / tests
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(kImg0 + 1024, env_kb * 1024)) : kLdsTotal;
-    // queries per run: the image fill (one pass over the resident levels' slices) is paid per run
-    int q_per_run = 512;
+    // Queries per run: the image fill (one pass over the resident levels' slices + the barrier around it: 14-19 k clocks
+    // per wave, a quarter of a 512-query run at the LLM geometry, r04f) is paid per run, so runs are as long as the shape
+    // allows while every CU still gets one: up to 1024 queries (longer runs put more (b, h) slabs of the row-gather
+    // levels into an XCD's L2 at a time: r03bf).
+    const int unit = kMmaWaves * kQT;
+    const int n_slices = d.D / kCS;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+    }();
+    // (shapes whose levels do not all fit keep 512: at the LLM geometry with 4 images 1024 cost 258 us against 234)
+    int q_per_run = q8_all_resident_likely(d) ? 1024 : 512;
+    const int64_t units = (int64_t)d.B * d.H * n_slices;
+    while (q_per_run > unit && units * ((d.Nq + q_per_run - 1) / q_per_run) < cus) q_per_run -= unit;
     static const int env_q = getenv("MMFS_FWD_Q8_QPR") ? atoi(getenv("MMFS_FWD_Q8_QPR")) : 0;
     if (env_q > 0) q_per_run = env_q;
-    const int unit = kMmaWaves * kQT;
     q_per_run = std::max(unit, (q_per_run + unit - 1) / unit * unit);
     d.q_tiles = (d.Nq + q_per_run - 1) / q_per_run;
-    const int n_slices = d.D / kCS;
     const int64_t runs = (int64_t)d.B * d.q_tiles * n_slices * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)persistent_grid(runs, d.H);
@@ -650,7 +668,12 @@ bool fwd_q8_applies(int dtype, const Dims &d)
     if (!fwd_q8_supported(dtype, d)) return false;
     if (algo && algo[0] == 'q') return true;
     if (algo) return false;
-    return false;
+    // Default where it measured faster than the row gather (profiles/r04_experiments.md r04n): heads of 32 / 64 channels
+    // whose whole pyramid is resident -- the LLM layer with one image per sequence (61 -> 53 us at cfg3's op), the
+    // ViT-Adapter's injector (42 -> 35 us).  With a row-gather level left (the image decoder's 64x64: 335 vs 339 us; the
+    // LLM's 4 images: 234 vs 222) it does not pay, and heads of 128 channels pay the per-sample arithmetic four times
+    // (north star: 196 us against msda_fwd_mma's 128).
+    return d.D <= 64 && q8_all_resident_likely(d) && d.S >= 512 && d.Nq >= 128 && (int64_t)d.Nq * d.K >= 4096;
 }
 
 hipError_t forward_q8(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

@@ -650,6 +650,24 @@ def test_sliced_forward_with_less_lds_moves_levels_to_the_row_gather(kb, monkeyp
     assert max_abs(got, want) <= TOL[torch.bfloat16] * max(1.0, float(np.abs(want).max()))
 
 
+def test_sliced_forward_is_the_default_where_the_whole_pyramid_is_resident():
+    """Heads of 32 / 64 channels whose levels all fit in the image (judged from S on the host: the entry point sees
+    device pointers only) take the sliced formulation by default from 128 queries and 4096 samples per (b, h) on -- the
+    LLM layer's real geometry with one image; heads of 128 channels, shapes with a level left to the row gather, and
+    short runs keep what they had."""
+    llm = [(32, 32), (16, 16), (8, 8)]
+    x = make_inputs(1, 16, 64, 200, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    a = run_fwd(x, torch.bfloat16, "auto")
+    assert max_abs(a, run_fwd(x, torch.bfloat16, "slices")) == 0.0
+    assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0         # (another summation order: not bit-equal)
+    x = make_inputs(1, 16, 64, 100, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # fewer than 128 queries
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
+    x = make_inputs(1, 16, 64, 200, 8, [(64, 64)] + llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)   # 64 x 64 does not fit
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
+    x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # heads of 128 channels
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "lds")) == 0.0
+
+
 def test_sliced_forward_non_finite_rows_stay_inside_their_tile():
     """A product of the sliced forward multiplies the rows of EIGHT queries with a block-diagonal weight tile: a
     non-finite value row turns the zeros of the other queries' weights into NaN, so it reaches the queries of its
