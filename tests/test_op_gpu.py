@@ -427,13 +427,22 @@ FULL = [
 ]
 
 
+@pytest.mark.parametrize("route", ["fresh", "registered"])
 @pytest.mark.parametrize("name,cfg,dtype", FULL, ids=[f[0] for f in FULL])
-def test_full_size_properties(name, cfg, dtype):
+def test_full_size_properties(name, cfg, dtype, route):
+    """``fresh``: level tensors nobody has looked at (the reference's call pattern: table checked on the device, bound-sized
+    grids); ``registered``: the same tensors announced to the shim -- hybrid routing, host-sized grids, the hosted plan:
+    the route ``bench.py`` times (it was held by the bench's own Euler guard only)."""
+    import MultiScaleDeformableAttention as MSDA
     from mmfs_amd.functions import MSDeformAttnFunction
     g = torch.Generator(device=DEV).manual_seed(0)
     sh, start = level_tables(cfg["shapes"], DEV)
     B, H, D, Nq, P = cfg["B"], cfg["H"], cfg["D"], cfg["Nq"], cfg["P"]
     S, L = int(sh.prod(1).sum()), sh.shape[0]
+    if route == "registered":
+        assert MSDA.register_level_tables(sh, start, S)[0]             # (canonical)
+    else:
+        assert MSDA._level_info(sh, start, S, sync=False) is None
     value = torch.rand(B, S, H, D, device=DEV, generator=g).to(dtype)
     loc = (torch.rand(B, Nq, H, L, P, 2, device=DEV, generator=g) * 1.2 - 0.1).to(dtype)
     attn = torch.rand(B, Nq, H, L, P, device=DEV, generator=g) + 1e-5
