@@ -314,6 +314,9 @@ def main():
                     help="the literal drop-in: spatial_shapes / level_start_index rebuilt as NEW device tensors on every "
                          "call, as the reference's callers do (modeling_llama_mmfs.py:298-308, sd_mmfs.py:31-41) -- the shim "
                          "has never seen them, the backward checks the table on the device and has no hybrid routing")
+    ap.add_argument("--fresh-levels-unused", action="store_true",
+                    help="measurement: build the two fresh level tensors per call as --fresh-levels does, but hand the op the "
+                         "registered pair -- what of the fresh line's distance to the default line is the CALLER's tensor construction")
     ap.add_argument("--grad", default="randn", choices=["randn", "ones"],
                     help="grad_output: N(0,1) or ones (the reference's speed test backpropagates .sum())")
     ap.add_argument("--exchange-in-step", action="store_true",
@@ -364,10 +367,12 @@ def main():
     def step():
         if overlap is not None:
             overlap.issue()                     # the all-gather rides a side stream under the op
-        if args.fresh_levels:
+        if args.fresh_levels or args.fresh_levels_unused:
             # what the reference's callers do per call: two new device tensors, nothing registered
             sh = host_shapes.to(device)
             st = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+            if args.fresh_levels_unused:      # (measurement: the caller's tensor construction alone -- the op gets the registered pair)
+                sh, st = shapes, start
             out = MSDeformAttnFunction.apply(value, sh, st, loc, attn, 1)
         else:
             out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
@@ -481,7 +486,9 @@ def main():
                              if k in ab and v > 0 and ab[k] > 0},
             # event brackets cost a few us each and span a stage's helper launches: their sum may exceed the clean step
             "event_overhead_us": round(sum(mean_ms.values()) * 1e3 - elapsed / args.steps * 1e6, 2),
-            "levels": "fresh per call, unregistered (reference call pattern)" if args.fresh_levels else "make_level_tables (built once, known to the shim)",
+            "levels": "fresh per call, unregistered (reference call pattern)" if args.fresh_levels else
+                      "fresh tensors built per call but NOT used (registered pair to the op)" if args.fresh_levels_unused else
+                      "make_level_tables (built once, known to the shim)",
             # whole step against the roofline: algorithmic bytes of forward + backward / the clean step time
             "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
