@@ -208,8 +208,10 @@ class MMFSBlock(CacheInvalidation, nn.Module):
             # the op is stateless and re-entrant: the forward is simply re-run in backward
             # (a projected ``value`` is an input of the checkpoint: kept, not recomputed)
             # (``residual`` is an input the caller holds anyway -- for ``MMFSNet`` the sample itself)
+            # (no random numbers inside: nothing of the generator's state to save -- which would also be a host round
+            # trip that a HIP-graph capture of the step refuses)
             return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
-                                 normed, use_reentrant=False)
+                                 normed, use_reentrant=False, preserve_rng_state=False)
         return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual, normed)
 
 
@@ -242,6 +244,12 @@ class MMFSNet(CacheInvalidation, nn.Module):
     fused_schedule = True
     cache_projected_features = True
     share_normalised_bank = True        # training under gradient checkpointing: see forward
+    # Training under gradient checkpointing, round 4: project the bank for all blocks ONCE, as one batched GEMM, OUTSIDE
+    # the checkpoints, and hand every block its projection as a checkpoint input (kept through the step, not recomputed).
+    # The reference recomputes LayerNorm + projection inside every checkpoint to save memory -- 13 bank-sized tensors,
+    # 1.16 GB at B = 8 in bf16: a quarter of a percent of this GPU's 288 GB -- and pays 26 forward projections and 13
+    # weight-gradient GEMMs of the worst shape for it.  False: the round-3 schedule.
+    project_once_in_training = True
 
     def __init__(self, input_channel, block_out_channels, layers_per_block, downsample_factor=1,
                  n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]):
@@ -294,13 +302,21 @@ class MMFSNet(CacheInvalidation, nn.Module):
         bank = self._pack(mmfs_features)
         norm = self.mmfs_mid_block.feat_norm
         xhat = F.layer_norm(bank, norm.normalized_shape, None, None, norm.eps)
-        values = []
-        for blk in self._blocks():
-            proj, ln = blk.mmfs.value_proj, blk.feat_norm
-            bias = F.linear(ln.bias, proj.weight, proj.bias)
-            values.append(F.linear(xhat, proj.weight * ln.weight, bias))
-        return ProjectedFeatures(values, bank, shapes, [(f, tensor_version(f)) for f in mmfs_features],
+        return ProjectedFeatures(self._project_all(xhat), bank, shapes, [(f, tensor_version(f)) for f in mmfs_features],
                                  self._projection_weights())
+
+    def _project_all(self, xhat):
+        """Every block's value projection of the normalised bank as ONE batched GEMM, [tokens, C] x [n_blocks, C, d_inner]
+        (the left operand broadcast over the batch): block k's result is contiguous, and with gradients the 13 weight
+        gradients are one batched GEMM too instead of 13 products of a [1024, 43 520] by a [43 520, 1024] matrix that fill
+        an eighth of the chip each (profiles/r03bb_train_kernels_cfg4.log: 264 us apiece, 14 % of the MFMA peak).
+        Same mathematics as ``value_proj_k(feat_norm_k(bank))``: the affine folds into the weights,
+        value_proj_k(g_k * xhat + b_k) = (W_k diag g_k) xhat + (W_k b_k + bias_k)."""
+        blocks = self._blocks()
+        wt = torch.stack([(b.mmfs.value_proj.weight * b.feat_norm.weight).t() for b in blocks])          # [n_blocks, C, d_inner]
+        bias = torch.stack([F.linear(b.feat_norm.bias, b.mmfs.value_proj.weight, b.mmfs.value_proj.bias) for b in blocks])
+        y = torch.matmul(xhat.reshape(1, -1, xhat.shape[-1]).to(wt.dtype), wt) + bias[:, None, :]       # [n_blocks, tokens, d_inner]
+        return [y[k].view(*xhat.shape[:-1], -1) for k in range(len(blocks))]
 
     def _projection_weights(self):
         return (cache_epoch(),) + tuple((p.data_ptr(), tensor_version(p)) for b in self._blocks()
@@ -334,6 +350,8 @@ class MMFSNet(CacheInvalidation, nn.Module):
         # checkpointing was meant to save memory.  Training with checkpointing recomputes every block's projection as
         # the reference does (the un-affined normalisation alone is shared: below).
         ckpt = self.training and torch.is_grad_enabled() and any(b.gradient_checkpointing for b in self._blocks())
+        if ckpt and self.project_once_in_training:
+            ckpt = False                                   # (the projections become checkpoint inputs: below)
         if proj is None and self.fused_schedule and self._can_fuse() and not ckpt:
             keep = self.cache_projected_features and not torch.is_grad_enabled() and not self.training
             proj = self.__dict__.get("_projected") if keep else None

@@ -9,6 +9,9 @@ capture and baked in -- and replays it per step: one launch, no Python between k
 
 The kernels underneath need nothing special for this: the C ABI takes its stream as an argument,
 allocates nothing, and never synchronises (tests/test_modules_gpu.py checks the last).
+
+``GraphedTrainingStep`` (round 4) does the same for a TRAINING step -- forward + backward recorded as one graph: the 13-block
+net's step is ~5 000 launches that the host issues in 37-39 ms while their kernels take under 30.
 """
 import torch
 
@@ -104,3 +107,56 @@ class GraphedLlamaMMFSStack:
         self._hidden.copy_(hidden)
         self.graph.replay()
         return self._out
+
+
+class GraphedTrainingStep:
+    """Forward + backward of ``fn`` recorded ONCE into a HIP graph and replayed per step ("whole-network capture" restricted
+    to the part of the network this package owns).
+
+    ``fn(*inputs)`` returns a tensor or a tuple of tensors; ``inputs`` / ``grad_outputs`` are example tensors of the step's
+    shapes (inputs that require grad get one); ``params``: the parameters whose ``.grad`` the step produces.
+    ``outs, input_grads = step(inputs, grad_outputs)`` copies the arguments into the graph's static buffers, replays, and
+    returns the graph-owned results (overwritten by the next replay); parameter gradients are WRITTEN (not accumulated)
+    into ``p.grad`` -- tensors the graph owns: an optimiser may read them, ``zero_grad(set_to_none=True)`` must not be
+    called between replays (``zero_grad(set_to_none=False)`` is fine, and pointless).
+
+    What it needs from ``fn``: fixed shapes, no host synchronisation (the ops and modules here have none), no random
+    numbers.  Gradient checkpointing inside ``fn`` works (the blocks' checkpoints do not save RNG state) but is better
+    switched off: a replayed step is bound by its kernels, and the recompute pass is kernels."""
+
+    def __init__(self, fn, inputs, grad_outputs, params, warmup=3):
+        self.fn = fn
+        self.params = [p for p in params if p.requires_grad]
+        dev = inputs[0].device
+        self._in = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
+        self._go = [g.detach().clone() for g in grad_outputs]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._run()
+                self._clear()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._out = self._run()
+        self._in_grads = [x.grad for x in self._in]
+
+    def _run(self):
+        outs = self.fn(*self._in)
+        tup = outs if isinstance(outs, (tuple, list)) else (outs,)
+        torch.autograd.backward(list(tup), self._go)
+        return outs
+
+    def _clear(self):
+        for x in self._in:
+            x.grad = None
+        for p in self.params:
+            p.grad = None
+
+    def __call__(self, inputs, grad_outputs):
+        with torch.no_grad():
+            torch._foreach_copy_(self._in, [x.detach() for x in inputs])
+            torch._foreach_copy_(self._go, list(grad_outputs))
+        self.graph.replay()
+        return self._out, self._in_grads

@@ -238,6 +238,7 @@ def test_sd_mmfs_net_shares_the_normalised_bank_under_checkpointing(oracle_op):
     for share in (False, True):
         net = _tiny_net(z)
         net.share_normalised_bank = share
+        net.project_once_in_training = False              # (round 3's schedule: everything recomputed inside the checkpoints)
         for blk in net._blocks():
             blk.gradient_checkpointing = True
         net.train()
@@ -265,6 +266,49 @@ def test_sd_mmfs_net_shares_the_normalised_bank_under_checkpointing(oracle_op):
         close(x, y, 1e-10)
     assert sorted(a["gparam"]) == sorted(b["gparam"])
     assert any("feat_norm.weight" in k for k in a["gparam"]) and any("feat_norm.bias" in k for k in a["gparam"])
+    for k in a["gparam"]:
+        close(b["gparam"][k], a["gparam"][k], 1e-9)
+
+
+def test_sd_mmfs_net_projects_once_in_training(oracle_op):
+    """Round 4: a training step under gradient checkpointing projects the bank for all blocks ONCE, as
+    one batched GEMM outside the checkpoints (MMFSNet.project_once_in_training, default) -- every block gets its
+    projection as a checkpoint input, in the forward and in the recompute pass -- against the reference's schedule
+    (LayerNorm + projection inside every checkpoint): outputs, input gradients, EVERY parameter gradient."""
+    z = load_golden("block_sd_mmfs_net")
+    outs = []
+    for once in (False, True):
+        net = _tiny_net(z)
+        net.project_once_in_training = once
+        net.share_normalised_bank = False                 # (the reference's schedule on the other side)
+        net.fused_schedule = once
+        for blk in net._blocks():
+            blk.gradient_checkpointing = True
+        net.train()
+        seen = []
+        hooks = [blk.mmfs.register_forward_pre_hook(lambda m, args, kwargs: seen.append(kwargs.get("value") is not None),
+                                                    with_kwargs=True) for blk in net._blocks()]
+        res = [T(z[f"res.{i}"]).requires_grad_(True) for i in range(6)]
+        feats = [T(z[f"feat.{i}"]).requires_grad_(True) for i in range(3)]
+        mid = T(z["mid"]).requires_grad_(True)
+        new_mid, new_res = net(mid, res, feats, T(z["ms_mask"]))
+        g = torch.Generator().manual_seed(5)
+        loss = (new_mid * torch.randn(new_mid.shape, generator=g, dtype=torch.float64)).sum()
+        for r in new_res:
+            loss = loss + (r * torch.randn(r.shape, generator=g, dtype=torch.float64)).sum()
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        assert len(seen) == 14 and all(v == once for v in seen)       # 7 blocks, forward + recompute: handed a projection or not
+        outs.append(dict(mid=new_mid.detach(), res=[r.detach() for r in new_res],
+                         gfeat=[f.grad for f in feats], gres=[r.grad for r in res],
+                         gparam={k: p.grad for k, p in net.named_parameters() if p.grad is not None}))
+    a, b = outs
+    close(b["mid"], a["mid"], 1e-11)
+    for x, y in zip(b["res"] + b["gfeat"] + b["gres"], a["res"] + a["gfeat"] + a["gres"]):
+        close(x, y, 1e-10)
+    assert sorted(a["gparam"]) == sorted(b["gparam"])
+    assert any("feat_norm.weight" in k for k in a["gparam"]) and any("value_proj.bias" in k for k in a["gparam"])
     for k in a["gparam"]:
         close(b["gparam"][k], a["gparam"][k], 1e-9)
 

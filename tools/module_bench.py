@@ -156,10 +156,25 @@ def cfg3():
         for l in layers:
             l.eval()
         graphed = GraphedLlamaMMFSStack(layers, hidden, feats, mask)
+
+        def stack_fn(h):
+            x = h
+            for l in layers:
+                x = x + l(x, feats, mask)
+            return x
+        gstep = [None]
+
+        def train_graphed():
+            if gstep[0] is None:                   # (captured in training mode, once per shape)
+                from mmfs_amd.graphs import GraphedTrainingStep
+                gstep[0] = GraphedTrainingStep(stack_fn, [hidden.clone().requires_grad_(True)], [torch.ones_like(hidden)],
+                                               [p for l in layers for p in l.parameters()])
+            gstep[0]([hidden], [torch.ones_like(hidden)])
         cases = [("forward", fwd, False), ("forward, shared normalisation + batched value projection", lambda: fwd_sched(False), False),
                  ("forward, projected bank kept across calls (decode / generation)", lambda: fwd_sched(True), False),
                  ("forward, projected bank kept, HIP-graph replay", lambda: graphed(hidden), False),      # (replays what the line above runs)
-                 ("forward+backward", train, True), ("forward+backward, shared normalisation + batched value projection", train_sched, True)]
+                 ("forward+backward", train, True), ("forward+backward, shared normalisation + batched value projection", train_sched, True),
+                 ("forward+backward, whole step replayed as ONE HIP graph", train_graphed, True)]
         for label, fn, bwd in cases:
             if bwd and Lq == 1:
                 continue
@@ -168,7 +183,7 @@ def cfg3():
             ms = timed(fn)
             fam, launches = split(fn)
             analytic = 8 * mmfs_linear_flops(B * Lq, B * n * S, 4096, 1024, 1024, 4096, 16, 3, 8, 50) * (3 if bwd else 1)
-            flops = executed_gemm_flops((lambda: fwd_sched(True)) if "replay" in label else fn)
+            flops = executed_gemm_flops((lambda: fwd_sched(True)) if "graph replay" in label else train if "ONE HIP graph" in label else fn)
             ob = 8 * op_bytes(B, Lq, 16, 64, 3 * n, 8, S * n, backward=bwd)
             print(json.dumps({
                 "config": "cfg3", "what": f"8 MMFS layers (Vicuna-7B geometry), B={B}, Lq={Lq}, n_images={n}, bf16, {label}",
@@ -221,12 +236,41 @@ def cfg4():
         (m.float().sum() + sum(x.float().sum() for x in rr)).backward()
         net_t.eval()
 
-    cases.append(("training step (forward + backward, gradient checkpointing as the reference builds it)", train_step,
+    cases.append(("training step (forward + backward, gradient checkpointing; bank projected once for all blocks: round 4 default)", train_step,
                   3 * (flops + flops_proj) + flops + flops_proj, True))
+
+    def train_step_r3():
+        net_t.project_once_in_training = False
+        try:
+            train_step()
+        finally:
+            net_t.project_once_in_training = True
+    cases.append(("training step, round 3's schedule (normalised bank shared, projections recomputed inside every checkpoint)", train_step_r3,
+                  3 * (flops + flops_proj) + flops + flops_proj, True))
+    gstep = [None]
+    gins = [mid.clone().requires_grad_(True)] + [x.clone().requires_grad_(True) for x in res]
+
+    def net_fn(m, *r):
+        mm, rr = net_t(m, list(r), feats, mask)
+        return (mm,) + tuple(rr)
+
+    def train_graphed():
+        if gstep[0] is None:
+            from mmfs_amd.graphs import GraphedTrainingStep
+            net_t.train()
+            for blk in net_t._blocks():
+                blk.gradient_checkpointing = False        # (288 GB: a replayed step is bound by its kernels, and recomputation is kernels)
+            gstep[0] = GraphedTrainingStep(net_fn, gins, [torch.ones_like(x) for x in gins], list(net_t.parameters()))
+            for blk in net_t._blocks():
+                blk.gradient_checkpointing = True
+            net_t.eval()
+        gstep[0](gins, [torch.ones_like(x) for x in gins])
+    cases.append(("training step, whole step replayed as ONE HIP graph (no checkpointing)", train_graphed,
+                  3 * (flops + flops_proj), True))
     for label, fn, fl, bwd in cases:
         ms = timed(fn, iters=10, warm=3)
         fam, launches = split(fn, iters=3)
-        analytic, fl = fl, executed_gemm_flops(sample_step if "replay" in label else fn)
+        analytic, fl = fl, executed_gemm_flops(sample_step if "HIP-graph replay" in label else train_step if "ONE HIP graph" in label else fn)
         obb = sum(op_bytes(B, t, 16, 64, 4 * n, 8, S * n, backward=bwd) for _, t in tokens) + (ob if bwd else 0)
         print(json.dumps({
             "config": "cfg4", "what": f"MMFSNet, 13 blocks at 512 px, B={B}, n_images={n}, bf16, {label}",
