@@ -230,11 +230,11 @@ def cfg4():
     net_t = net
 
     def train_step():
-        net_t.train()
+        # (the mode is set once per line, below: every train() / eval() drops what the modules keep -- the blocks' position
+        # tables among it, 2.4 ms of bicubic resize each -- and a training loop does not change mode per step)
         r = [x.clone().requires_grad_(True) for x in res]
         m, rr = net_t(mid.clone().requires_grad_(True), r, feats, mask)
         (m.float().sum() + sum(x.float().sum() for x in rr)).backward()
-        net_t.eval()
 
     cases.append(("training step (forward + backward, gradient checkpointing; bank projected once for all blocks: round 4 default)", train_step,
                   3 * (flops + flops_proj) + flops + flops_proj, True))
@@ -257,17 +257,16 @@ def cfg4():
     def train_graphed():
         if gstep[0] is None:
             from mmfs_amd.graphs import GraphedTrainingStep
-            net_t.train()
             for blk in net_t._blocks():
                 blk.gradient_checkpointing = False        # (288 GB: a replayed step is bound by its kernels, and recomputation is kernels)
             gstep[0] = GraphedTrainingStep(net_fn, gins, [torch.ones_like(x) for x in gins], list(net_t.parameters()))
             for blk in net_t._blocks():
                 blk.gradient_checkpointing = True
-            net_t.eval()
         gstep[0](gins, [torch.ones_like(x) for x in gins])
     cases.append(("training step, whole step replayed as ONE HIP graph (no checkpointing)", train_graphed,
                   3 * (flops + flops_proj), True))
     for label, fn, fl, bwd in cases:
+        net_t.train(bwd)
         ms = timed(fn, iters=10, warm=3)
         fam, launches = split(fn, iters=3)
         analytic, fl = fl, executed_gemm_flops(sample_step if "HIP-graph replay" in label else train_step if "ONE HIP graph" in label else fn)
