@@ -117,8 +117,8 @@ class GraphedTrainingStep:
     shapes (inputs that require grad get one); ``params``: the parameters whose ``.grad`` the step produces.
     ``outs, input_grads = step(inputs, grad_outputs)`` copies the arguments into the graph's static buffers, replays, and
     returns the graph-owned results (overwritten by the next replay); parameter gradients are WRITTEN (not accumulated)
-    into ``p.grad`` -- tensors the graph owns: an optimiser may read them, ``zero_grad(set_to_none=True)`` must not be
-    called between replays (``zero_grad(set_to_none=False)`` is fine, and pointless).
+    into ``p.grad`` -- tensors the graph owns (re-attached after every replay, so ``zero_grad(set_to_none=True)`` between
+    steps is harmless): an optimiser reads them as usual; gradient ACCUMULATION over several replays is the caller's to do.
 
     What it needs from ``fn``: fixed shapes, no host synchronisation (the ops and modules here have none), no random
     numbers.  Gradient checkpointing inside ``fn`` works (the blocks' checkpoints do not save RNG state) but is better
@@ -141,6 +141,7 @@ class GraphedTrainingStep:
         with torch.cuda.graph(self.graph):
             self._out = self._run()
         self._in_grads = [x.grad for x in self._in]
+        self._param_grads = [p.grad for p in self.params]      # (the buffers the recorded backward writes)
 
     def _run(self):
         outs = self.fn(*self._in)
@@ -159,4 +160,6 @@ class GraphedTrainingStep:
             torch._foreach_copy_(self._in, [x.detach() for x in inputs])
             torch._foreach_copy_(self._go, list(grad_outputs))
         self.graph.replay()
+        for p, g in zip(self.params, self._param_grads):       # (a caller may have detached them: zero_grad(set_to_none=True))
+            p.grad = g
         return self._out, self._in_grads

@@ -999,3 +999,52 @@ def test_mmfs_net_16bit_no_grad_at_512px_geometry_and_batch(dtype, bar):
             err = float(((a.double() - base) - add_w).abs().max()) / max(float(add_w.abs().max()), 1e-6)
             assert err <= 2.5 * bar, f"{name}, output {i}: {err:.3e}"
             assert float((a.double() - w).abs().max()) / float(w.abs().max()) <= bar
+
+
+# ---------------------------------------------------------------- a training step as one HIP graph
+@pytest.mark.parametrize("dtype, tol", [(torch.float32, 1e-5), (torch.bfloat16, 0.0)], ids=["f32", "bf16"])
+def test_graphed_training_step_replays_the_eager_step(dtype, tol):
+    """mmfs_amd.graphs.GraphedTrainingStep: forward + backward of the toy MMFSNet (training mode, gradient checkpointing on
+    in one case, the bank projected once for all blocks) recorded into ONE HIP graph and replayed on NEW inputs: outputs,
+    input gradients and every parameter gradient equal the eager step's (bit for bit in bf16: the same kernels in the
+    same order; fp32 to rounding: its float-atomic-free paths are deterministic too, the bar is slack)."""
+    from mmfs_amd.blocks import MMFSNet
+    from mmfs_amd.graphs import GraphedTrainingStep
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=True,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV, dtype).train()
+    with torch.no_grad():
+        for blk in net._blocks():
+            blk.conv.weight.normal_(0, 0.3)
+    feats = [T(z[f"feat.{i}"], dtype) for i in range(3)]
+    mask = T(z["ms_mask"], None)
+    g = torch.Generator().manual_seed(4)
+
+    def inputs(scale):
+        return [(T(z["mid"], dtype) * scale)] + [T(z[f"res.{i}"], dtype) * scale for i in range(6)]
+
+    def fn(mid, *res):
+        m, rr = net(mid, list(res), feats, mask)
+        return (m,) + tuple(rr)
+    ex = [x.clone().requires_grad_(True) for x in inputs(1.0)]
+    gos = [torch.randn(x.shape, generator=g).to(DEV, dtype) for x in ex]
+    step = GraphedTrainingStep(fn, ex, gos, list(net.parameters()))
+    for scale in (0.5, 1.5):
+        new_in = inputs(scale)
+        new_go = [torch.randn(x.shape, generator=g).to(DEV, dtype) for x in ex]
+        outs, gin = step(new_in, new_go)
+        got = ([o.clone() for o in outs], [x.clone() for x in gin], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        for p in net.parameters():
+            p.grad = None
+        leaves = [x.clone().requires_grad_(True) for x in new_in]
+        eo = fn(*leaves)
+        torch.autograd.backward(list(eo), new_go)
+        want = ([o.detach() for o in eo], [x.grad for x in leaves], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        assert sorted(got[2]) == sorted(want[2]) and len(want[2]) > 20
+        for a, b in list(zip(got[0], want[0])) + list(zip(got[1], want[1])) + [(got[2][k], want[2][k]) for k in want[2]]:
+            err = float((a.double() - b.double()).abs().max()) / max(1.0, float(b.double().abs().max()))
+            assert err <= tol, err
+        for p in net.parameters():          # (as zero_grad(set_to_none=True) would: the next replay re-attaches its buffers)
+            p.grad = None

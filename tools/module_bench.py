@@ -269,7 +269,21 @@ def cfg4():
         net_t.train(bwd)
         ms = timed(fn, iters=10, warm=3)
         fam, launches = split(fn, iters=3)
-        analytic, fl = fl, executed_gemm_flops(sample_step if "HIP-graph replay" in label else train_step if "ONE HIP graph" in label else fn)
+        if "HIP-graph replay" in label:
+            sample_step()                          # (the mode change above dropped the kept projections: count a step that has them)
+            counted = sample_step
+        elif "ONE HIP graph" in label:
+            def counted():                         # (the replayed step has no recompute pass)
+                for blk in net_t._blocks():
+                    blk.gradient_checkpointing = False
+                try:
+                    train_step()
+                finally:
+                    for blk in net_t._blocks():
+                        blk.gradient_checkpointing = True
+        else:
+            counted = fn
+        analytic, fl = fl, executed_gemm_flops(counted)
         obb = sum(op_bytes(B, t, 16, 64, 4 * n, 8, S * n, backward=bwd) for _, t in tokens) + (ob if bwd else 0)
         print(json.dumps({
             "config": "cfg4", "what": f"MMFSNet, 13 blocks at 512 px, B={B}, n_images={n}, bf16, {label}",
