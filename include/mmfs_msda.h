@@ -36,7 +36,12 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 8   /* 8: + stage MMFS_HYB_BWD_VALUE_BLOCKS of mmfs_msda_backward_hybrid (grad_value of the small levels sorted
+#define MMFS_MSDA_ABI_VERSION 9   /* 9: + MMFS_FWD_SLICES (the forward's third formulation, csrc/msda_fwd_q8.hip);
+                                   *    mmfs_msda_backward_checked serves a table its device-side check refuses IN THE
+                                   *    SAME CALL (float-atomic fallback, csrc/msda_bwd_refused.hip; round 3 returned a
+                                   *    zero grad_value for it): the workspace of MMFS_BWD_DEVICE_CHECKED_LEVELS grows by
+                                   *    an fp32 image for 16-bit storage
+                                   * 8: + stage MMFS_HYB_BWD_VALUE_BLOCKS of mmfs_msda_backward_hybrid (grad_value of the small levels sorted
                                    *      and reduced inside a workgroup, csrc/msda_gv_mma.hip), MMFS_BWD_VALUE_SORTED_ONLY /
                                    *      MMFS_BWD_VALUE_LDS_BLOCKS, mmfs_msda_backward_value_lds_levels
                                    * 7: + mmfs_msda_forward_flags (the forward's two formulations, selectable);

@@ -22,6 +22,7 @@
 // an image changes at most once per image along the sequence), flushing it with a few float atomics.
 #include "../../include/mmfs_msda.h"
 #include "msda_device.h"
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <type_traits>
@@ -296,8 +297,8 @@ __device__ __forceinline__ float rgroup_add(float v, int G)
     return v;
 }
 
-template <typename T, int LPI, int P>
-__global__ void __launch_bounds__(kThreads)
+template <typename T, int LPI, int P, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                 const T *__restrict__ off_q, const T *__restrict__ att_q,
                 const T *__restrict__ off_tab, const T *__restrict__ att_tab,
@@ -307,7 +308,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
-    constexpr int QPB = kThreads / LPI;
+    constexpr int QPB = THREADS / LPI;
     constexpr int KC = (kSampleRecs / QPB) > P ? (kSampleRecs / QPB) : P;      // samples per query per chunk: whole rows of P
     __shared__ float ssum[QPB];                           // the queries' summed sink weights (for the ignore-token term)
     static_assert(KC % P == 0 && KC % kSampleUnroll == 0, "chunks hold whole rows of P points");
@@ -318,7 +319,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     __shared__ float4 plan[QPB * KC];                     // {x, y, weight} of the chunk's samples
     constexpr bool kPipe = KC <= 64;                      // live-tap mask + pipelined walk, as in msda_fwd_vec
     constexpr int QPW = 64 / LPI > 0 ? 64 / LPI : 1;
-    __shared__ unsigned long long live[kThreads / 64];
+    __shared__ unsigned long long live[THREADS / 64];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
@@ -331,8 +332,8 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const uint32_t lane_off = (uint32_t)(lig * 16);
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
-    levels.load(shapes, start, nL, tid, kThreads);
-    if (kPipe && tid < kThreads / 64) live[tid] = 0ull;
+    levels.load(shapes, start, nL, tid, THREADS);
+    if (kPipe && tid < THREADS / 64) live[tid] = 0ull;
     const float sink_logit = -logf((float)nL);
 
     // logits of row gl (= image k, level l) of the item (bc.b, sq, bc.h), as plan_forward_kernel forms them
@@ -350,7 +351,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     };
 
     // ---- softmax statistics of the tile's queries (lane group of G per query, like the plan kernel)
-    for (int base = 0; base < QPB * G; base += kThreads) {
+    for (int base = 0; base < QPB * G; base += THREADS) {
         if (base + (tid & ~63) >= QPB * G) continue;      // (whole waves only: the groups shuffle)
         const int s = base + tid, rq = s / G, gl = s % G;
         const int sq = bc.q0 + rq;
@@ -392,7 +393,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         if (k0 > 0) __syncthreads();
         // ---- stage, step 1: one lane per (query, row): the row's P weights and locations, rounded to the
         // storage type like the tensors of the two-kernel path, parked in LDS
-        for (int s = tid; s < QPB * rows; s += kThreads) {
+        for (int s = tid; s < QPB * rows; s += THREADS) {
             const int rq = s / rows, rr = s - rq * rows, gl = k0 / P + rr;
             const int sq = bc.q0 + rq;
             float4 *dst = &plan[rq * KC + rr * P];
@@ -425,7 +426,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
         __syncthreads();
         // ---- stage, step 2: one lane per sample: location -> tap record (as msda_fwd_vec does from its tensors)
-        for (int r = tid; r < QPB * kc; r += kThreads) {
+        for (int r = tid; r < QPB * kc; r += THREADS) {
             const int rq = r / kc, kk = r - rq * kc, gl = (k0 + kk) / P;
             const float4 pl = plan[rq * KC + kk];
             const float a = pl.z;
@@ -720,19 +721,31 @@ int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shape
     int G = 4;
     while (G < d.L) G *= 2;                                                 // the plan kernel's lane-group width
     hipStream_t st = (hipStream_t)stream;
-    auto go = [&](auto tag_t, auto tag_lpi, auto tag_p) {
+    auto go_threads = [&](auto tag_t, auto tag_lpi, auto tag_p, auto tag_threads) {
         typedef decltype(tag_t) T;
-        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value;
-        constexpr int QPB = kThreads / LPI;
+        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value, THREADS = decltype(tag_threads)::value;
+        constexpr int QPB = THREADS / LPI;
         Dims dd = d;
         dd.q_tiles = (d.Nq + QPB - 1) / QPB;
         const int64_t blocks = (int64_t)d.B * dd.q_tiles * d.H;
         if (blocks > 0x7fffffffLL) return (int)MMFS_E_DIMS;
-        hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, st,
                            (const T *)value, shapes, start, (const T *)off_q, (const T *)att_q,
                            (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, dd, pd, G,
                            (const T *)token);
         return (int)hipGetLastError();
+    };
+    // A decode step (one new token per sequence) is a handful of queries per (b, h): a 256-lane workgroup holds 256 / LPI
+    // query slots, so its tap records come in chunks of 512 / (256 / LPI) samples -- 16 at the LLM's geometry, where a
+    // query has 24: two rounds of stage -> barrier -> gather, each a dependent global round trip, 13.9 us per call for 4
+    // queries (profiles/r03by_decode_kernel_stats.csv).  When a (b, h)'s queries fit ONE wave the kernel
+    // runs as 64-lane workgroups: 64 samples per chunk (one round), barriers that are a wave's own.  Same arithmetic in
+    // the same lane groups: bit-identical (MMFS_SAMPLE_WAVE=0: always 256 lanes).
+    static const bool wave_ok = !(getenv("MMFS_SAMPLE_WAVE") && getenv("MMFS_SAMPLE_WAVE")[0] == '0');
+    auto go = [&](auto tag_t, auto tag_lpi, auto tag_p) {
+        constexpr int LPI = decltype(tag_lpi)::value;
+        if (wave_ok && d.Nq * LPI <= 64) return go_threads(tag_t, tag_lpi, tag_p, std::integral_constant<int, 64>());
+        return go_threads(tag_t, tag_lpi, tag_p, std::integral_constant<int, kThreads>());
     };
     auto by_p = [&](auto tag_t, auto tag_lpi) {
         if (P == 4) return go(tag_t, tag_lpi, std::integral_constant<int, 4>());
