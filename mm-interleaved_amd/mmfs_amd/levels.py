@@ -82,7 +82,8 @@ class CacheInvalidation:
     """Mixin for the modules that keep something: mode changes and state-dict loads move the epoch."""
 
     def train(self, mode=True):
-        invalidate_caches()
+        if bool(mode) != self.training:     # (a generation loop that says model.eval() before every step keeps its folds)
+            invalidate_caches()
         return super().train(mode)
 
     def _load_from_state_dict(self, *args, **kwargs):
