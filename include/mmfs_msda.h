@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 9   /* 9: + MMFS_FWD_SLICES (the forward's third formulation, csrc/msda_fwd_q8.hip);
+#define MMFS_MSDA_ABI_VERSION 10  /* 10: + mmfs_sample_forward_groups, mmfs_linear_small_add; mmfs_sample_forward* serve at most 8 queries per (sample,
+                                   *     head) -- a decode step -- with a workgroup per query (same products, another order of
+                                   *     the fp32 sums: see there)
+                                   * 9: + MMFS_FWD_SLICES (the forward's third formulation, csrc/msda_fwd_q8.hip);
                                    *    mmfs_msda_backward_checked serves a table its device-side check refuses IN THE
                                    *    SAME CALL (float-atomic fallback, csrc/msda_bwd_refused.hip; round 3 returned a
                                    *    zero grad_value for it): the workspace of MMFS_BWD_DEVICE_CHECKED_LEVELS grows by
@@ -391,7 +394,8 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
  * mmfs_msda_forward as ONE kernel -- the locations and weights [N, Lq, H, n*L, P(, 2)] never exist in
  * memory.  Same inputs as mmfs_plan_forward plus the op's value / level tables (``shapes`` / ``start``
  * have n*L rows), same arithmetic (the plan's numbers are rounded to the storage type before use), so
- * ``out`` [N, Lq, H*D] is bit-identical to the two calls.  ``sink`` [N, Lq, H] fp32 may be NULL.
+ * ``out`` [N, Lq, H*D] is bit-identical to the two calls (more than 8 queries per (sample, head); fewer: see
+ * mmfs_sample_forward_groups).  ``sink`` [N, Lq, H] fp32 may be NULL.
  * Forward only -- the backward needs loc / attn as tensors (a training step keeps the two calls).
  * MMFS_E_UNSUPPORTED (use the two calls) for P = 16, head rows that are not 16 bytes x 2^k (k <= 6), value
  * slabs of 2 GiB or more.
@@ -422,6 +426,13 @@ int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shape
                               void *out, float *sink,
                               int64_t N, int64_t S, int64_t Lq, int64_t H, int64_t D, int64_t L, int64_t P, int64_t n,
                               int64_t M, int64_t Lr, int64_t Nr, void *stream);
+
+/* How many lane groups share ONE query's samples in mmfs_sample_forward* for this shape (``nL`` = n * L level rows):
+ * 1 = the samples are summed in their order, ``out`` bit-identical to mmfs_plan_forward + mmfs_msda_forward;
+ * > 1 (at most 8 queries per (sample, head): a decode step; csrc/mmfs_plan.hip ``mmfs_sample_decode``) = every row of
+ * a query is requested at once and the groups' fp32 partial sums are added in a fixed tree: the same products, equal to
+ * the two calls within one rounding of the storage type, deterministic.  0 for shapes mmfs_sample_forward refuses. */
+int mmfs_sample_forward_groups(int dtype, int64_t Lq, int64_t D, int64_t nL, int64_t P);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-image feature bank: MMFS's ``input_flatten`` built in one pass.
@@ -492,6 +503,11 @@ int mmfs_tokens_add(int dtype, const void *tok, const void *res, void *y, int64_
 int mmfs_linear_small_supported(int dtype, int64_t M, int64_t N, int64_t K);
 int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *bias, void *y,
                       int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void *stream);
+/* The same followed by ``+ residual`` [M, N] (rows ``ldr`` apart; NULL = mmfs_linear_small): the decoder layer's
+ * ``hidden_states = residual + hidden_states`` (modeling_llama_mmfs.py:700-717) in the projection's store -- the result is
+ * rounded to the storage type, THEN added and rounded again: the bits of the framework's two kernels. */
+int mmfs_linear_small_add(int dtype, const void *x, const void *weight, const void *bias, const void *residual, void *y,
+                          int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldr, void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,11 +21,13 @@ constexpr int kLinThreads = 256;
 // (weight rows per wave R, 16-byte pieces of a row a lane has in flight U: template parameters; MMFS_LIN_ROWS /
 // MMFS_LIN_UNROLL: tuning)
 
-// x [M, K] (rows ldx elements apart), W [N, K] packed, bias [N] or null -> y [M, N] (rows ldy apart); M <= MT
+// x [M, K] (rows ldx elements apart), W [N, K] packed, bias [N] or null, res [M, N] (rows ldr apart) or null -> y [M, N]
+// (rows ldy apart); M <= MT
 template <typename T, int MT, int kLinRows, int kLinUnroll>
 __global__ void __launch_bounds__(kLinThreads)
-linear_small(const T *__restrict__ x, const T *__restrict__ W, const T *__restrict__ bias, T *__restrict__ y,
-             const int M, const int N, const int K, const int64_t ldx, const int64_t ldy, const int early)
+linear_small(const T *__restrict__ x, const T *__restrict__ W, const T *__restrict__ bias, const T *__restrict__ res,
+             T *__restrict__ y, const int M, const int N, const int K, const int64_t ldx, const int64_t ldy,
+             const int64_t ldr, const int early)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *xs = reinterpret_cast<uint4 *>(smem_raw);                       // [MT][K / 8]
@@ -90,7 +92,10 @@ linear_small(const T *__restrict__ x, const T *__restrict__ W, const T *__restri
 #pragma unroll
                 for (int mm = 0; mm < MT; ++mm) s = (cc == c && mm == m) ? acc[cc][mm] : s;
             if (bias != nullptr) s += to_f32(bias[n0 + c]);
-            y[(int64_t)m * ldy + n0 + c] = (T)s;
+            T r = (T)s;
+            // (+ the caller's residual, as the framework's add that would follow: a second rounding, of the sum of two stored values)
+            if (res != nullptr) r = (T)(to_f32(r) + to_f32(res[(int64_t)m * ldr + n0 + c]));
+            y[(int64_t)m * ldy + n0 + c] = r;
         }
     }
 }
@@ -108,8 +113,8 @@ int mmfs_linear_small_supported(int dtype, int64_t M, int64_t N, int64_t K)
     return mt * K * 2 <= 64 * 1024 && N <= 0x3fffffffLL;
 }
 
-int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *bias, void *y,
-                      int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void *stream)
+int mmfs_linear_small_add(int dtype, const void *x, const void *weight, const void *bias, const void *residual, void *y,
+                          int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldr, void *stream)
 {
     using namespace mmfs;
     if (dtype != MMFS_F32 && dtype != MMFS_F16 && dtype != MMFS_BF16) return MMFS_E_DTYPE;
@@ -117,7 +122,7 @@ int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *
     if (M == 0 || N == 0) return MMFS_OK;
     if (!mmfs_linear_small_supported(dtype, M, N, K)) return MMFS_E_UNSUPPORTED;
     if (!x || !weight || !y) return MMFS_E_NULLPTR;
-    if (ldx < K || ldy < N) return MMFS_E_DIMS;
+    if (ldx < K || ldy < N || (residual && ldr < N)) return MMFS_E_DIMS;
     if (((uintptr_t)x | (uintptr_t)weight) % 16 || (ldx * 2) % 16) return MMFS_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     static const int env_rows = getenv("MMFS_LIN_ROWS") ? atoi(getenv("MMFS_LIN_ROWS")) : 0;
@@ -131,7 +136,7 @@ int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *
     const size_t lds = (size_t)mt * K * 2;
 #define MMFS_LIN(T, MT, R, U)                                                                                         \
     hipLaunchKernelGGL((linear_small<T, MT, R, U>), grid, dim3(kLinThreads), lds, st, (const T *)x, (const T *)weight, \
-                       (const T *)bias, (T *)y, (int)M, (int)N, (int)K, ldx, ldy, early)
+                       (const T *)bias, (const T *)residual, (T *)y, (int)M, (int)N, (int)K, ldx, ldy, ldr, early)
 #define MMFS_LIN_RU(T, MT)                                                                                            \
     do {                                                                                                              \
         if (rows == 1) { if (unroll == 8) MMFS_LIN(T, MT, 1, 8); else MMFS_LIN(T, MT, 1, 4); }                        \
@@ -142,6 +147,12 @@ int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *
 #undef MMFS_LIN_RU
 #undef MMFS_LIN
     return (int)hipGetLastError();
+}
+
+int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *bias, void *y,
+                      int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, void *stream)
+{
+    return mmfs_linear_small_add(dtype, x, weight, bias, nullptr, y, M, N, K, ldx, ldy, 0, stream);
 }
 
 }  // extern "C"

@@ -297,8 +297,8 @@ __device__ __forceinline__ float rgroup_add(float v, int G)
     return v;
 }
 
-template <typename T, int LPI, int P, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+template <typename T, int LPI, int P>
+__global__ void __launch_bounds__(kThreads)
 mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
                 const T *__restrict__ off_q, const T *__restrict__ att_q,
                 const T *__restrict__ off_tab, const T *__restrict__ att_tab,
@@ -308,7 +308,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
 {
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
-    constexpr int QPB = THREADS / LPI;
+    constexpr int QPB = kThreads / LPI;
     constexpr int KC = (kSampleRecs / QPB) > P ? (kSampleRecs / QPB) : P;      // samples per query per chunk: whole rows of P
     __shared__ float ssum[QPB];                           // the queries' summed sink weights (for the ignore-token term)
     static_assert(KC % P == 0 && KC % kSampleUnroll == 0, "chunks hold whole rows of P points");
@@ -319,7 +319,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     __shared__ float4 plan[QPB * KC];                     // {x, y, weight} of the chunk's samples
     constexpr bool kPipe = KC <= 64;                      // live-tap mask + pipelined walk, as in msda_fwd_vec
     constexpr int QPW = 64 / LPI > 0 ? 64 / LPI : 1;
-    __shared__ unsigned long long live[THREADS / 64];
+    __shared__ unsigned long long live[kThreads / 64];
 
     const BlockCoord bc = block_coord(d, QPB);
     const int tid = threadIdx.x;
@@ -332,8 +332,8 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
     const uint32_t lane_off = (uint32_t)(lig * 16);
     const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)bc.h * d.D) * (int64_t)sizeof(T));
-    levels.load(shapes, start, nL, tid, THREADS);
-    if (kPipe && tid < THREADS / 64) live[tid] = 0ull;
+    levels.load(shapes, start, nL, tid, kThreads);
+    if (kPipe && tid < kThreads / 64) live[tid] = 0ull;
     const float sink_logit = -logf((float)nL);
 
     // logits of row gl (= image k, level l) of the item (bc.b, sq, bc.h), as plan_forward_kernel forms them
@@ -351,7 +351,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     };
 
     // ---- softmax statistics of the tile's queries (lane group of G per query, like the plan kernel)
-    for (int base = 0; base < QPB * G; base += THREADS) {
+    for (int base = 0; base < QPB * G; base += kThreads) {
         if (base + (tid & ~63) >= QPB * G) continue;      // (whole waves only: the groups shuffle)
         const int s = base + tid, rq = s / G, gl = s % G;
         const int sq = bc.q0 + rq;
@@ -393,7 +393,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         if (k0 > 0) __syncthreads();
         // ---- stage, step 1: one lane per (query, row): the row's P weights and locations, rounded to the
         // storage type like the tensors of the two-kernel path, parked in LDS
-        for (int s = tid; s < QPB * rows; s += THREADS) {
+        for (int s = tid; s < QPB * rows; s += kThreads) {
             const int rq = s / rows, rr = s - rq * rows, gl = k0 / P + rr;
             const int sq = bc.q0 + rq;
             float4 *dst = &plan[rq * KC + rr * P];
@@ -426,7 +426,7 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
         __syncthreads();
         // ---- stage, step 2: one lane per sample: location -> tap record (as msda_fwd_vec does from its tensors)
-        for (int r = tid; r < QPB * kc; r += THREADS) {
+        for (int r = tid; r < QPB * kc; r += kThreads) {
             const int rq = r / kc, kk = r - rq * kc, gl = (k0 + kk) / P;
             const float4 pl = plan[rq * KC + kk];
             const float a = pl.z;
@@ -548,6 +548,178 @@ mmfs_sample_fwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         }
         *reinterpret_cast<uint4 *>(o) = V::pack(acc);
     }
+}
+
+// ---------------------------------------------------------------- the same for a handful of queries (a decode step)
+// One new token per sequence is ONE query per (sample, head), and mmfs_sample_fwd serves it with 8 of a workgroup's
+// 256 lanes: softmax statistics (index -> table row: two dependent round trips), barrier, the same rows again for the
+// plan, barrier, tap records, barrier, and then the query's 24 samples two at a time -- a dozen dependent round trips,
+// 13.9 us per call for 4 tokens (profiles/r03by_decode_kernel_stats.csv; 64-lane workgroups of the
+// same kernel: 13.6, r04w).  Here a 64-lane workgroup (one wave: its barriers are free) owns ONE query:
+//   A  lane gl < n*L evaluates row gl of the plan ONCE (logits, softmax over the lane group, locations) -- the
+//      arithmetic, lane groups and reduction order of plan_forward_kernel, so locations and weights are the same bits;
+//   B  lane s evaluates sample s's tap record from A's row (LDS);
+//   C  the 64 / LPI lane groups take the samples round-robin, EVERY row load of the query in flight at once, and add
+//      their partial sums up in a fixed tree.
+// Three dependent global round trips (index, table rows, value rows).  Against the two-kernel path (and mmfs_sample_fwd)
+// the same products in fp32, summed in another order: equal within one rounding of the storage type, not bit for bit
+// (mmfs_sample_forward_groups tells a caller which kernel a shape takes).
+constexpr int kDecodeMaxQ = 8;          // queries per (sample, head) up to which a workgroup per query pays
+constexpr int kDecodeMaxK = 256;        // samples per query held as tap records
+constexpr int kDecodeBatch = 4;         // samples in flight per lane group (16 row loads per lane)
+
+template <typename T, int LPI, int P>
+__global__ void __launch_bounds__(64)
+mmfs_sample_decode(const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                   const T *__restrict__ off_q, const T *__restrict__ att_q,
+                   const T *__restrict__ off_tab, const T *__restrict__ att_tab,
+                   const int64_t *__restrict__ relpos, const float *__restrict__ ref, const float *__restrict__ ratios,
+                   T *__restrict__ out, float *__restrict__ sink, const Dims d, const PlanDims pd, const int G,
+                   const T *__restrict__ token)
+{
+    typedef Vec16<T> V;
+    constexpr int VEC = V::N;
+    constexpr int NSUB = 64 / LPI;
+    __shared__ float4 plan[kDecodeMaxK];                  // {x, y, weight} per sample, rounded to the storage type
+    __shared__ int rowinfo[64 * 3];                       // Hl, Wl, start of the rows' levels
+    __shared__ uint4 recs[2 * kDecodeMaxK];               // per sample: four row offsets, four corner weights
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x % d.H;
+    const int q = (blockIdx.x / d.H) % d.Nq, b = blockIdx.x / d.H / d.Nq;
+    const int nL = d.L;
+    const int64_t HD = (int64_t)d.H * d.D;
+    const T *slab = value + ((int64_t)b * d.S) * HD + (int64_t)h * d.D;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsrc = make_slab_rsrc(slab, ((int64_t)d.S * HD - (int64_t)h * d.D) * (int64_t)sizeof(T));
+    const float sink_logit = -logf((float)nL);
+    const int64_t tk = (int64_t)b * pd.Lq + q;
+
+    // ---- A: row gl of the plan (lanes of the first lane group; the others idle through the shuffles)
+    float sink_sum;
+    {
+        const int gl = tid;
+        const bool act = gl < nL;
+        float lg[P], oq[2 * P], ot[2 * P];
+        float m = sink_logit, rx = 0.f, ry = 0.f, sx = 0.f, sy = 0.f;
+        if (act) {
+            const int k = gl / pd.L, l = gl % pd.L;
+            const int64_t r = relpos[((int64_t)b * pd.Lr + (pd.Lr == 1 ? 0 : q)) * pd.n + k];
+            float a[P], t[P];
+            load_row<T, P>(att_q + tk * pd.ld_att + (h * pd.L + l) * P, a);
+            load_row<T, 2 * P>(off_q + tk * pd.ld_off + h * 2 * P, oq);
+            rx = ref[((int64_t)(pd.Nr == 1 ? 0 : b) * pd.Lq + q) * 2];
+            ry = ref[((int64_t)(pd.Nr == 1 ? 0 : b) * pd.Lq + q) * 2 + 1];
+            const int Hl = (int)shapes[2 * gl], Wl = (int)shapes[2 * gl + 1];
+            rowinfo[3 * gl] = Hl; rowinfo[3 * gl + 1] = Wl; rowinfo[3 * gl + 2] = (int)start[gl];
+            sx = ratios[l] / (float)Wl; sy = ratios[l] / (float)Hl;
+            load_row<T, P>(att_tab + ((r * pd.H + h) * pd.L + l) * P, t);
+            load_row<T, 2 * P>(off_tab + (r * pd.H + h) * 2 * P, ot);
+            const float pen = r == 0 ? -10000.f : 0.f;
+#pragma unroll
+            for (int p = 0; p < P; ++p) { lg[p] = a[p] + t[p] + pen; m = fmaxf(m, lg[p]); }
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; ++p) lg[p] = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < 2 * P; ++p) { oq[p] = 0.f; ot[p] = 0.f; }
+        }
+        m = rgroup_max(m, G);
+        float z = act ? __expf(sink_logit - m) : 0.f;
+        const float my_sink = z;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { lg[p] = __expf(lg[p] - m); z += lg[p]; }
+        z = rgroup_add(z, G);
+        const float inv = 1.f / z;
+        sink_sum = rgroup_add(my_sink, G) * inv;
+        if (tid == 0 && sink != nullptr) sink[tk * pd.H + h] = sink_sum;
+        if (act) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float wgt = lg[p] * inv;
+                // (as plan_forward_kernel: fp32 results behind an opaque register, then rounded to the storage type)
+                float lx = fmaf(oq[2 * p] + ot[2 * p], sx, rx), ly = fmaf(oq[2 * p + 1] + ot[2 * p + 1], sy, ry);
+                asm volatile("" : "+v"(lx), "+v"(ly), "+v"(wgt));
+                plan[gl * P + p] = make_float4(to_f32((T)lx), to_f32((T)ly), to_f32((T)wgt), 0.f);
+            }
+        }
+    }
+    sink_sum = __shfl(sink_sum, 0, 64);
+    __syncthreads();
+    // ---- B: one lane per sample: location -> tap record (as msda_fwd_vec does from its tensors)
+    for (int s = tid; s < d.K; s += 64) {
+        const int gl = s / P;
+        const float4 pl = plan[s];
+        const float a = pl.z;
+        const Tap<float> t = locate<float>(pl.x, pl.y, rowinfo[3 * gl], rowinfo[3 * gl + 1], rowinfo[3 * gl + 2]);
+        const float gy = 1.f - t.fy, gx = 1.f - t.fx;
+        uint32_t off[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            off[c] = (a != 0.f && t.row[c] >= 0) ? (uint32_t)t.row[c] * row_bytes : kOobOffset;
+        recs[2 * s] = make_uint4(off[0], off[1], off[2], off[3]);
+        recs[2 * s + 1] = make_uint4(__float_as_uint(gy * gx * a), __float_as_uint(gy * t.fx * a),
+                                     __float_as_uint(t.fy * gx * a), __float_as_uint(t.fy * t.fx * a));
+    }
+    __syncthreads();
+    // ---- C: lane group `sub` takes samples sub, sub + NSUB, ...; a batch's row loads all leave before the first is used
+    const int sub = tid / LPI, lig = tid % LPI;
+    const uint32_t lane_off = (uint32_t)(lig * 16);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < d.K; k0 += NSUB * kDecodeBatch) {
+        uint4 raw[kDecodeBatch][4], wq[kDecodeBatch];
+#pragma unroll
+        for (int u = 0; u < kDecodeBatch; ++u) {
+            const int kk = k0 + u * NSUB + sub;
+            uint4 rr = make_uint4(kOobOffset, kOobOffset, kOobOffset, kOobOffset);
+            wq[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (kk < d.K) { rr = recs[2 * kk]; wq[u] = recs[2 * kk + 1]; }
+            raw[u][0] = buffer_load16(rsrc, rr.x + lane_off);
+            raw[u][1] = buffer_load16(rsrc, rr.y + lane_off);
+            raw[u][2] = buffer_load16(rsrc, rr.z + lane_off);
+            raw[u][3] = buffer_load16(rsrc, rr.w + lane_off);
+        }
+#pragma unroll
+        for (int u = 0; u < kDecodeBatch; ++u) {
+            const float w4[4] = {__uint_as_float(wq[u].x), __uint_as_float(wq[u].y), __uint_as_float(wq[u].z), __uint_as_float(wq[u].w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v[VEC];
+                V::unpack(raw[u][c], v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w4[c], v[i], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= LPI; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    if (sub == 0) {
+        T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
+        if (token != nullptr) {
+            // (mmfs_sample_fwd's statement of the ignore-token term: sampled output, sink weight and product each rounded first)
+            const float sw = to_f32((T)sink_sum);
+            float tkn[VEC];
+            V::unpack(*reinterpret_cast<const uint4 *>(token + (int64_t)h * d.D + lig * VEC), tkn);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float prod = tkn[i] * sw;
+                asm volatile("" : "+v"(prod));
+                acc[i] = to_f32((T)acc[i]) + to_f32((T)prod);
+            }
+        }
+        *reinterpret_cast<uint4 *>(o) = V::pack(acc);
+    }
+}
+
+// lane groups that share a query's samples: 1 = mmfs_sample_fwd (sums in sample order, bit-identical to plan + op)
+int sample_groups(int64_t Lq, int64_t K, int64_t nL, int lpi)
+{
+    const char *e = getenv("MMFS_SAMPLE_DECODE");           // (read per call: the tests hold both kernels to the same goldens)
+    if ((e && e[0] == '0') || Lq > kDecodeMaxQ || K > kDecodeMaxK || nL > 64 || lpi > 32) return 1;
+    return 64 / lpi;
 }
 
 int esize(int dtype) { return dtype == MMFS_F32 ? 4 : (dtype == MMFS_F16 || dtype == MMFS_BF16) ? 2 : 0; }
@@ -721,33 +893,39 @@ int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shape
     int G = 4;
     while (G < d.L) G *= 2;                                                 // the plan kernel's lane-group width
     hipStream_t st = (hipStream_t)stream;
-    auto go_threads = [&](auto tag_t, auto tag_lpi, auto tag_p, auto tag_threads) {
+    auto go = [&](auto tag_t, auto tag_lpi, auto tag_p) {
         typedef decltype(tag_t) T;
-        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value, THREADS = decltype(tag_threads)::value;
-        constexpr int QPB = THREADS / LPI;
+        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value;
+        constexpr int QPB = kThreads / LPI;
         Dims dd = d;
         dd.q_tiles = (d.Nq + QPB - 1) / QPB;
         const int64_t blocks = (int64_t)d.B * dd.q_tiles * d.H;
         if (blocks > 0x7fffffffLL) return (int)MMFS_E_DIMS;
-        hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, st,
+        hipLaunchKernelGGL((mmfs_sample_fwd<T, LPI, PP>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                            (const T *)value, shapes, start, (const T *)off_q, (const T *)att_q,
                            (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, dd, pd, G,
                            (const T *)token);
         return (int)hipGetLastError();
     };
-    // A decode step (one new token per sequence) is a handful of queries per (b, h): a 256-lane workgroup holds 256 / LPI
-    // query slots, so its tap records come in chunks of 512 / (256 / LPI) samples -- 16 at the LLM's geometry, where a
-    // query has 24: two rounds of stage -> barrier -> gather, each a dependent global round trip, 13.9 us per call for 4
-    // queries (profiles/r03by_decode_kernel_stats.csv).  When a (b, h)'s queries fit ONE wave the kernel
-    // runs as 64-lane workgroups: 64 samples per chunk (one round), barriers that are a wave's own.  Same arithmetic in
-    // the same lane groups: bit-identical (MMFS_SAMPLE_WAVE=0: always 256 lanes).
-    static const bool wave_ok = !(getenv("MMFS_SAMPLE_WAVE") && getenv("MMFS_SAMPLE_WAVE")[0] == '0');
-    auto go = [&](auto tag_t, auto tag_lpi, auto tag_p) {
-        constexpr int LPI = decltype(tag_lpi)::value;
-        if (wave_ok && d.Nq * LPI <= 64) return go_threads(tag_t, tag_lpi, tag_p, std::integral_constant<int, 64>());
-        return go_threads(tag_t, tag_lpi, tag_p, std::integral_constant<int, kThreads>());
+    auto go_decode = [&](auto tag_t, auto tag_lpi, auto tag_p) {
+        typedef decltype(tag_t) T;
+        constexpr int LPI = decltype(tag_lpi)::value, PP = decltype(tag_p)::value;
+        if constexpr (LPI <= 32) {
+            hipLaunchKernelGGL((mmfs_sample_decode<T, LPI, PP>), dim3((unsigned)(d.B * d.Nq * d.H)), dim3(64), 0, st,
+                               (const T *)value, shapes, start, (const T *)off_q, (const T *)att_q,
+                               (const T *)off_tab, (const T *)att_tab, relpos, ref, ratios, (T *)out, sink, d, pd, G,
+                               (const T *)token);
+            return (int)hipGetLastError();
+        } else {
+            return (int)MMFS_E_UNSUPPORTED;
+        }
     };
+    const bool decode = sample_groups(Lq, d.K, d.L, lpi) > 1;
     auto by_p = [&](auto tag_t, auto tag_lpi) {
+        if (decode) {
+            if (P == 4) return go_decode(tag_t, tag_lpi, std::integral_constant<int, 4>());
+            return go_decode(tag_t, tag_lpi, std::integral_constant<int, 8>());
+        }
         if (P == 4) return go(tag_t, tag_lpi, std::integral_constant<int, 4>());
         return go(tag_t, tag_lpi, std::integral_constant<int, 8>());
     };
@@ -765,6 +943,15 @@ int mmfs_sample_forward_heads(int dtype, const void *value, const int64_t *shape
     if (dtype == MMFS_F32) return by_lpi(float());
     if (dtype == MMFS_F16) return by_lpi(half_t());
     return by_lpi(bf16_t());
+}
+
+int mmfs_sample_forward_groups(int dtype, int64_t Lq, int64_t D, int64_t nL, int64_t P)
+{
+    const int es = mmfs::esize(dtype);
+    if (!es || D <= 0 || D % (16 / es) || (P != 4 && P != 8) || nL <= 0 || Lq <= 0) return 0;
+    const int64_t lpi = D / (16 / es);
+    if (lpi > 64 || (lpi & (lpi - 1))) return 0;
+    return mmfs::sample_groups(Lq, nL * P, nL, (int)lpi);
 }
 
 }  // extern "C"

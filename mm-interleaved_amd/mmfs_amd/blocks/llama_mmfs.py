@@ -99,12 +99,15 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
         self.fold_gate = True                     # no-grad calls: tanh(gate) folded into the output projection (forward)
         self._gate_fold = FoldedLinear()
 
-    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None, image_ranks=None):
+    def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None, image_ranks=None,
+                residual=None):
         """hidden_states [B, Lq, hidden]; vision_hidden_states [B, n, sum hw, image_embed_dim];
         cross_attention_mask [B, Lq', n] (float, 1 = visible) -> [B, Lq, hidden].
         ``value`` (an addition): this layer's ``value_proj(norm2(vision_hidden_states))`` [B, n, sum hw, d_inner] as
         a ``LlamaMMFSSchedule`` projected it for all layers at once; the bank is then only looked at for its shape.
-        ``image_ranks`` (another): ``LlamaMMFSSchedule.image_ranks(cross_attention_mask, Lq)``, made once per step."""
+        ``image_ranks`` (another): ``LlamaMMFSSchedule.image_ranks(cross_attention_mask, Lq)``, made once per step.
+        ``residual`` (a third) [B, Lq, hidden]: the result is ``residual + layer(...)`` -- the decoder layer's own next
+        statement (modeling_llama_mmfs.py:700-717), which without gradients rides in the output projection's kernel."""
         hidden_states = self.norm1(hidden_states)
         if value is None:
             vision_hidden_states = self.norm2(vision_hidden_states)
@@ -119,11 +122,12 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
             return self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                              input_spatial_shapes=shapes, input_level_start_index=start, input_padding_mask=None,
                              attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks,
-                             output_weights=folded)
+                             output_weights=folded, output_residual=residual)
         out = self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                         input_spatial_shapes=shapes, input_level_start_index=start,
                         input_padding_mask=None, attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks)
-        return out * self._gate()
+        out = out * self._gate()
+        return out if residual is None else residual + out
 
     def _gate(self):
         """tanh(gate) (modeling_llama_mmfs.py:356): a one-element kernel per layer and step; without gradients it is

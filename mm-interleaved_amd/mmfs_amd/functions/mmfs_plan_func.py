@@ -28,6 +28,8 @@ _lib.mmfs_sample_forward_token.restype = _int
 _lib.mmfs_sample_forward_token.argtypes = [_int] + [_vp] * 13 + [_i64] * 11 + [_vp]
 _lib.mmfs_sample_forward_heads.restype = _int
 _lib.mmfs_sample_forward_heads.argtypes = [_int] + [_vp] * 5 + [_i64] * 2 + [_vp] * 8 + [_i64] * 11 + [_vp]
+_lib.mmfs_sample_forward_groups.restype = _int
+_lib.mmfs_sample_forward_groups.argtypes = [_int] + [_i64] * 4
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -106,10 +108,18 @@ def _token_rows(t, vec):
     return t.contiguous(), 0
 
 
+def sample_forward_groups(dtype, Lq, D, nL, P):
+    """Lane groups that share one query's samples in ``mmfs_sample_forward`` for this shape (include/mmfs_msda.h
+    ``mmfs_sample_forward_groups``): 1 = summed in sample order, bit-identical to the two kernels; > 1 = a decode-sized
+    call (at most 8 queries per (sample, head)), equal within one rounding of the storage type; 0 = not served."""
+    return int(_lib.mmfs_sample_forward_groups(_CODE[dtype], Lq, D, nL, P)) if dtype in _CODE else 0
+
+
 def mmfs_sample_forward(value, shapes, start, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P, token=None):
     """Plan -> sampler in ONE kernel (``mmfs_sample_forward`` in include/mmfs_msda.h):
     the locations / weights [N, Lq, H, n*L, P(, 2)] are never written.  Inference only (no autograd graph);
-    bit-identical to ``MMFSPlanFunction`` + ``MSDeformAttnFunction``.  value [N, S, H, D]; the other
+    bit-identical to ``MMFSPlanFunction`` + ``MSDeformAttnFunction`` (decode-sized calls: the same products with the fp32
+    sums in another order, see ``sample_forward_groups``).  value [N, S, H, D]; the other
     arguments as for ``MMFSPlanFunction``.  Returns (out [N, Lq, H*D], sink [N, Lq, H] fp32), or None when
     the shape is outside the fused kernel's range (the caller then runs the two kernels).  ``token`` [.., H, D]
     (MMFS's ignore token): ``out + token * sink`` is formed inside the kernel, with the framework statement's roundings."""

@@ -49,7 +49,8 @@ class GraphedMMFSNet:
             # tables) at the addresses they had during the capture: hold them, so that an invalidation of the modules'
             # caches (a mode change, a state-dict load, ``invalidate_caches()``) cannot free what the graph replays.
             # A graph bakes the parameters of its capture in: re-capture after they change.
-            self._pinned = [(b.mmfs._tables, b._conv_fold._kept, b.__dict__.get("_pos_cache")) for b in net._blocks()]
+            self._pinned = [(b.mmfs._tables, b._conv_fold._kept, b.__dict__.get("_pos_cache"), b.mmfs.__dict__.get("_ratios_f32"))
+                            for b in net._blocks()]
 
     @torch.no_grad()
     def __call__(self, sample, down_block_res_samples):
@@ -66,7 +67,7 @@ class GraphedLlamaMMFSStack:
     8-10 layers are ~850 small launches that the host issues several times more slowly than the GPU runs them.
 
     ``g = GraphedLlamaMMFSStack(layers, hidden, features, mask)`` projects the bank once (LlamaMMFSSchedule), records
-    ``for k: h = h + layers[k](h, features, mask, value=bank.values[k], image_ranks=ranks)`` over a static input buffer and
+    ``for k: h = layers[k](h, features, mask, value=bank.values[k], image_ranks=ranks, residual=h)`` (= h + layer(h)) over a static input buffer and
     ``g(hidden)`` replays it.  The dense LLaMA layers that sit between the MMFS layers in the real decoder are out
     of scope here (a caller that graphs its whole decode step captures these layers with the rest: the op and the
     modules are capture-safe as they are -- no device->host copy, current stream, allocator workspaces).
@@ -94,12 +95,13 @@ class GraphedLlamaMMFSStack:
             with torch.cuda.graph(self.graph):
                 self._out = self._run()
             # (as GraphedMMFSNet: what the recorded kernels read stays alive with the graph)
-            self._pinned = [(l.attn._tables, l._gate_fold._kept, getattr(l, "_gate_tanh", None)) for l in self.layers]
+            self._pinned = [(l.attn._tables, l._gate_fold._kept, getattr(l, "_gate_tanh", None), l.attn.__dict__.get("_ratios_f32"))
+                            for l in self.layers]
 
     def _run(self):
         h = self._hidden
         for k, layer in enumerate(self.layers):
-            h = h + layer(h, self._bank.bank, self._mask, value=self._bank.values[k], image_ranks=self._ranks)
+            h = layer(h, self._bank.bank, self._mask, value=self._bank.values[k], image_ranks=self._ranks, residual=h)
         return h
 
     @torch.no_grad()

@@ -245,7 +245,7 @@ class MMFS(CacheInvalidation, nn.Module):
                 # returns the op's output and the sink weights instead of loc / attn
                 # (``sampler[2]``: the ignore token, whose term the kernel then adds itself -- the sink weights come back None)
                 res = mmfs_sample_forward(sampler[0], input_spatial_shapes, sampler[1], *heads[:4], relpos,
-                                          heads[5], self.scale_ratios, H, L, P, token=sampler[2])
+                                          heads[5], self._ratios32(), H, L, P, token=sampler[2])
                 if res is not None:
                     return None, res[0], (res[1] if sampler[2] is None else None)
             loc, attn, sink_sum = MMFSPlanFunction.apply(off_q.contiguous(), att_q.contiguous(), *heads[2:])
@@ -284,25 +284,43 @@ class MMFS(CacheInvalidation, nn.Module):
                 f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         return loc, attn, sink_w
 
-    def _project_out(self, out, output_weights):
-        """``output_proj`` (or the caller's folded weights in its place); a handful of token rows without gradients: the
-        weight-streaming kernel (functions/linear_func.py)."""
+    def _ratios32(self):
+        """``scale_ratios`` in fp32, as the fused sampler reads it: a module in 16-bit storage holds the buffer in 16 bits,
+        and a decode step converted it once per layer (a kernel of its own, 8 per step).  Kept like the tables."""
+        r = self.scale_ratios
+        if r.dtype == torch.float32:
+            return r
+        if torch.is_grad_enabled() or self.training:
+            return r.float()
+        sig = (cache_epoch(), r.data_ptr(), tensor_version(r), torch.is_inference_mode_enabled())
+        hit = self.__dict__.get("_ratios_f32")
+        if hit is None or hit[0] != sig:
+            hit = self.__dict__["_ratios_f32"] = (sig, r.float())
+        return hit[1]
+
+    def _project_out(self, out, output_weights, residual=None):
+        """``output_proj`` (or the caller's folded weights in its place), ``+ residual`` if the caller handed one; a
+        handful of token rows without gradients: the weight-streaming kernel (functions/linear_func.py), the residual
+        added in its store."""
         if output_weights is None:
             proj = self.output_proj
             if torch.is_grad_enabled() or type(proj) is not nn.Linear or not hook_free(proj):
-                return proj(out)                  # (with gradients, or wrapped / hooked: the layer is called as a layer)
+                y = proj(out)                     # (with gradients, or wrapped / hooked: the layer is called as a layer)
+                return y if residual is None else residual + y
             output_weights = (proj.weight, proj.bias)
-        return small_linear(out, *output_weights)
+        return small_linear(out, *output_weights, residual=residual)
 
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None,
-                output_weights=None):
+                output_weights=None, output_residual=None):
         """Arguments and result as mmfs.py:120-141 (``value`` is an addition: the caller's own
         ``value_proj(input_flatten)`` [N, n, hw, d_inner], e.g. one an ``MMFSNet`` projected for
         all its blocks at once; ``input_flatten`` is then only looked at for its shape; ``image_ranks`` another: this
         module's ``_image_relpos(attention_mask, Lq)`` as a caller made it once for several layers; ``output_weights``
-        a third: (weight, bias) to use in ``output_proj``'s place -- a caller's ``FoldedLinear`` of it with what follows):
+        a third: (weight, bias) to use in ``output_proj``'s place -- a caller's ``FoldedLinear`` of it with what follows;
+        ``output_residual`` [N, Lq, d_out] a fourth: added to the projected output -- the decoder layer's
+        ``residual + hidden_states``, which a decode step then gets inside the projection's kernel):
         query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
         input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
         input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
@@ -335,7 +353,7 @@ class MMFS(CacheInvalidation, nn.Module):
         if loc is None:
             out = attn                            # (the fused kernel's result)
             if sink_w is None:                    # ... the ignore token's term included
-                return self._project_out(out, output_weights)
+                return self._project_out(out, output_weights, output_residual)
         else:
             # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
             # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
@@ -344,4 +362,4 @@ class MMFS(CacheInvalidation, nn.Module):
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
-        return self._project_out(out, output_weights)
+        return self._project_out(out, output_weights, output_residual)

@@ -704,6 +704,10 @@ def test_llama_layer_in_inference_mode_then_no_grad_then_training(oracle_op):
         d = l(h, f, mask)
     assert float((d - b).abs().max()) > 1e-6
     close(d, (l(h, f, mask)).detach().numpy(), 1e-12)
+    # ``residual=``: the decoder layer's own next statement, with and without gradients
+    with torch.no_grad():
+        close(l(h, f, mask, residual=h), (h + d).numpy(), 1e-12)
+    close(l(h, f, mask, residual=h).detach(), (h + d).numpy(), 1e-12)
 
 
 def test_mmfs_net_in_inference_mode_then_training(oracle_op):

@@ -465,12 +465,15 @@ def test_mmfs_net_at_512px_geometry(oracle_op_cpu):
 # ---------------------------------------------------------------- plan -> sampler in one kernel (N1)
 @pytest.mark.parametrize("name", P48_CASES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype):
+@pytest.mark.parametrize("decode_kernel", [False, True])
+def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype, decode_kernel, monkeypatch):
     """Inference (no autograd graph): ``mmfs_sample_forward`` evaluates the plan inside the sampler's staging,
     loc / attn are never written.  Same arithmetic as the two kernels -> the module output must be EQUAL, bit
     for bit; in fp32 it is also held to the reference's golden.  The run must really take the fused kernel."""
     import MultiScaleDeformableAttention as MSDA
     from mmfs_amd.modules import MMFS
+    if not decode_kernel:
+        monkeypatch.setenv("MMFS_SAMPLE_DECODE", "0")          # (most goldens are decode-sized: hold mmfs_sample_fwd to them too)
     z = load_golden(name)
     cfg = ast.literal_eval(str(z["cfg"]))
     with contextlib.redirect_stdout(io.StringIO()):
@@ -489,7 +492,14 @@ def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype):
             MSDA._event_log = None
         names = {n for n, _, _ in log}
         assert ("mmfs_sample_fwd" in names) == fused and ("mmfs_plan_fwd" in names) == (not fused), names
-    assert torch.equal(outs[True], outs[False])
+    # (a decode-sized golden takes mmfs_sample_decode: the same products, the fp32 sums in another order)
+    from mmfs_amd.functions.mmfs_plan_func import sample_forward_groups
+    Lq, nL = int(z["query"].shape[1]), int(z["spatial_shapes"].shape[0])
+    in_order = sample_forward_groups(dtype, Lq, m.d_inner // m.n_heads, nL, m.n_points) == 1
+    assert in_order or decode_kernel
+    same = (lambda a, b: torch.equal(a, b)) if in_order else \
+        (lambda a, b: rel_err(a, b.double().cpu()) <= {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype])
+    assert same(outs[True], outs[False])
     if dtype == torch.float32:
         assert rel_err(outs[True], z["out"]) <= 2e-5
     # a non-zero ignore token (the reference initialises it to zeros and freezes it; a checkpoint may hold anything): its
@@ -500,7 +510,7 @@ def test_fused_sampler_is_bit_identical_to_plan_plus_op(name, dtype):
         m.fused_sampler = fused
         with torch.no_grad():
             outs[fused] = m(*args)
-    assert torch.equal(outs[True], outs[False]) and bool(torch.isfinite(outs[True]).all())
+    assert same(outs[True], outs[False]) and bool(torch.isfinite(outs[True]).all())
     m.ignore_token.zero_()
 
 
@@ -782,6 +792,51 @@ def test_fused_sampler_takes_the_query_heads_as_columns_of_one_matrix(dtype, Lq)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.bfloat16, 16), (torch.float16, 128), (torch.float32, 64),
+                                     (torch.float32, 128), (torch.float32, 256)])
+@pytest.mark.parametrize("Lq,n,P", [(1, 1, 8), (3, 4, 8), (8, 2, 4), (2, 7, 8)])
+def test_decode_sized_sampler_against_the_in_order_kernel(dtype, D, Lq, n, P):
+    """``mmfs_sample_decode`` (at most 8 queries per (sample, head): a workgroup per query, every row load in flight, the
+    lane groups' partial sums added in a tree) against ``mmfs_sample_fwd`` on the SAME queries -- reached by appending
+    queries until the call is no longer decode-sized.  Sink weights: equal (same arithmetic, same lane groups).
+    Outputs: within one rounding of the storage type (fp32: of the sums' magnitude), and deterministic."""
+    from mmfs_amd.functions.mmfs_plan_func import mmfs_sample_forward, sample_forward_groups
+    from mmfs_amd.levels import make_level_tables
+    g = torch.Generator().manual_seed(100 * Lq + 10 * n + P)
+    N, H, L, M = 3, 4, 3, 9
+    sh, st, S = make_level_tables([(8, 8), (4, 4), (2, 2)], n, DEV)
+    value = torch.randn(N, S, H, D, generator=g).to(DEV, dtype)
+    Lq_big = Lq + 9
+    off_q = (torch.randn(N, Lq_big, H * P * 2, generator=g) * 2.0).to(DEV, dtype)
+    att_q = torch.randn(N, Lq_big, H * L * P, generator=g).to(DEV, dtype)
+    off_tab = (torch.randn(M, H * P * 2, generator=g) * 0.5).to(DEV, dtype)
+    att_tab = (torch.randn(M, H * L * P, generator=g) * 0.3).to(DEV, dtype)
+    relpos = torch.randint(0, M, (N, 1, n), generator=g).to(DEV)          # (0 = "image not visible": the -10000 penalty)
+    ref = torch.rand(N, Lq_big, 2, generator=g).to(DEV)
+    ratios = torch.tensor([1.0, 0.5, 0.25], device=DEV)
+    tok = torch.randn(H, D, generator=g).to(DEV, dtype)
+    groups = sample_forward_groups(dtype, Lq, D, n * L, P)
+    lpi = D * value.element_size() // 16
+    assert groups == (64 // lpi if lpi <= 32 else 1) and sample_forward_groups(dtype, Lq_big, D, n * L, P) == 1
+    small = lambda: mmfs_sample_forward(value, sh, st, off_q[:, :Lq].contiguous(), att_q[:, :Lq].contiguous(), off_tab, att_tab,
+                                        relpos, ref[:, :Lq].contiguous(), ratios, H, L, P, token=tok)
+    got, big = small(), mmfs_sample_forward(value, sh, st, off_q, att_q, off_tab, att_tab, relpos, ref, ratios, H, L, P, token=tok)
+    assert got is not None and big is not None
+    assert torch.equal(got[1], big[1][:, :Lq])
+    want = big[0][:, :Lq]
+    assert bool(torch.isfinite(got[0]).all()) and float(want.float().abs().max()) > 1e-2
+    if groups == 1:
+        assert torch.equal(got[0], want)
+    else:
+        eps = {torch.float32: 2.0 ** -20, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
+        d = (got[0].double() - want.double()).abs()
+        # (one rounding of the storage type where the fp32 sums -- equal to ~2^-20 of the largest -- fall either side of a tie)
+        assert bool((d <= eps * want.double().abs() + 2.0 ** -20 * float(want.abs().max())).all()), float(d.max())
+    again = small()
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
 @pytest.mark.parametrize("shape", [(4, 640, 4096), (1, 4096, 1024), (8, 640, 4096), (3, 37, 72), (5, 1, 8), (2, 1000, 2048)])
 @pytest.mark.parametrize("with_bias", [True, False])
@@ -810,6 +865,10 @@ def test_small_linear_kernel_matches_the_library(dtype, tol, shape, with_bias):
     err = float(((got[0].double() - want).abs() / scale).max())
     lib_err = float(((lib.double() - want).abs() / scale).max())
     assert err <= max(tol, 1.5 * lib_err), (err, lib_err)
+    # + residual in the kernel's store: the bits of the kernel's result followed by the framework's add
+    res = torch.randn(1, M, N, generator=g).to(DEV, dtype)
+    with torch.no_grad():
+        assert torch.equal(small_linear(x.view(1, M, K), w, b, residual=res), res + got)
     # not taken: more than 8 rows, a gradient wanted, fp32 storage
     log2 = []
     MSDA._event_log = log2
@@ -945,6 +1004,7 @@ def test_llm_layers_16bit_no_grad_at_vicuna_7b_geometry_and_batch(dtype, bar, Lq
             x = x + l(x, fd, md, value=bank.values[k], image_ranks=ranks)
     graphed = GraphedLlamaMMFSStack(gpu, hd, fd, md)
     y = graphed(hd).clone()
+    assert torch.equal(x, y)            # (the replay adds the residual in the projection's store: the same two roundings)
     scale = float(want.abs().max())
     for name, got in (("eager", x), ("graph replay", y)):
         err = float((got.double().cpu() - want).abs().max()) / scale

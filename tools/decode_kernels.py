@@ -26,7 +26,7 @@ def step():
         ranks = sched.image_ranks(mask, Lq)
         h = hidden
         for k, l in enumerate(layers):
-            h = h + l(h, feats, mask, value=bank.values[k], image_ranks=ranks)
+            h = l(h, feats, mask, value=bank.values[k], image_ranks=ranks, residual=h)
         return h
 
 
