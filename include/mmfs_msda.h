@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 10  /* 10: + mmfs_sample_forward_groups, mmfs_linear_small_add; mmfs_sample_forward* serve at most 8 queries per (sample,
+#define MMFS_MSDA_ABI_VERSION 10  /* 10: + mmfs_sample_forward_groups, mmfs_linear_small_add, mmfs_plan_forward_heads / mmfs_plan_backward_heads; mmfs_sample_forward* serve at most 8 queries per (sample,
                                    *     head) -- a decode step -- with a workgroup per query (same products, another order of
                                    *     the fp32 sums: see there)
                                    * 9: + MMFS_FWD_SLICES (the forward's third formulation, csrc/msda_fwd_q8.hip);
@@ -388,6 +388,26 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
                        float *d_off_q, float *d_att_q, float *d_off_tab, float *d_att_tab,
                        int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
                        int64_t Lr, int64_t Nr, void *stream);
+
+/* The two calls for a caller that evaluates both query heads as ONE GEMM (their weights stacked: both read the same
+ * activations, mmfs.py:174-176) and both tables as one: ``off_q`` / ``att_q`` are two column ranges of one
+ * [N*Lq, H*2P + H*L*P] matrix -- token rows ``ld_off`` / ``ld_att`` elements apart (0 = packed) --, ``off_tab`` / ``att_tab``
+ * likewise of one [M, ...] matrix (``ld_toff`` / ``ld_tatt``); the backward writes the gradients in the same layout, the
+ * query-side ones in the storage type when ``q_grads_in_storage_type`` (one rounding of the fp32 sums, what a caller's cast
+ * of the fp32 tensors does) -- so the gradient of the stacked GEMM's result is ONE tensor, made by this kernel. */
+int mmfs_plan_forward_heads(int dtype, const void *off_q, const void *att_q, int64_t ld_off, int64_t ld_att,
+                            const void *off_tab, const void *att_tab, int64_t ld_toff, int64_t ld_tatt,
+                            const int64_t *relpos, const float *ref,
+                            const int64_t *shapes, const float *ratios, void *loc, void *attn, float *sink,
+                            int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                            int64_t Lr, int64_t Nr, void *stream);
+int mmfs_plan_backward_heads(int dtype, const void *grad_loc, const void *grad_attn, const float *grad_sink,
+                             const void *attn, const float *sink, const int64_t *relpos,
+                             const int64_t *shapes, const float *ratios,
+                             void *d_off_q, void *d_att_q, int64_t ld_off, int64_t ld_att, int q_grads_in_storage_type,
+                             float *d_off_tab, float *d_att_tab, int64_t ld_toff, int64_t ld_tatt,
+                             int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                             int64_t Lr, int64_t Nr, void *stream);
 
 /*
  * The plan feeding the sampler (second half): mmfs_plan_forward followed by

@@ -36,7 +36,8 @@ constexpr int kQueryRun = 8;            // backward: consecutive queries a lane 
 
 struct PlanDims {
     int N, Lq, H, L, P, n, M, Lr, Nr;
-    int ld_off, ld_att;     // sampler only: elements between the rows of two tokens in off_q / att_q (H*2P / H*L*P when packed)
+    int ld_off, ld_att;     // elements between the rows of two tokens in off_q / att_q (H*2P / H*L*P when packed)
+    int ld_toff, ld_tatt;   // the same for the two tables' rows (plan kernels; the sampler's tables are packed)
 };
 
 // lane group: G = 2^k lanes, one per (image, level) row of P points; reductions stay inside it
@@ -98,8 +99,8 @@ plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
     float m = sink_logit;
     if (act) {
         float a[P], t[P];
-        load_row<T, P>(att_q + (it * d.L + l) * P, a);
-        load_row<T, P>(att_tab + ((r * d.H + h) * d.L + l) * P, t);
+        load_row<T, P>(att_q + nq * d.ld_att + (h * d.L + l) * P, a);
+        load_row<T, P>(att_tab + r * d.ld_tatt + (h * d.L + l) * P, t);
         const float pen = r == 0 ? -10000.f : 0.f;          // image not visible (mmfs.py:203-218)
 #pragma unroll
         for (int p = 0; p < P; ++p) { lg[p] = a[p] + t[p] + pen; m = fmaxf(m, lg[p]); }
@@ -123,8 +124,8 @@ plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
     store_row<T, P>(attn + row * P, lg);
     // locations: ref + (offset_q + offset_table) * ratio_l / (W, H)        (mmfs.py:193-198, 243-250)
     float oq[2 * P], ot[2 * P], xy[2 * P];
-    load_row<T, 2 * P>(off_q + it * 2 * P, oq);
-    load_row<T, 2 * P>(off_tab + (r * d.H + h) * 2 * P, ot);
+    load_row<T, 2 * P>(off_q + nq * d.ld_off + h * 2 * P, oq);
+    load_row<T, 2 * P>(off_tab + r * d.ld_toff + h * 2 * P, ot);
     const float rx = ref[((int64_t)(d.Nr == 1 ? 0 : nb) * d.Lq + q) * 2];
     const float ry = ref[((int64_t)(d.Nr == 1 ? 0 : nb) * d.Lq + q) * 2 + 1];
     const float sx = ratios[l] / (float)shapes[2 * gl + 1], sy = ratios[l] / (float)shapes[2 * gl];
@@ -147,13 +148,14 @@ plan_forward_kernel(const T *__restrict__ off_q, const T *__restrict__ att_q,
 // registers, flushing them with P + 2P float atomics when the relative position changes or the
 // run ends.  d_att_q / d_off_q need the sum over the images of a level / over the levels of an
 // image: done through a per-group LDS slab.
-template <typename T, int P, int G>
+// (OT: the type the query-side gradients are stored in -- fp32, or the storage type for a caller that casts them anyway)
+template <typename T, typename OT, int P, int G>
 __global__ void __launch_bounds__(kThreads)
 plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_attn,
                      const float *__restrict__ grad_sink, const T *__restrict__ attn,
                      const float *__restrict__ sink, const int64_t *__restrict__ relpos,
                      const int64_t *__restrict__ shapes, const float *__restrict__ ratios,
-                     float *__restrict__ d_off_q, float *__restrict__ d_att_q,
+                     OT *__restrict__ d_off_q, OT *__restrict__ d_att_q,
                      float *__restrict__ d_off_tab, float *__restrict__ d_att_tab, const PlanDims d)
 {
     constexpr int GPB = kThreads / G;                       // lane groups per workgroup
@@ -179,8 +181,8 @@ plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_
     for (int p = 0; p < P; ++p) { t_att[p] = 0.f; t_off[2 * p] = 0.f; t_off[2 * p + 1] = 0.f; }
     auto flush = [&]() {
         if (t_rp < 0) return;
-        float *ta = d_att_tab + ((t_rp * d.H + h) * d.L + l) * P;
-        float *to = d_off_tab + (t_rp * d.H + h) * 2 * P;
+        float *ta = d_att_tab + t_rp * d.ld_tatt + (h * d.L + l) * P;
+        float *to = d_off_tab + t_rp * d.ld_toff + h * 2 * P;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             __hip_atomic_fetch_add(ta + p, t_att[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -233,7 +235,7 @@ plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_
             for (int kk = 0; kk < d.n; ++kk)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] += slab[grp][kk * d.L + gl][p];
-            store_row<float, P>(d_att_q + (item * d.L + gl) * P, acc);
+            store_row<OT, P>(d_att_q + (item / d.H) * d.ld_att + (h * d.L + gl) * P, acc);
         }
         // d_off_q[item, :, :] = sum over all rows (images and levels) of doff  (row 0 does it)
         if (unit_ok && gl == 0) {
@@ -243,7 +245,7 @@ plan_backward_kernel(const T *__restrict__ grad_loc, const T *__restrict__ grad_
             for (int rr = 0; rr < nL; ++rr)
 #pragma unroll
                 for (int p = 0; p < 2 * P; ++p) acc[p] += slab[grp][rr][P + p];
-            store_row<float, 2 * P>(d_off_q + item * 2 * P, acc);
+            store_row<OT, 2 * P>(d_off_q + (item / d.H) * d.ld_off + h * 2 * P, acc);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -735,7 +737,8 @@ int check_dims(int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n
     if (N * Lq * H > lim) return MMFS_E_DIMS;
     d->N = (int)N; d->Lq = (int)Lq; d->H = (int)H; d->L = (int)L; d->P = (int)P; d->n = (int)n;
     d->M = (int)M; d->Lr = (int)Lr; d->Nr = (int)Nr;
-    d->ld_off = d->ld_att = 0;
+    d->ld_off = d->ld_toff = (int)(H * 2 * P);
+    d->ld_att = d->ld_tatt = (int)(H * L * P);
     return MMFS_OK;
 }
 
@@ -755,14 +758,36 @@ static int for_group(int nL, F &&f)
 
 extern "C" {
 
+// rows `ld` elements apart (0 = packed, `cols`), vector accesses of `vec` elements of `es` bytes: dimensions and alignment
+static int heads_rows(int64_t &ld, int64_t cols, const void *p, int64_t vec, int64_t es)
+{
+    if (ld == 0) ld = cols;
+    if (ld < cols || ld > 0x7fffffffLL) return MMFS_E_DIMS;
+    const int64_t a = vec * es < 16 ? vec * es : 16;                   // (load_row / store_row: accesses of at most 16 bytes)
+    if ((ld * es) % a || (uintptr_t)p % (uintptr_t)a) return MMFS_E_ALIGN;
+    return MMFS_OK;
+}
+
 int mmfs_plan_forward(int dtype, const void *off_q, const void *att_q, const void *off_tab,
                       const void *att_tab, const int64_t *relpos, const float *ref,
                       const int64_t *shapes, const float *ratios, void *loc, void *attn, float *sink,
                       int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
                       int64_t Lr, int64_t Nr, void *stream)
 {
+    return mmfs_plan_forward_heads(dtype, off_q, att_q, 0, 0, off_tab, att_tab, 0, 0, relpos, ref, shapes, ratios, loc, attn,
+                                   sink, N, Lq, H, L, P, n, M, Lr, Nr, stream);
+}
+
+int mmfs_plan_forward_heads(int dtype, const void *off_q, const void *att_q, int64_t ld_off, int64_t ld_att,
+                            const void *off_tab, const void *att_tab, int64_t ld_toff, int64_t ld_tatt,
+                            const int64_t *relpos, const float *ref,
+                            const int64_t *shapes, const float *ratios, void *loc, void *attn, float *sink,
+                            int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                            int64_t Lr, int64_t Nr, void *stream)
+{
     using namespace mmfs;
-    if (!esize(dtype)) return MMFS_E_DTYPE;
+    const int es = esize(dtype);
+    if (!es) return MMFS_E_DTYPE;
     PlanDims d;
     const int rc = check_dims(N, Lq, H, L, P, n, M, Lr, Nr, &d);
     if (rc) return rc;
@@ -770,6 +795,11 @@ int mmfs_plan_forward(int dtype, const void *off_q, const void *att_q, const voi
     if (items == 0) return MMFS_OK;
     if (!off_q || !att_q || !off_tab || !att_tab || !relpos || !ref || !shapes || !ratios || !loc || !attn || !sink)
         return MMFS_E_NULLPTR;
+    int rr;
+    if ((rr = heads_rows(ld_off, H * 2 * P, off_q, 2 * P, es)) || (rr = heads_rows(ld_att, H * L * P, att_q, P, es)) ||
+        (rr = heads_rows(ld_toff, H * 2 * P, off_tab, 2 * P, es)) || (rr = heads_rows(ld_tatt, H * L * P, att_tab, P, es)))
+        return rr;
+    d.ld_off = (int)ld_off; d.ld_att = (int)ld_att; d.ld_toff = (int)ld_toff; d.ld_tatt = (int)ld_tatt;
     hipStream_t st = (hipStream_t)stream;
     auto go = [&](auto tag_t, auto tag_p) {
         typedef decltype(tag_t) T;
@@ -800,8 +830,21 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
                        int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
                        int64_t Lr, int64_t Nr, void *stream)
 {
+    return mmfs_plan_backward_heads(dtype, grad_loc, grad_attn, grad_sink, attn, sink, relpos, shapes, ratios, d_off_q, d_att_q,
+                                    0, 0, 0, d_off_tab, d_att_tab, 0, 0, N, Lq, H, L, P, n, M, Lr, Nr, stream);
+}
+
+int mmfs_plan_backward_heads(int dtype, const void *grad_loc, const void *grad_attn, const float *grad_sink,
+                             const void *attn, const float *sink, const int64_t *relpos,
+                             const int64_t *shapes, const float *ratios,
+                             void *d_off_q, void *d_att_q, int64_t ld_off, int64_t ld_att, int q_grads_in_storage_type,
+                             float *d_off_tab, float *d_att_tab, int64_t ld_toff, int64_t ld_tatt,
+                             int64_t N, int64_t Lq, int64_t H, int64_t L, int64_t P, int64_t n, int64_t M,
+                             int64_t Lr, int64_t Nr, void *stream)
+{
     using namespace mmfs;
-    if (!esize(dtype)) return MMFS_E_DTYPE;
+    const int es = esize(dtype);
+    if (!es) return MMFS_E_DTYPE;
     PlanDims d;
     const int rc = check_dims(N, Lq, H, L, P, n, M, Lr, Nr, &d);
     if (rc) return rc;
@@ -809,6 +852,12 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
     if (!grad_loc || !grad_attn || !attn || !sink || !relpos || !shapes || !ratios || !d_off_q || !d_att_q ||
         !d_off_tab || !d_att_tab)
         return MMFS_E_NULLPTR;
+    const int qes = q_grads_in_storage_type ? es : 4;
+    int rr;
+    if ((rr = heads_rows(ld_off, H * 2 * P, d_off_q, 2 * P, qes)) || (rr = heads_rows(ld_att, H * L * P, d_att_q, P, qes)) ||
+        (rr = heads_rows(ld_toff, H * 2 * P, d_off_tab, 1, 4)) || (rr = heads_rows(ld_tatt, H * L * P, d_att_tab, 1, 4)))
+        return rr;
+    d.ld_off = (int)ld_off; d.ld_att = (int)ld_att; d.ld_toff = (int)ld_toff; d.ld_tatt = (int)ld_tatt;
     const int64_t units = N * H * ((Lq + kQueryRun - 1) / kQueryRun);
     hipStream_t st = (hipStream_t)stream;
     auto go = [&](auto tag_t, auto tag_p) {
@@ -817,9 +866,14 @@ int mmfs_plan_backward(int dtype, const void *grad_loc, const void *grad_attn, c
         return for_group<T, PP>(d.n * d.L, [&](auto tag_g) {
             constexpr int G = decltype(tag_g)::value;
             const unsigned blocks = (unsigned)((units + kThreads / G - 1) / (kThreads / G));
-            hipLaunchKernelGGL((plan_backward_kernel<T, PP, G>), dim3(blocks), dim3(kThreads), 0, st,
-                               (const T *)grad_loc, (const T *)grad_attn, grad_sink, (const T *)attn, sink,
-                               relpos, shapes, ratios, d_off_q, d_att_q, d_off_tab, d_att_tab, d);
+            if (q_grads_in_storage_type && !std::is_same<T, float>::value)
+                hipLaunchKernelGGL((plan_backward_kernel<T, T, PP, G>), dim3(blocks), dim3(kThreads), 0, st,
+                                   (const T *)grad_loc, (const T *)grad_attn, grad_sink, (const T *)attn, sink,
+                                   relpos, shapes, ratios, (T *)d_off_q, (T *)d_att_q, d_off_tab, d_att_tab, d);
+            else
+                hipLaunchKernelGGL((plan_backward_kernel<T, float, PP, G>), dim3(blocks), dim3(kThreads), 0, st,
+                                   (const T *)grad_loc, (const T *)grad_attn, grad_sink, (const T *)attn, sink,
+                                   relpos, shapes, ratios, (float *)d_off_q, (float *)d_att_q, d_off_tab, d_att_tab, d);
             return (int)hipGetLastError();
         });
     };

@@ -123,11 +123,16 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
                              input_spatial_shapes=shapes, input_level_start_index=start, input_padding_mask=None,
                              attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks,
                              output_weights=folded, output_residual=residual)
+        if residual is not None:
+            # the gate and the residual sum ride with the output projection (``GatedProjectionFunction`` with gradients)
+            return self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
+                             input_spatial_shapes=shapes, input_level_start_index=start, input_padding_mask=None,
+                             attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks,
+                             output_gate=self._gate(), output_residual=residual)
         out = self.attn(query=hidden_states, reference_points=ref, input_flatten=vision_hidden_states,
                         input_spatial_shapes=shapes, input_level_start_index=start,
                         input_padding_mask=None, attention_mask=cross_attention_mask, value=value, image_ranks=image_ranks)
-        out = out * self._gate()
-        return out if residual is None else residual + out
+        return out * self._gate()
 
     def _gate(self):
         """tanh(gate) (modeling_llama_mmfs.py:356): a one-element kernel per layer and step; without gradients it is

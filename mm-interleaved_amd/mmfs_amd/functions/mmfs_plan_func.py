@@ -28,6 +28,10 @@ _lib.mmfs_sample_forward_token.restype = _int
 _lib.mmfs_sample_forward_token.argtypes = [_int] + [_vp] * 13 + [_i64] * 11 + [_vp]
 _lib.mmfs_sample_forward_heads.restype = _int
 _lib.mmfs_sample_forward_heads.argtypes = [_int] + [_vp] * 5 + [_i64] * 2 + [_vp] * 8 + [_i64] * 11 + [_vp]
+_lib.mmfs_plan_forward_heads.restype = _int
+_lib.mmfs_plan_forward_heads.argtypes = [_int, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64] + [_vp] * 7 + [_i64] * 9 + [_vp]
+_lib.mmfs_plan_backward_heads.restype = _int
+_lib.mmfs_plan_backward_heads.argtypes = [_int] + [_vp] * 8 + [_vp, _vp, _i64, _i64, _int, _vp, _vp, _i64, _i64] + [_i64] * 9 + [_vp]
 _lib.mmfs_sample_forward_groups.restype = _int
 _lib.mmfs_sample_forward_groups.argtypes = [_int] + [_i64] * 4
 _CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -92,6 +96,64 @@ class MMFSPlanFunction(Function):
         s0, s1, s2, s3 = ctx.shapes_in
         return (d_off_q.to(dt).reshape(s0), d_att_q.to(dt).reshape(s1), d_off_tab.to(dt).reshape(s2),
                 d_att_tab.to(dt).reshape(s3), None, None, None, None, None, None, None)
+
+
+class MMFSHeadsPlanFunction(Function):
+    """``MMFSPlanFunction`` for a caller that evaluates the two query heads as ONE GEMM and the two tables as one
+    (``MMFS.sampling_plan`` with gradients): both [N, Lq, H*P*2 + H*L*P] -- the stacked heads' result, offsets' columns
+    first --, tabs [M, H*P*2 + H*L*P] likewise; the kernels read the column ranges as they lie (C ABI
+    ``mmfs_plan_forward_heads`` / ``mmfs_plan_backward_heads``).  The backward returns ONE gradient per stacked tensor,
+    the query-side one written by the kernel in the storage type: against the packed Function's four fp32 tensors, four
+    casts and (in autograd) two zero-filled buffers with two slice copies and an add per stacked tensor.
+    -> loc [N,Lq,H,n*L,P,2], attn [N,Lq,H,n*L,P], sink [N,Lq,H] (fp32)."""
+
+    @staticmethod
+    def forward(ctx, both, tabs, relpos, ref, shapes, ratios, H, L, P):
+        dt = both.dtype
+        N, Lq, C = both.shape
+        n_off = H * P * 2
+        assert C == n_off + H * L * P and tabs.shape[1] == C and tabs.dtype == dt
+        n, Lr, Nr, M = relpos.shape[-1], relpos.shape[1], ref.shape[0], tabs.shape[0]
+        both, tabs = both.contiguous(), tabs.contiguous()
+        relpos, ref, ratios = relpos.contiguous(), ref.float().contiguous(), ratios.float().contiguous()
+        assert shapes.dtype == torch.int64 and shapes.is_contiguous() and shapes.shape == (n * L, 2), "spatial_shapes must be a contiguous int64 [n*L, 2] tensor"
+        dev, es = both.device, both.element_size()
+        loc = torch.empty((N, Lq, H, n * L, P, 2), dtype=dt, device=dev)
+        attn = torch.empty((N, Lq, H, n * L, P), dtype=dt, device=dev)
+        sink = torch.empty((N, Lq, H), dtype=torch.float32, device=dev)
+        dims = (N, Lq, H, L, P, n, M, Lr, Nr)
+        with torch.cuda.device(dev):
+            rc = MSDA._launch("mmfs_plan_fwd", dev, _lib.mmfs_plan_forward_heads, _CODE[dt], both.data_ptr(),
+                              both.data_ptr() + n_off * es, C, C, tabs.data_ptr(), tabs.data_ptr() + n_off * es, C, C,
+                              relpos.data_ptr(), ref.data_ptr(), shapes.data_ptr(), ratios.data_ptr(), loc.data_ptr(),
+                              attn.data_ptr(), sink.data_ptr(), *dims, MSDA._stream(dev))
+        MSDA._check(rc, "mmfs_plan_forward_heads")
+        ctx.save_for_backward(attn, sink, relpos, shapes, ratios)
+        ctx.dims = dims
+        return loc, attn, sink
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loc, g_attn, g_sink):
+        attn, sink, relpos, shapes, ratios = ctx.saved_tensors
+        dt, dev = attn.dtype, attn.device
+        N, Lq, H, L, P, n, M, Lr, Nr = ctx.dims
+        n_off, C = H * P * 2, H * P * 2 + H * L * P
+        g_loc = g_loc.to(dt).contiguous()
+        g_attn = g_attn.to(dt).contiguous()
+        g_sink = g_sink.float().contiguous() if g_sink is not None else None
+        d_both = torch.empty((N, Lq, C), dtype=dt, device=dev)
+        d_tabs = torch.zeros((M, C), dtype=torch.float32, device=dev)
+        es = d_both.element_size()
+        with torch.cuda.device(dev):
+            rc = MSDA._launch("mmfs_plan_bwd", dev, _lib.mmfs_plan_backward_heads, _CODE[dt], g_loc.data_ptr(),
+                              g_attn.data_ptr(), g_sink.data_ptr() if g_sink is not None else None,
+                              attn.data_ptr(), sink.data_ptr(), relpos.data_ptr(), shapes.data_ptr(),
+                              ratios.data_ptr(), d_both.data_ptr(), d_both.data_ptr() + n_off * es, C, C, 1,
+                              d_tabs.data_ptr(), d_tabs.data_ptr() + n_off * 4, C, C,
+                              N, Lq, H, L, P, n, M, Lr, Nr, MSDA._stream(dev))
+        MSDA._check(rc, "mmfs_plan_backward_heads")
+        return d_both, d_tabs.to(dt), None, None, None, None, None, None, None
 
 
 def _token_rows(t, vec):

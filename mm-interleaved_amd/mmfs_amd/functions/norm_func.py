@@ -93,3 +93,61 @@ class RMSNormFunction(Function):
                               rows, C, MSDA._stream(xc.device))
         MSDA._check(rc, "mmfs_rmsnorm_backward_partials")
         return gx, parts.sum(0).to(wc.dtype), None
+
+
+class GatedProjectionFunction(Function):
+    """(x [..., K], weight [N, K], bias [N] | None, g [1], residual [..., N]) -> residual + g * (x W^T + bias): an MMFS
+    layer's output projection, its tanh(gate) and the decoder layer's residual sum (modeling_llama_mmfs.py:346-367,
+    700-717) as one node of the graph.  Forward: the GEMM and ONE elementwise kernel (the framework: a multiply and an
+    add).  Backward: NO pass over a [tokens, N] tensor besides the GEMMs' own -- the gate is applied to the SMALL side:
+        d x = grad (g W),   d W = g (grad^T x),   d bias = g sum(grad),   d residual = grad,
+        d g = sum(grad * (x W^T + bias)) = sum((grad^T x) * W) + sum(sum(grad) * bias)
+    where the framework multiplies grad by g (a pass), multiplies grad by the projection's output and reduces it (two
+    passes, and the output kept for it).  Same mathematics; the roundings differ by where g meets 16-bit storage."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, g, residual):
+        import torch.nn.functional as F
+        y = F.linear(x, weight, bias)
+        ctx.save_for_backward(x, weight, bias, g)
+        return torch.addcmul(residual, y, g.to(y.dtype))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        x, weight, bias, g = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        N, K = weight.shape
+        g2, x2 = grad.reshape(-1, N), x.reshape(-1, K)
+        gs = g.to(weight.dtype)
+        dx = (g2 @ (weight * gs)).reshape(x.shape) if need[0] else None
+        dw0 = g2.t() @ x2 if (need[1] or need[3]) else None
+        db0 = g2.sum(0) if bias is not None and (need[2] or need[3]) else None
+        dg = None
+        if need[3]:
+            acc = torch.promote_types(weight.dtype, torch.float32)
+            dg = _dot(dw0.reshape(-1), weight.reshape(-1)).to(acc)
+            if db0 is not None:
+                dg = dg + _dot(db0, bias).to(acc)
+            dg = dg.to(g.dtype).reshape(g.shape)
+        dw = dw0 * gs if need[1] else None
+        db = db0 * gs if (bias is not None and need[2]) else None
+        return dx, dw, db, dg, (grad if need[4] else None)
+
+
+_dot_ok = {}
+
+
+def _dot(a, b):
+    """sum(a * b) as the BLAS library's dot product where it has one for the type (one pass, fp32 accumulation), else
+    a multiply and a reduction."""
+    key = (a.dtype, a.device.type)
+    ok = _dot_ok.get(key)
+    if ok is None:
+        try:
+            torch.dot(a[:8], b[:8])
+            ok = True
+        except RuntimeError:
+            ok = False
+        _dot_ok[key] = ok
+    return torch.dot(a, b) if ok else (a * b).sum()

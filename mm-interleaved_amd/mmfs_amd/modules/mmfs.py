@@ -28,7 +28,8 @@ from torch import nn
 
 from ..functions import MSDeformAttnFunction
 from ..functions.linear_func import small_linear
-from ..functions.mmfs_plan_func import MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
+from ..functions.norm_func import GatedProjectionFunction
+from ..functions.mmfs_plan_func import MMFSHeadsPlanFunction, MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
 from ..levels import CacheInvalidation, cache_epoch, hook_free, host_shapes, tensor_version
 
 
@@ -100,6 +101,8 @@ class MMFS(CacheInvalidation, nn.Module):
         self.n_levels = n_levels
         self.n_heads = n_heads
         self.n_points = n_points
+        # with gradients: the two query heads as one GEMM on stacked weights, the two tables as another (_plan_tables)
+        self.stack_heads_in_training = True
         self.ratio = ratio
         self.offset_init_magnitude = offset_init_magnitude
         self.max_num_image_per_seq = max_num_image_per_seq
@@ -172,7 +175,7 @@ class MMFS(CacheInvalidation, nn.Module):
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]
         table = self.query_relpos.weight                                      # [max_img, d_query]
-        off_tab = F.linear(table, self.sampling_offsets.weight)               # [max_img, H*P*2]
+        off_tab = F.linear(table, self.sampling_offsets.weight) if (keep or not fused or not self.stack_heads_in_training) else None   # [max_img, H*P*2]
         if fused:
             H, L, P = self.n_heads, self.n_levels, self.n_points
             dq = self.attention_weights.in_features
@@ -181,7 +184,10 @@ class MMFS(CacheInvalidation, nn.Module):
             # (kept tables only: the two heads read the same activations -- stacked, they are ONE GEMM per call whose
             # result's two column ranges the fused sampler takes as they lie, ``mmfs_sample_forward_heads``)
             so = self.sampling_offsets
-            stack = keep and so.bias is not None and so.weight.dtype == aw_w.dtype and so.bias.dtype == aw_b.dtype
+            # (with gradients too: one GEMM forward, two backward instead of two and four, and the plan's Function hands
+            # back ONE gradient for the stacked result -- ``stack_heads_in_training``)
+            stack = ((keep or self.stack_heads_in_training) and so.bias is not None and so.weight.dtype == aw_w.dtype
+                     and so.bias.dtype == aw_b.dtype)
             cat_w = torch.cat((so.weight, aw_w), 0) if stack else None
             cat_b = torch.cat((so.bias, aw_b), 0) if stack else None
             # ... and nothing non-linear stands between ``dynamic_offset_mask`` (d_query x d_query: 32 MB of weights at the
@@ -192,7 +198,7 @@ class MMFS(CacheInvalidation, nn.Module):
             # (the intermediate is not rounded to 16 bits, the folded weights are): ``fold_query_projection = False``
             # keeps the two GEMMs.
             dom = self.dynamic_offset_mask
-            fold = (stack and self.fold_query_projection and dom.weight.dtype == cat_w.dtype and not torch.is_autocast_enabled()
+            fold = (stack and keep and self.fold_query_projection and dom.weight.dtype == cat_w.dtype and not torch.is_autocast_enabled()
                     and type(dom) is nn.Linear and hook_free(dom))
             fold_w = fold_b = None
             if fold:
@@ -201,7 +207,11 @@ class MMFS(CacheInvalidation, nn.Module):
                 fold_w = (wh @ dom.weight.to(ft)).to(cat_w.dtype)
                 fold_b = cat_b.to(ft) if dom.bias is None else torch.addmv(cat_b.to(ft), wh, dom.bias.to(ft))
                 fold_b = fold_b.to(cat_b.dtype)
-            res = (off_tab, F.linear(table, aw_w), aw_w, aw_b, cat_w, cat_b, fold_w, fold_b)
+            if stack and not keep:
+                # both tables as one GEMM on the stacked weights; the plan's Function reads the two column ranges
+                res = (F.linear(table, cat_w), None, aw_w, aw_b, cat_w, cat_b, None, None)
+            else:
+                res = (off_tab, F.linear(table, aw_w), aw_w, aw_b, cat_w, cat_b, fold_w, fold_b)
         else:
             res = (off_tab, F.linear(table, self.attention_weights.weight), None, None, None, None, None, None)   # [max_img, H*L*(P+1)]
         if keep:
@@ -228,6 +238,7 @@ class MMFS(CacheInvalidation, nn.Module):
             # the P point columns of the attention head are evaluated: its (P+1)-th column is
             # overwritten by a constant in the reference (mmfs.py:225) and never gets a gradient.
             off_tab, att_tab, aw_w, aw_b, cat_w, cat_b, fold_w, fold_b = self._plan_tables(True)
+            both = None
             if fold_w is not None and query.dtype == fold_w.dtype:            # (no gradients wanted: see _plan_tables)
                 both = small_linear(query, fold_w, fold_b)                    # [N, Lq, H*P*2 + H*L*P], straight from the query
                 off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
@@ -238,6 +249,12 @@ class MMFS(CacheInvalidation, nn.Module):
                     off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
                 else:
                     off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
+            if att_tab is None:               # (with gradients: both tables as the column ranges of one GEMM's result)
+                tabs = off_tab
+                if both is not None and sampler is None and tabs.dtype == both.dtype:
+                    return MMFSHeadsPlanFunction.apply(both, tabs, relpos, reference_points[:, :, 0, :],
+                                                       input_spatial_shapes, self.scale_ratios, H, L, P)
+                off_tab, att_tab = tabs[:, :H * P * 2], tabs[:, H * P * 2:]
             heads = (off_q, att_q, off_tab, att_tab, relpos,
                      reference_points[:, :, 0, :], input_spatial_shapes, self.scale_ratios, H, L, P)
             if sampler is not None:
@@ -298,10 +315,17 @@ class MMFS(CacheInvalidation, nn.Module):
             hit = self.__dict__["_ratios_f32"] = (sig, r.float())
         return hit[1]
 
-    def _project_out(self, out, output_weights, residual=None):
+    def _project_out(self, out, output_weights, residual=None, gate=None):
         """``output_proj`` (or the caller's folded weights in its place), ``+ residual`` if the caller handed one; a
         handful of token rows without gradients: the weight-streaming kernel (functions/linear_func.py), the residual
         added in its store."""
+        if gate is not None:                      # (a caller's one-element gate on the projected output: with gradients)
+            proj = self.output_proj
+            if (residual is not None and torch.is_grad_enabled() and not torch.is_autocast_enabled() and type(proj) is nn.Linear
+                    and hook_free(proj) and gate.dtype == out.dtype == residual.dtype == proj.weight.dtype):
+                return GatedProjectionFunction.apply(out, proj.weight, proj.bias, gate, residual)
+            y = proj(out) * gate
+            return y if residual is None else residual + y
         if output_weights is None:
             proj = self.output_proj
             if torch.is_grad_enabled() or type(proj) is not nn.Linear or not hook_free(proj):
@@ -313,14 +337,16 @@ class MMFS(CacheInvalidation, nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None, attention_mask=None, value=None, image_ranks=None,
-                output_weights=None, output_residual=None):
+                output_weights=None, output_residual=None, output_gate=None):
         """Arguments and result as mmfs.py:120-141 (``value`` is an addition: the caller's own
         ``value_proj(input_flatten)`` [N, n, hw, d_inner], e.g. one an ``MMFSNet`` projected for
         all its blocks at once; ``input_flatten`` is then only looked at for its shape; ``image_ranks`` another: this
         module's ``_image_relpos(attention_mask, Lq)`` as a caller made it once for several layers; ``output_weights``
         a third: (weight, bias) to use in ``output_proj``'s place -- a caller's ``FoldedLinear`` of it with what follows;
         ``output_residual`` [N, Lq, d_out] a fourth: added to the projected output -- the decoder layer's
-        ``residual + hidden_states``, which a decode step then gets inside the projection's kernel):
+        ``residual + hidden_states``, which a decode step then gets inside the projection's kernel; ``output_gate`` [1] a
+        fifth: multiplies the projected output before that sum -- the LLM layer's tanh(gate), which with gradients becomes
+        part of the projection's node, ``GatedProjectionFunction``):
         query [N, Lq, d_query]; reference_points [N|1, Lq, 1|n*L, 2|4] in [0,1];
         input_flatten [N, n_images, sum_l H_l*W_l, d_value]; input_spatial_shapes [n*L, 2];
         input_level_start_index [n*L]; input_padding_mask [N, n, hw] or None;
@@ -353,7 +379,7 @@ class MMFS(CacheInvalidation, nn.Module):
         if loc is None:
             out = attn                            # (the fused kernel's result)
             if sink_w is None:                    # ... the ignore token's term included
-                return self._project_out(out, output_weights, output_residual)
+                return self._project_out(out, output_weights, output_residual, output_gate)
         else:
             # (last argument: the softmax that made ``attn`` multiplies the gradient of every weight by the
             # weight itself, so the op need not compute it where the weight -- an invisible image -- is 0)
@@ -362,4 +388,4 @@ class MMFS(CacheInvalidation, nn.Module):
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
-        return self._project_out(out, output_weights, output_residual)
+        return self._project_out(out, output_weights, output_residual, output_gate)

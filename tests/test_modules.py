@@ -621,7 +621,15 @@ def test_folded_query_projection_is_the_two_gemms():
         m.fold_query_projection = False
         assert m._plan_tables(True)[6] is None and m._plan_tables(True)[4] is not None
         m.fold_query_projection = True
-    assert m._plan_tables(True)[4] is None and m._plan_tables(True)[6] is None     # with gradients: nothing kept, nothing folded
+    # with gradients: nothing kept, nothing folded; the heads' weights stacked per call (part of the graph), the two
+    # tables one GEMM on them
+    t = m._plan_tables(True)
+    assert t[6] is None and t[4].requires_grad and t[1] is None and t[0].shape == (6, H * P * 2 + H * L * P)
+    assert m._tables is None or m._tables[1] is not t
+    m.stack_heads_in_training = False
+    t = m._plan_tables(True)
+    assert t[4] is None and t[6] is None and t[1] is not None
+    m.stack_heads_in_training = True
 
 
 def test_folded_linear_is_the_two_layers_and_follows_its_parameters():
@@ -708,6 +716,22 @@ def test_llama_layer_in_inference_mode_then_no_grad_then_training(oracle_op):
     with torch.no_grad():
         close(l(h, f, mask, residual=h), (h + d).numpy(), 1e-12)
     close(l(h, f, mask, residual=h).detach(), (h + d).numpy(), 1e-12)
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_gated_projection_function_gradients(with_bias):
+    """``GatedProjectionFunction`` (residual + g (x W^T + b), the gate applied to the small side of every backward product)
+    against autograd's gradients of the framework statement, fp64."""
+    from mmfs_amd.functions.norm_func import GatedProjectionFunction
+    g = torch.Generator().manual_seed(2)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).requires_grad_(True)
+    x, W, b, gate, res = mk(2, 5, 6), mk(7, 6), (mk(7) if with_bias else None), mk(1), mk(2, 5, 7)
+    go = torch.randn(2, 5, 7, generator=g, dtype=torch.float64)
+    leaves = [t for t in (x, W, b, gate, res) if t is not None]
+    got = torch.autograd.grad(GatedProjectionFunction.apply(x, W, b, gate.tanh(), res), leaves, go)
+    want = torch.autograd.grad(res + torch.nn.functional.linear(x, W, b) * gate.tanh(), leaves, go)
+    for a, w in zip(got, want):
+        close(a, w.numpy(), 1e-12)
 
 
 def test_mmfs_net_in_inference_mode_then_training(oracle_op):

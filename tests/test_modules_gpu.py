@@ -613,6 +613,67 @@ def test_llama_layer_with_the_fused_norm_and_schedule_matches_the_layerwise_path
     assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 4e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.6e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_gated_projection_with_the_residual_handed_over(dtype, tol, with_bias):
+    """``GatedProjectionFunction``: residual + g * (x W^T + b) as one node -- the gate applied to the small side of every
+    backward product -- against the framework's statement in fp64 on the same stored inputs: value and every gradient."""
+    from mmfs_amd.functions.norm_func import GatedProjectionFunction
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 37, 256, generator=g).to(DEV, dtype)
+    W = (torch.randn(512, 256, generator=g) * 0.05).to(DEV, dtype)
+    b = (torch.randn(512, generator=g) * 0.1).to(DEV, dtype) if with_bias else None
+    gate = torch.tensor([0.6]).to(DEV, dtype)
+    res = torch.randn(3, 37, 512, generator=g).to(DEV, dtype)
+    go = torch.randn(3, 37, 512, generator=g).to(DEV, dtype)
+    outs = []
+    for ours, dt in ((True, dtype), (False, torch.float64)):
+        leaves = [t.detach().to(dt).requires_grad_(True) if t is not None else None for t in (x, W, b, gate, res)]
+        xx, ww, bb, gg, rr = leaves
+        y = GatedProjectionFunction.apply(xx, ww, bb, gg.tanh(), rr) if ours else rr + torch.nn.functional.linear(xx, ww, bb) * gg.tanh()
+        y.backward(go.to(dt))
+        outs.append([y.detach().double()] + [t.grad.double() for t in leaves if t is not None])
+    names = ["out", "grad x", "grad weight"] + (["grad bias"] if with_bias else []) + ["grad gate", "grad residual"]
+    for name, a, bb in zip(names, outs[0], outs[1]):
+        err = float((a - bb).abs().max() / bb.abs().max().clamp_min(1e-6))
+        assert err <= tol * (4 if name in ("grad weight", "grad gate", "grad bias") else 1), f"{name}: {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_llama_layer_training_step_with_the_residual_handed_over():
+    """``layer(x, ..., residual=x)`` with gradients (norm + residual and gate + residual as one Function each, the heads
+    stacked) against ``x + layer(x, ...)`` with ``stack_heads_in_training = False`` -- the round-3 statement -- in bf16:
+    output and every gradient within 16-bit rounding of each other."""
+    import types
+    from mmfs_amd.blocks import LlamaMMFSAttention
+    cfg = types.SimpleNamespace(hidden_size=512, num_attention_heads=8, rms_norm_eps=1e-6, max_position_embeddings=64,
+                                image_embed_dim=128, spatial_shapes=[8, 4, 2])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        l = LlamaMMFSAttention(cfg, 0).to(DEV, torch.bfloat16).train()
+    with torch.no_grad():
+        l.gate.fill_(0.7)
+        l.attn.sampling_offsets.weight.normal_(0, 0.02)
+    B, Lq, n, hw = 2, 33, 2, 64 + 16 + 4
+    hidden = torch.randn(B, Lq, 512, device=DEV, dtype=torch.bfloat16)
+    feats = torch.randn(B, n, hw, 128, device=DEV, dtype=torch.bfloat16)
+    mask = torch.ones(B, Lq, n, device=DEV)
+    go = torch.randn(B, Lq, 512, device=DEV, dtype=torch.bfloat16)
+    res = {}
+    for new in (True, False):
+        l.attn.stack_heads_in_training = new
+        l.zero_grad(set_to_none=True)
+        x = hidden.clone().requires_grad_(True)
+        y = l(x, feats, mask, residual=x) if new else x + l(x, feats, mask)
+        y.backward(go)
+        res[new] = [y.detach().float(), x.grad.float()] + [p.grad.float() for p in l.parameters() if p.grad is not None]
+    assert len(res[True]) == len(res[False]) >= 10
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b).clamp_min(1e-12)) <= 2e-2, i
+        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) <= 8e-2, i
+
+
 # ---------------------------------------------------------------- layout kernels around the image decoder's block
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])

@@ -123,7 +123,14 @@ def cfg3():
                     h = h + l(h, feats, mask)
                 return h
 
+        params = [p for l in layers for p in l.parameters()]
+
+        def zero_grad():                # (what optimizer.zero_grad(set_to_none=True) does: no accumulation kernels in the step)
+            for p in params:
+                p.grad = None
+
         def train():
+            zero_grad()
             h = hidden.clone().requires_grad_(True)
             x = h
             for l in layers:
@@ -142,15 +149,17 @@ def cfg3():
                 ranks = sched.image_ranks(mask, Lq)
                 h = hidden
                 for k, l in enumerate(layers):
-                    h = h + l(h, feats, mask, value=bank.values[k], image_ranks=ranks)
+                    h = l(h, feats, mask, value=bank.values[k], image_ranks=ranks, residual=h)
                 return h
 
         def train_sched():
+            zero_grad()
             h = hidden.clone().requires_grad_(True)
             bank = sched.project(feats)
+            ranks = sched.image_ranks(mask, Lq)
             x = h
             for k, l in enumerate(layers):
-                x = x + l(x, feats, mask, value=bank.values[k])
+                x = l(x, feats, mask, value=bank.values[k], image_ranks=ranks, residual=x)
             x.backward(torch.ones_like(x))
 
         for l in layers:
@@ -158,9 +167,11 @@ def cfg3():
         graphed = GraphedLlamaMMFSStack(layers, hidden, feats, mask)
 
         def stack_fn(h):
+            bank = sched.project(feats)
+            ranks = sched.image_ranks(mask, Lq)
             x = h
-            for l in layers:
-                x = x + l(x, feats, mask)
+            for k, l in enumerate(layers):
+                x = l(x, feats, mask, value=bank.values[k], image_ranks=ranks, residual=x)
             return x
         gstep = [None]
 
@@ -173,7 +184,8 @@ def cfg3():
         cases = [("forward", fwd, False), ("forward, shared normalisation + batched value projection", lambda: fwd_sched(False), False),
                  ("forward, projected bank kept across calls (decode / generation)", lambda: fwd_sched(True), False),
                  ("forward, projected bank kept, HIP-graph replay", lambda: graphed(hidden), False),      # (replays what the line above runs)
-                 ("forward+backward", train, True), ("forward+backward, shared normalisation + batched value projection", train_sched, True),
+                 ("forward+backward", train, True),
+                 ("forward+backward, shared normalisation + batched value projection, residual handed to the layer", train_sched, True),
                  ("forward+backward, whole step replayed as ONE HIP graph", train_graphed, True)]
         for label, fn, bwd in cases:
             if bwd and Lq == 1:
@@ -183,7 +195,7 @@ def cfg3():
             ms = timed(fn)
             fam, launches = split(fn)
             analytic = 8 * mmfs_linear_flops(B * Lq, B * n * S, 4096, 1024, 1024, 4096, 16, 3, 8, 50) * (3 if bwd else 1)
-            counted = (lambda: fwd_sched(True)) if "graph replay" in label else train if "ONE HIP graph" in label else fn
+            counted = (lambda: fwd_sched(True)) if "graph replay" in label else train_sched if "ONE HIP graph" in label else fn
             counted()                   # (the mode change above dropped what the modules keep: count a call that has it again)
             flops = executed_gemm_flops(counted)
             ob = 8 * op_bytes(B, Lq, 16, 64, 3 * n, 8, S * n, backward=bwd)

@@ -7,6 +7,7 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+seq = len(sys.argv) > 2 and sys.argv[2] == "seq"        # cfg3 seq: ONE layer's forward + backward, kernel by kernel in time order
 dev, dt = "cuda", torch.bfloat16
 if which == "cfg3":
     from mmfs_amd.blocks import LlamaMMFSAttention, LlamaMMFSSchedule
@@ -14,7 +15,7 @@ if which == "cfg3":
                                 max_position_embeddings=2048, image_embed_dim=1024, spatial_shapes=[32, 16, 8])
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt) for i in range(8)]
+        layers = [LlamaMMFSAttention(cfg, 4 * i).to(dev, dt) for i in range(1 if seq else 8)]
     with torch.no_grad():
         for l in layers:
             l.gate.fill_(0.5)
@@ -26,12 +27,15 @@ if which == "cfg3":
     sched = LlamaMMFSSchedule(layers)
 
     def step():
+        for l in layers:
+            for p in l.parameters():
+                p.grad = None
         h = hidden.clone().requires_grad_(True)
         bank = sched.project(feats)
         ranks = sched.image_ranks(mask, Lq)
         x = h
         for k, l in enumerate(layers):
-            x = x + l(x, feats, mask, value=bank.values[k], image_ranks=ranks)
+            x = l(x, feats, mask, value=bank.values[k], image_ranks=ranks, residual=x)
         x.backward(torch.ones_like(x))
 else:
     from mmfs_amd.blocks import MMFSNet
@@ -69,3 +73,12 @@ tot = sum(e.device_time_total for e in rows) / iters
 print("%s: %.0f us of kernels per step, %d launches" % (which, tot, sum(e.count for e in rows) // iters))
 for e in rows[:45]:
     print("  %8.1f us  x%-4d %s" % (e.device_time_total / iters, e.count // iters, e.key[:140]))
+
+if seq:
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        step()
+        torch.cuda.synchronize()
+    evs = sorted((e for e in prof.events() if e.device_type.name == "CUDA"), key=lambda e: e.time_range.start)
+    print("one layer, forward + backward, in time order: %d kernels" % len(evs))
+    for e in evs:
+        print("  %7.1f us  %s" % (e.device_time, e.name[:150]))
