@@ -170,7 +170,10 @@ class MMFS(CacheInvalidation, nn.Module):
             ps = (self.query_relpos.weight, self.sampling_offsets.weight, self.sampling_offsets.bias,
                   self.attention_weights.weight, self.attention_weights.bias,
                   self.dynamic_offset_mask.weight, self.dynamic_offset_mask.bias)
-            sig = (cache_epoch(), self.fold_query_projection, torch.is_autocast_enabled())
+            # (whether a hook could observe ``dynamic_offset_mask`` is part of the key: tables made while a profiler's
+            # or a FLOP counter's process-wide hooks were registered keep the two GEMMs, and must not outlive the hooks
+            # -- nor may folded ones be used while hooks are there: tools/module_bench.py measured both, r04zf)
+            sig = (cache_epoch(), self.fold_query_projection and hook_free(self.dynamic_offset_mask), torch.is_autocast_enabled())
             sig = sig + (fused, torch.is_inference_mode_enabled()) + tuple((t.data_ptr(), tensor_version(t), t.dtype) for t in ps if t is not None)
             if self._tables is not None and self._tables[0] == sig:
                 return self._tables[1]

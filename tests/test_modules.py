@@ -621,6 +621,15 @@ def test_folded_query_projection_is_the_two_gemms():
         m.fold_query_projection = False
         assert m._plan_tables(True)[6] is None and m._plan_tables(True)[4] is not None
         m.fold_query_projection = True
+        # a process-wide module hook (a profiler's, a FLOP counter's) must see dynamic_offset_mask run: no fold while
+        # it is registered -- and the tables made then must not be the ones used after it is gone
+        assert m._plan_tables(True)[6] is not None
+        handle = torch.nn.modules.module.register_module_forward_hook(lambda mod, i, o: None)
+        try:
+            assert m._plan_tables(True)[6] is None
+        finally:
+            handle.remove()
+        assert m._plan_tables(True)[6] is not None
     # with gradients: nothing kept, nothing folded; the heads' weights stacked per call (part of the graph), the two
     # tables one GEMM on them
     t = m._plan_tables(True)

@@ -12,7 +12,7 @@ benchmark (that is bench.py, the op at config 2), but what surrounds the op on t
 One JSON line per case: ms per call, the time split by kernel family from the torch profiler (GEMM =
 hipBLASLt / rocBLAS kernels of the F.linear layers; op = this library's HIP kernels; other = framework
 elementwise / norm / copy kernels), and the two rooflines the north star asks for:
-  gemm_mfma_util   = FLOPs of the matrix products the call actually EXECUTED (counted by torch's FlopCounterMode on
+  gemm_mfma_util   = FLOPs of the matrix products the call actually EXECUTED (counted with torch's FLOP formulas under a bare dispatch mode on
                      one call: a projection that is kept or folded away is not counted -- round 3 divided a fixed analytic
                      count by the measured time and reported utilisations above 1) / GEMM kernel time /
                      2.5 PFLOP/s (dense bf16 MFMA peak).  Products that run in this library's own kernels (the
@@ -71,12 +71,26 @@ def split(fn, iters=5):
 
 
 def executed_gemm_flops(fn):
-    """FLOPs of the aten matrix products (mm / addmm / bmm / convolution, forward and backward) one call of fn dispatches."""
-    from torch.utils.flop_counter import FlopCounterMode
-    with FlopCounterMode(display=False) as fc:
+    """FLOPs of the aten matrix products (mm / addmm / bmm / convolution, forward and backward) one call of fn dispatches.
+    torch's own formulas (``flop_registry``) under a bare dispatch mode: ``FlopCounterMode`` also registers process-wide
+    module hooks, and a module that sees hooks does not take its folds -- the counted call would not be the timed one."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils.flop_counter import flop_registry
+
+    class Count(TorchDispatchMode):
+        total = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            f = flop_registry.get(getattr(func, "_overloadpacket", None))
+            if f is not None:
+                self.total += int(f(*args, **(kwargs or {}), out_val=out))
+            return out
+
+    with Count() as c:
         fn()
     torch.cuda.synchronize()
-    return int(fc.get_total_flops())
+    return int(c.total)
 
 
 def mmfs_linear_flops(tokens, bank_tokens, d_query, d_value, d_inner, d_out, H, L, P, max_img):
