@@ -65,12 +65,6 @@ __device__ unsigned long long g_q8_prof[kQProfSlots * 8];
 #define QPROF_FLUSH() do {} while (0)
 #endif
 
-#ifdef Q8_DEBUG_CHECK
-__device__ unsigned int g_q8_dbg[16];
-#define QDBG(i, cond) do { if (cond) atomicAdd(&g_q8_dbg[i], 1u); } while (0)
-#else
-#define QDBG(i, cond) do {} while (0)
-#endif
 
 // The tile's products as inline assembly, accumulating IN PLACE, fenced by wait states on both sides.
 // With the builtin, and >= 5 busy waves per CU, the accumulator rows of lanes 48 .. 63 (queries 6 and 7 of a tile) came out
@@ -109,9 +103,6 @@ __device__ __forceinline__ void keep_alive(uint32_t v) { asm volatile("" :: "v"(
 
 namespace q8 {
 
-#ifdef Q8_DEBUG_HARD_SYNC
-#define wave_sync() do { asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory"); mma::wave_sync(); asm volatile("s_nop 7" ::: "memory"); } while (0)
-#endif
 
 typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32v2 __attribute__((ext_vector_type(2)));
@@ -254,11 +245,7 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
     const int bkb = lane >> 4, br = (lane >> 2) & 3, bc = lane & 3;       // B operand: K block, corner, 8-byte piece
     const uint32_t b_rd = lds0 + wrec + 8 * bkb;                          // offsets of queries 2 kb, 2 kb + 1
     // (odd K blocks read the OTHER 32-byte piece of their rows: header)
-#ifdef Q8_DEBUG_NO_SWAP
-    const uint32_t b_c0 = lds0 + (br & 1) * kRB + 8 * bc;
-#else
     const uint32_t b_c0 = lds0 + (br & 1) * kRB + 8 * bc + ((bkb & 1) ? 32 : 0);
-#endif
     const uint32_t b_hi = br >> 1;
     const int gj = lane >> 3, ghalf = (lane >> 2) & 1, gc = lane & 3;     // row gather: query, corner pair, 16-byte piece
     const uint32_t g_rd = lds0 + wrec + 16 * gj + 8 * ghalf;
@@ -286,9 +273,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
 
     // (the next pass's sample words are requested while this pass multiplies; kept RAW until they are used)
     uint32_t pf_w0 = 0u, pf_w1 = 0u, pf_a = 0u;
-#ifdef Q8_DEBUG_CHECK
-    uint32_t dbg_off = 0xffffffffu;
-#endif
     auto prefetch = [&](int tile, int pass) {
         const int q = q_first + tile * (kMmaWaves * kQT) + sj;
         const int k = pass * 8 + si;
@@ -331,15 +315,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         {
             const int q = q0 + sj;
             asm volatile("" : "+v"(pf_w0), "+v"(pf_w1), "+v"(pf_a));      // (opaque HERE: the decode must not move up to the loads)
-#ifdef Q8_DEBUG_CHECK
-            if (k_ok && q < q_run1) {
-                const uint32_t s_ = (uint32_t)q * q_stride + (uint32_t)k;
-                const uint32_t fresh = *reinterpret_cast<const volatile uint32_t *>(loc_wg + 2 * (size_t)s_);
-                const uint32_t fresha = *reinterpret_cast<const volatile uint16_t *>(attn_wg + s_);
-                QDBG(0, pair_ok && fresh != pf_w0);
-                QDBG(1, fresha != pf_a);
-            }
-#endif
             const uint32_t xb = pair_ok ? (pf_w0 & 0xffffu) : pf_w0, yb = pair_ok ? (pf_w0 >> 16) : pf_w1;
             const float lx = to_f32(__builtin_bit_cast(T, (uint16_t)xb)), ly = to_f32(__builtin_bit_cast(T, (uint16_t)yb));
             const float a = to_f32(__builtin_bit_cast(T, (uint16_t)pf_a));
@@ -354,9 +329,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
             const float aa = on ? a : 0.f;
             const float w[4] = {gy * gx * aa, gy * fx * aa, fy * gx * aa, fy * fx * aa};
             unsigned char *rec = smem + wrec + si * kRec;
-#ifdef Q8_DEBUG_CHECK
-            dbg_off = 0xffffffffu;
-#endif
             st_a = st_b = make_uint4(0u, 0u, 0u, 0u);                     // what this lane's 16-byte stores hand to the LDS
             if (k_ok && resident) {
                 // "off": the last pixel of line -1 -- its four "corners" are that zero pixel, the border pixel (0, -1)
@@ -366,9 +338,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
 #pragma unroll
                 for (int c = 0; c < 4; ++c) M::split(w[c], hi[c], lo[c]);
                 *reinterpret_cast<uint32_t *>(rec + 4 * sj) = (uint32_t)(ibase + rel);
-#ifdef Q8_DEBUG_CHECK
-                dbg_off = (uint32_t)(ibase + rel);
-#endif
                 const uint32_t h01 = hi[0] | (hi[1] << 16), h23 = hi[2] | (hi[3] << 16);
                 const uint32_t l01 = lo[0] | (lo[1] << 16), l23 = lo[2] | (lo[3] << 16);
                 const bool odd = sj & 1;                                  // K positions 4 .. 7 of the query pair's K block
@@ -410,15 +379,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         keep_alive(st_a); keep_alive(st_b);                               // (the stores' registers were theirs until here)
 #endif
         wave_sync();
-#ifdef Q8_DEBUG_CHECK
-        if (k_ok && resident) {      // read-back of this lane's own offset
-            const uint32_t back = *reinterpret_cast<const volatile uint32_t *>(smem + wrec + si * kRec + 4 * sj);
-            QDBG(2, back != dbg_off);
-        }
-#endif
-#ifdef Q8_DEBUG_WAIT_AFTER_STAGE
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15" ::: "memory");
-#endif
         if (pass + 1 < n_pass) prefetch(tile, pass + 1); else prefetch(tile + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         QPROF(1);                                                         // stage
@@ -444,16 +404,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
                 o2[u] = *reinterpret_cast<const lds_u32v2 *>((uintptr_t)(b_rd + (IB + u) * kRec));     // queries 2 kb, 2 kb + 1
 #endif
             }
-#ifdef Q8_DEBUG_CHECK
-#pragma unroll
-            for (int u = 0; u < N; ++u) {
-                const uint32_t e0 = (uint32_t)__shfl((int)dbg_off, 8 * (2 * bkb) + IB + u, 64);
-                const uint32_t e1 = (uint32_t)__shfl((int)dbg_off, 8 * (2 * bkb + 1) + IB + u, 64);
-                QDBG(3, o2[u].x != e0);
-                QDBG(4, o2[u].y != e1);
-                QDBG(5, (o2[u].x != e0 || o2[u].y != e1) && bkb == 3);
-            }
-#endif
             s16x8 Bv[N][2];
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -467,21 +417,9 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
                     Bv[u][g][4] = v1[0]; Bv[u][g][5] = v1[1]; Bv[u][g][6] = v1[2]; Bv[u][g][7] = v1[3];
                 }
             }
-#ifdef Q8_DEBUG_NOP_BEFORE_MFMA
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int z = 0; z < Q8_DEBUG_NOP_BEFORE_MFMA; ++z) asm volatile("s_nop 15" ::: "memory");
-#endif
 #pragma unroll
             for (int u = 0; u < N; ++u) {
-#ifdef Q8_DEBUG_MASK_A
-                const uint32_t am_ = (akb == (am >> 2)) ? 0xffffffffu : 0u;
-                u32v4 a4m = a4[u];
-                a4m[0] &= am_; a4m[1] &= am_; a4m[2] &= am_; a4m[3] &= am_;
-                const s16x8 A = __builtin_bit_cast(s16x8, a4m);
-#else
                 const s16x8 A = __builtin_bit_cast(s16x8, a4[u]);
-#endif
 #ifndef Q8_BUILTIN_MFMA
                 Q8Mma<T>::run2(A, Bv[u][0], Bv[u][1], acc[0], acc[1]);
 #else
@@ -489,10 +427,6 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
                 for (int g = 0; g < 2; ++g) acc[g] = M::run(A, Bv[u][g], acc[g]);
 #endif
             }
-#ifdef Q8_DEBUG_NOP_AFTER_MFMA
-#pragma unroll
-            for (int z = 0; z < Q8_DEBUG_NOP_AFTER_MFMA; ++z) asm volatile("s_nop 15" ::: "memory");
-#endif
         };
         using N1 = std::integral_constant<int, 1>;
         using N2 = std::integral_constant<int, 2>;
@@ -500,12 +434,10 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         auto nibble = [&](uint32_t rm, auto ib_tag) {
             constexpr int IB = decltype(ib_tag)::value;
             const uint32_t m4 = (rm >> IB) & 0xfu;
-#ifndef Q8_DEBUG_N1
             if (m4 == 0xfu) {
                 products(N2{}, std::integral_constant<int, IB>{});
                 products(N2{}, std::integral_constant<int, IB + 2>{});
             } else
-#endif
             if (m4) {
                 if (m4 & 1u) products(N1{}, std::integral_constant<int, IB>{});
                 if (m4 & 2u) products(N1{}, std::integral_constant<int, IB + 1>{});
@@ -565,11 +497,7 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         float *es = reinterpret_cast<float *>(smem + wrec);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-#ifdef Q8_DEBUG_NO_SWAP
-            const int ch = 16 * g + dn;
-#else
             const int ch = 16 * ((drq & 1) ? (g ^ 1) : g) + dn;
-#endif
             es[(2 * drq) * kCS + ch] = acc[g][0] + acc[g][1];
             es[(2 * drq + 1) * kCS + ch] = acc[g][2] + acc[g][3];
         }
@@ -701,14 +629,3 @@ extern "C" int mmfs_debug_q8_profile(unsigned long long *out, int reset)
 }
 #endif
 
-#ifdef Q8_DEBUG_CHECK
-extern "C" int mmfs_debug_q8_check(unsigned int *out, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mmfs::g_q8_dbg), 16 * sizeof(unsigned int));
-    if (e == hipSuccess && reset) {
-        unsigned int z[16] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_q8_dbg), z, sizeof z);
-    }
-    return (int)e;
-}
-#endif

@@ -35,7 +35,9 @@ names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_reduce": "msda_bwd_value_re
          "msda_bwd_tile_reduce": "msda_bwd_value_reduce", "msda_bwd_prepare": "msda_bwd_value_prepare",
          "msda_taps_coarse": "msda_bwd_taps_coarse",
          # round 3: LDS-resident levels on the matrix cores (forward; all-levels taps)
-         "msda_fwd_mma": "msda_fwd", "msda_taps_mma": "msda_bwd_taps"}
+         "msda_fwd_mma": "msda_fwd", "msda_taps_mma": "msda_bwd_taps",
+         # round 4: the sliced forward (heads of 32 / 64 channels, whole pyramid resident)
+         "msda_fwd_q8": "msda_fwd"}
 traffic = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
     kern, _, rest = line.partition(": ")

@@ -32,7 +32,7 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
         k = r.get("Kernel_Name", "")
         if "msda" not in k and "repack" not in k: continue
         import re
-        m = re.search(r"(msda_[a-z_]+|repack_kernel<\d+>|repack_kernel)", k)
+        m = re.search(r"(msda_[a-z_0-9]+|repack_kernel<\d+>|repack_kernel)", k)
         short = m.group(1) if m else k[:60]
         flags = re.search(r"msda_bwd_vecI\w+?Li\d+ELb(\d)E", k)          # first bool = SCATTER
         if flags: short += "_atomic" if flags.group(1) == "1" else "_taps"
