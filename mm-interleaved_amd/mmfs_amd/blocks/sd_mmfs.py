@@ -19,6 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
+from ..functions.linear_func import _split_k, token_linear
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
 from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
@@ -85,8 +86,10 @@ class _ProjectAll(torch.autograd.Function):
     GEMM).  Written as a Function because of its backward: left to autograd, every consumer's gradient of "its" slice of
     the stacked result becomes a zero-filled [K, T, D] tensor with one slice set, and the K of them are added up -- at the
     image decoder's shape 13 fills and 13 adds of 1.16 GB each, 10.8 ms of a 37 ms training step (r04t).  Here the K
-    incoming gradients are copied side by side, the weight gradients are one batched GEMM, the input gradient K GEMMs
-    accumulating in place."""
+    incoming gradients are taken as they come: every weight gradient x^T g_k is a product whose sum over the T tokens is
+    cut into chunks (``linear_func._split_k``: a [C, T] x [T, D] product is 16 output tiles for 256 CUs, each walking
+    all 43 520 tokens -- 264 us apiece, and as ONE batched GEMM over the K gradients copied side by side 1.93 ms + 0.57 ms
+    of copies, r04zk), the input gradient K GEMMs accumulating in place."""
 
     @staticmethod
     def forward(ctx, x, wt, bias):
@@ -98,22 +101,27 @@ class _ProjectAll(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         x, wt = ctx.saved_tensors
-        K, T = wt.shape[0], x.shape[0]
-        gy = torch.empty((K, T, wt.shape[2]), dtype=wt.dtype, device=wt.device)
-        for k, g in enumerate(grads):
-            if g is None:
-                gy[k].zero_()
-            else:
-                gy[k].copy_(g)
+        K, T, C, D = wt.shape[0], x.shape[0], wt.shape[1], wt.shape[2]
+        gs = [None if g is None else g.reshape(T, D).contiguous() for g in grads]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.mm(gy[0], wt[0].t())
-            for k in range(1, K):
-                gx.addmm_(gy[k], wt[k].t())
+            for k, g in enumerate(gs):
+                if g is not None:
+                    gx = torch.mm(g, wt[k].t()) if gx is None else gx.addmm_(g, wt[k].t())
+            if gx is None:
+                gx = torch.zeros_like(x)
         if ctx.needs_input_grad[1]:
-            gw = torch.matmul(x.t()[None], gy)                             # [K, C, D]
+            S = _split_k(T, C, D) if (x.is_cuda and x.is_contiguous()) else 1
+            gw = torch.empty_like(wt)                                      # [K, C, D]
+            for k, g in enumerate(gs):
+                if g is None:
+                    gw[k].zero_()
+                elif S > 1:
+                    torch.sum(torch.bmm(x.view(S, T // S, C).transpose(1, 2), g.view(S, T // S, D)), 0, out=gw[k])
+                else:
+                    torch.mm(x.t(), g, out=gw[k])
         if ctx.needs_input_grad[2]:
-            gb = gy.sum(1)
+            gb = torch.stack([torch.zeros(D, dtype=wt.dtype, device=wt.device) if g is None else g.sum(0) for g in gs])
         return gx, gw, gb
 
 
@@ -221,7 +229,8 @@ class MMFSBlock(CacheInvalidation, nn.Module):
         # backward took 0.45 ms per block at B=8, the GEMMs take ~0.05)
         if self._conv_is_pointwise():
             if not one_gemm:
-                out = F.linear(out, self.conv.weight.view(C, C), self.conv.bias)
+                out = token_linear(out, self.conv.weight.view(C, C), self.conv.bias) if hook_free(self.conv) \
+                    else self.conv(out.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
             if fast and residual is not None and residual.shape == sample.shape and residual.dtype == out.dtype:
                 # "b (h w) c -> b c h w" + the caller's add
                 return TokensAddFunction.apply(out, residual) if torch.is_grad_enabled() else tokens_add(out, residual)

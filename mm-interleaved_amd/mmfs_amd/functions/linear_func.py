@@ -54,3 +54,68 @@ def small_linear(x, weight, bias=None, residual=None):
                           MSDA._stream(x.device))
     MSDA._check(rc, "mmfs_linear_small")
     return y
+
+
+# ---------------------------------------------------------------- many tokens, few features: the weight gradient
+def _split_k(T, N, K):
+    """Chunks of the token axis for dW = g^T x (``TokenLinearFunction``): the BLAS call gives every output tile ONE
+    workgroup that walks all T tokens -- 4 tiles for a 320 x 320 weight and 32768 tokens (the image decoder's first
+    blocks), 117 us at 0.06 PFLOP/s; as a batch of S shorter products + a sum: 33 us (tools/gemm_splitk.py, r04zj).
+    Largest power of two <= min(T / 1024, 256 / tiles); 1 = the plain call (few tokens, or enough tiles anyway)."""
+    if T < 4096:
+        return 1
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    cap = min(T // 1024, 256 // tiles)
+    s = 1
+    while 2 * s <= cap and T % (2 * s) == 0:
+        s *= 2
+    return s
+
+
+class TokenLinearFunction(torch.autograd.Function):
+    """``F.linear(x, weight, bias)`` for [..., K] activations whose weight gradient sums over MANY token rows: the same
+    products as autograd's backward of ``F.linear``, the token sum of dW cut into ``_split_k`` chunks (a batched GEMM +
+    one reduction; every partial product accumulated in fp32, rounded to the storage type, summed in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2, x2 = grad.reshape(-1, N), x.reshape(-1, K)
+        T = g2.shape[0]
+        dx = (g2 @ weight).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            S = _split_k(T, N, K)
+            if S > 1 and g2.is_contiguous() and x2.is_contiguous():
+                dw = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).sum(0)
+            else:
+                dw = g2.t() @ x2
+        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def token_linear(x, layer_or_weight, bias=None):
+    """A Linear layer on token rows.  ``layer_or_weight``: an ``nn.Linear`` (called as the module it is when it is not a
+    plain one or a hook could observe it) or a weight tensor (+ ``bias``).  With gradients, on the device, for 16-bit
+    storage and enough tokens for ``_split_k`` to cut: ``TokenLinearFunction``; else ``F.linear``."""
+    if isinstance(layer_or_weight, torch.nn.Module):
+        layer = layer_or_weight
+        from ..levels import hook_free
+        if type(layer) is not torch.nn.Linear or not hook_free(layer):
+            return layer(x)
+        weight, bias = layer.weight, layer.bias
+    else:
+        weight = layer_or_weight
+    if (torch.is_grad_enabled() and x.is_cuda and x.dtype in _CODE and weight.dtype == x.dtype and weight.requires_grad
+            and not torch.is_autocast_enabled() and weight.dim() == 2
+            and _split_k(x.numel() // max(1, x.shape[-1]), weight.shape[0], weight.shape[1]) > 1):
+        return TokenLinearFunction.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -27,8 +27,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
-from ..functions.linear_func import small_linear
-from ..functions.norm_func import GatedProjectionFunction
+from ..functions.linear_func import small_linear, token_linear
+from ..functions.norm_func import GatedProjectionFunction, IgnoreTokenFunction
 from ..functions.mmfs_plan_func import MMFSHeadsPlanFunction, MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
 from ..levels import CacheInvalidation, cache_epoch, hook_free, host_shapes, tensor_version
 
@@ -246,9 +246,9 @@ class MMFS(CacheInvalidation, nn.Module):
                 both = small_linear(query, fold_w, fold_b)                    # [N, Lq, H*P*2 + H*L*P], straight from the query
                 off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
             else:
-                q = self.dynamic_offset_mask(query)                           # one GEMM, not n
+                q = token_linear(query, self.dynamic_offset_mask)             # one GEMM, not n
                 if cat_w is not None and q.dtype == cat_w.dtype:
-                    both = F.linear(q, cat_w, cat_b)                          # [N, Lq, H*P*2 + H*L*P]
+                    both = token_linear(q, cat_w, cat_b)                      # [N, Lq, H*P*2 + H*L*P]
                     off_q, att_q = both[..., :H * P * 2], both[..., H * P * 2:]
                 else:
                     off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
@@ -332,7 +332,7 @@ class MMFS(CacheInvalidation, nn.Module):
         if output_weights is None:
             proj = self.output_proj
             if torch.is_grad_enabled() or type(proj) is not nn.Linear or not hook_free(proj):
-                y = proj(out)                     # (with gradients, or wrapped / hooked: the layer is called as a layer)
+                y = token_linear(out, proj)       # (with gradients: a layer that is wrapped / hooked is called as a layer)
                 return y if residual is None else residual + y
             output_weights = (proj.weight, proj.bias)
         return small_linear(out, *output_weights, residual=residual)
@@ -390,5 +390,11 @@ class MMFS(CacheInvalidation, nn.Module):
                                              loc.to(value.dtype).contiguous(), attn, self.im2col_step, True)
         # the sinks' share goes to the (frozen, zero-initialised) ignore token (mmfs.py:236-241, 274)
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
-        out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
+        if (out.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and tok.dtype == out.dtype
+                and out.dtype in (torch.float16, torch.bfloat16) and out.is_contiguous()):
+            # one product each way instead of four passes over [tokens, d_inner] tensors (functions/norm_func.py)
+            out = IgnoreTokenFunction.apply(out.view(N * Lq, -1), tok.view(self.n_heads, -1),
+                                            sink_w.reshape(N * Lq, self.n_heads)).view(N, Lq, -1)
+        else:
+            out = out + (tok * sink_w[..., None].to(tok.dtype)).reshape(N, Lq, -1).to(out.dtype)
         return self._project_out(out, output_weights, output_residual, output_gate)

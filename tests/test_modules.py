@@ -743,6 +743,25 @@ def test_gated_projection_function_gradients(with_bias):
         close(a, w.numpy(), 1e-12)
 
 
+@pytest.mark.parametrize("token_grad", [False, True])
+def test_ignore_token_function_gradients(token_grad):
+    """``IgnoreTokenFunction`` (out + token * sink per head as one block-diagonal product each way) against autograd's
+    gradients of the framework statement, fp64."""
+    from mmfs_amd.functions.norm_func import IgnoreTokenFunction
+    g = torch.Generator().manual_seed(3)
+    T, H, D = 11, 4, 6
+    out = torch.randn(T, H * D, generator=g, dtype=torch.float64).requires_grad_(True)
+    tok = torch.randn(H, D, generator=g, dtype=torch.float64).requires_grad_(token_grad)
+    sink = torch.rand(T, H, generator=g, dtype=torch.float64).requires_grad_(True)
+    go = torch.randn(T, H * D, generator=g, dtype=torch.float64)
+    leaves = [out, sink] + ([tok] if token_grad else [])
+    y = IgnoreTokenFunction.apply(out, tok, sink)
+    want_y = out + (tok[None] * sink[..., None]).reshape(T, H * D)
+    close(y.detach(), want_y.detach().numpy(), 1e-12)
+    for a, w in zip(torch.autograd.grad(y, leaves, go), torch.autograd.grad(want_y, leaves, go)):
+        close(a, w.numpy(), 1e-12)
+
+
 def test_mmfs_net_in_inference_mode_then_training(oracle_op):
     """The same for the image decoder's net: a first call inside ``torch.inference_mode()`` (kept projections, folded
     convolutions, position tables made there) must not poison a later ``no_grad`` call or a training step."""

@@ -641,6 +641,61 @@ def test_gated_projection_with_the_residual_handed_over(dtype, tol, with_bias):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.6e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("T,N,K", [(32768, 320, 320), (8192, 640, 1024), (4096, 96, 40), (2048, 320, 320)])
+def test_token_linear_weight_gradient_in_chunks(dtype, tol, T, N, K):
+    """``token_linear`` with gradients: the weight gradient's sum over the tokens cut into chunks (a batched GEMM + one
+    reduction; ``_split_k``) against fp64 on the same stored operands and against autograd's own ``F.linear`` backward:
+    output equal, gradients within the storage type's rounding of fp64 and no worse than the library's."""
+    from mmfs_amd.functions.linear_func import TokenLinearFunction, _split_k, token_linear
+    g = torch.Generator().manual_seed(T + N)
+    x = torch.randn(4, T // 4, K, generator=g).to(DEV, dtype)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, dtype)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV, dtype)
+    go = torch.randn(4, T // 4, N, generator=g).to(DEV, dtype)
+    res = {}
+    for tag, dt in (("ours", dtype), ("lib", dtype), ("f64", torch.float64)):
+        xx, ww, bb = (t.detach().to(dt).requires_grad_(True) for t in (x, w, b))
+        y = token_linear(xx, ww, bb) if tag == "ours" else torch.nn.functional.linear(xx, ww, bb)
+        if tag == "ours":
+            assert (type(y.grad_fn).__name__ == "TokenLinearFunctionBackward") == (_split_k(T, N, K) > 1)
+        y.backward(go.to(dt))
+        res[tag] = [y.detach().double(), xx.grad.double(), ww.grad.double(), bb.grad.double()]
+    assert _split_k(T, N, K) > 1 or T < 4096
+    assert torch.equal(res["ours"][0], res["lib"][0]) and torch.equal(res["ours"][1], res["lib"][1])
+    for name, a, l, f in zip(("out", "grad x", "grad weight", "grad bias"), res["ours"], res["lib"], res["f64"]):
+        scale = f.abs().max().clamp_min(1e-6)
+        err, lib_err = float((a - f).abs().max() / scale), float((l - f).abs().max() / scale)
+        assert err <= max(tol, 1.5 * lib_err), f"{name}: {err:.3e} (library {lib_err:.3e})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.6e-2), (torch.float16, 2e-3)])
+def test_ignore_token_term_as_one_product(dtype, tol):
+    """``IgnoreTokenFunction`` on the device, 16-bit storage with the plan's fp32 sink weights: value and gradients against
+    the framework statement in fp64 on the same stored operands."""
+    from mmfs_amd.functions.norm_func import IgnoreTokenFunction
+    g = torch.Generator().manual_seed(9)
+    T, H, D = 4096, 16, 64
+    out = torch.randn(T, H * D, generator=g).to(DEV, dtype)
+    tok = torch.randn(H, D, generator=g).to(DEV, dtype)
+    sink = torch.rand(T, H, generator=g).to(DEV)
+    go = torch.randn(T, H * D, generator=g).to(DEV, dtype)
+    res = []
+    for ours in (True, False):
+        dt = dtype if ours else torch.float64
+        o, t = out.detach().to(dt).requires_grad_(True), tok.detach().to(dt).requires_grad_(True)
+        s = sink.detach().to(torch.float32 if ours else dt).requires_grad_(True)
+        y = IgnoreTokenFunction.apply(o, t, s) if ours else o + (t[None] * s[..., None]).reshape(T, H * D)
+        y.backward(go.to(dt))
+        res.append([y.detach().double(), o.grad.double(), t.grad.double(), s.grad.double()])
+    assert res[0][3].shape == sink.shape
+    for name, a, b in zip(("out", "grad out", "grad token", "grad sink"), *res):
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+        assert err <= tol * (4 if name == "grad token" else 1), f"{name}: {err:.3e}"
+
+
+@pytest.mark.gpu
 def test_llama_layer_training_step_with_the_residual_handed_over():
     """``layer(x, ..., residual=x)`` with gradients (norm + residual and gate + residual as one Function each, the heads
     stacked) against ``x + layer(x, ...)`` with ``stack_heads_in_training = False`` -- the round-3 statement -- in bf16:

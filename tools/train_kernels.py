@@ -54,8 +54,13 @@ else:
     feats = [torch.randn(B, n, 1024, s, s, device=dev, dtype=dt) for s in (64, 32, 16, 8)]
     mask = torch.ones(B, n, device=dev, dtype=torch.long)
     net.train()
+    if "nockpt" in sys.argv:            # (the replayed step of tools/module_bench.py runs without checkpointing)
+        for blk in net._blocks():
+            blk.gradient_checkpointing = False
 
     def step():
+        for p in net.parameters():
+            p.grad = None
         r = [x.clone().requires_grad_(True) for x in res]
         m, rr = net(mid.clone().requires_grad_(True), r, feats, mask)
         (m.float().sum() + sum(x.float().sum() for x in rr)).backward()
