@@ -196,7 +196,10 @@ class LlamaMMFSSchedule:
         n0, v0 = self.layers[0].norm2, self.layers[0].attn.value_proj
         return all(l.norm2.weight.shape == n0.weight.shape and l.norm2.variance_epsilon == n0.variance_epsilon
                    and l.attn.value_proj.weight.shape == v0.weight.shape
-                   and (l.attn.value_proj.bias is None) == (v0.bias is None) for l in self.layers)
+                   and (l.attn.value_proj.bias is None) == (v0.bias is None)
+                   # (the batched projection evaluates these layers' mathematics without calling them: only unobserved)
+                   and type(l.attn.value_proj) is nn.Linear and hook_free(l.attn.value_proj) and hook_free(l.norm2)
+                   for l in self.layers)
 
     def _weights(self):
         return (cache_epoch(),) + tuple((p.data_ptr(), tensor_version(p)) for l in self.layers

@@ -339,7 +339,10 @@ class MMFSNet(CacheInvalidation, nn.Module):
         return all(isinstance(b.feat_norm, nn.LayerNorm) and b.feat_norm.elementwise_affine
                    and b.feat_norm.bias is not None
                    and b.feat_norm.normalized_shape == n0.normalized_shape and b.feat_norm.eps == n0.eps
-                   and b.mmfs.value_proj.weight.shape == v0.weight.shape for b in blocks)
+                   and b.mmfs.value_proj.weight.shape == v0.weight.shape
+                   # (the batched projection evaluates these layers' mathematics without calling them: only unobserved)
+                   and type(b.mmfs.value_proj) is nn.Linear and hook_free(b.mmfs.value_proj) and hook_free(b.feat_norm)
+                   for b in blocks)
 
     def project_features(self, mmfs_features):
         """Per level [B, n, C, h_l, w_l] -> ``ProjectedFeatures``: the bank normalised ONCE, then

@@ -924,3 +924,17 @@ def test_hooked_layers_are_called_as_layers(oracle_op):
     finally:
         hg.remove()
     assert hook_free(proj)
+    # the decoder-level schedule (one batched value projection for all layers) steps aside for a hooked value_proj
+    from mmfs_amd.blocks import LlamaMMFSSchedule
+    sched = LlamaMMFSSchedule(layers)
+    assert sched.can_fuse()
+    hv = l.attn.value_proj.register_forward_hook(lambda m, i, o: seen.append("value_proj"))
+    try:
+        assert not sched.can_fuse()
+        with torch.no_grad():
+            bank = sched.project(f)
+            l(h.detach(), f, mask, value=bank.values[0])
+        assert "value_proj" in seen
+    finally:
+        hv.remove()
+    assert sched.can_fuse()
