@@ -82,14 +82,24 @@ def one_case(rng, idx):
     else:
         os.environ.pop("MMFS_SORT_WINDOW_KB", None)
     os.environ["MMFS_SORT_MANY_POINTS"] = rng.choice(["0", "1", "1"])
+    # round 4: the forward's third kernel wherever it is supported (the library's own choice takes it only where the whole
+    # pyramid is resident), next to the library's choice and the two older kernels
+    MSDA._fwd_algo = rng.choice(["auto", "auto", "slices", "slices", "gather", "lds"])
     MSDA._ws_cache.clear()
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
     desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
-            f"value={algo} bwd={MSDA._bwd_algo}")
+            f"value={algo} bwd={MSDA._bwd_algo} fwd={MSDA._fwd_algo}")
     dsh, dst = dev(sh), dev(st)
     if registered:
         MSDA.register_level_tables(dsh, dst, S, sh.numpy(), st.numpy())
-    out = MSDA.ms_deform_attn_forward(dev(value), dsh, dst, dev(loc), dev(attn), 1)
+    try:
+        out = MSDA.ms_deform_attn_forward(dev(value), dsh, dst, dev(loc), dev(attn), 1)
+    except RuntimeError as e:            # a forced kernel refuses shapes outside its range: the library's choice then
+        if MSDA._fwd_algo == "auto" or f"status {MSDA._E_UNSUPPORTED}" not in str(e):
+            raise
+        MSDA._fwd_algo = "auto"
+        desc += " (forced kernel: unsupported)"
+        out = MSDA.ms_deform_attn_forward(dev(value), dsh, dst, dev(loc), dev(attn), 1)
     gv, gl, ga = MSDA.ms_deform_attn_backward(dev(value), dsh, dst, dev(loc), dev(attn), dev(grad), 1)
     torch.cuda.synchronize()
     want = msda_oracle.forward(value, sh, st, loc, attn)

@@ -21,9 +21,9 @@ def _fuzz():
 @pytest.fixture
 def restore_knobs():
     import MultiScaleDeformableAttention as MSDA
-    keep = (MSDA._hybrid, MSDA._bwd_algo, os.environ.get("MMFS_VALUE_ALGO"))
+    keep = (MSDA._hybrid, MSDA._bwd_algo, os.environ.get("MMFS_VALUE_ALGO"), MSDA._fwd_algo)
     yield
-    MSDA._hybrid, MSDA._bwd_algo = keep[0], keep[1]
+    MSDA._hybrid, MSDA._bwd_algo, MSDA._fwd_algo = keep[0], keep[1], keep[3]
     if keep[2] is None:
         os.environ.pop("MMFS_VALUE_ALGO", None)
     else:
