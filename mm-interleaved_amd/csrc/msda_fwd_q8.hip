@@ -601,7 +601,7 @@ bool fwd_q8_applies(int dtype, const Dims &d)
     // ViT-Adapter's injector (42 -> 35 us).  With a row-gather level left (the image decoder's 64x64: 335 vs 339 us; the
     // LLM's 4 images: 234 vs 222) it does not pay, and heads of 128 channels pay the per-sample arithmetic four times
     // (north star: 196 us against msda_fwd_mma's 128).
-    return d.D <= 64 && q8_all_resident_likely(d) && d.S >= 512 && d.Nq >= 128 && (int64_t)d.Nq * d.K >= 4096;
+    return d.D <= 64 && q8_all_resident_likely(d) && d.S >= 512 && d.Nq >= 128 && (int64_t)d.Nq * d.K >= 3072;      // (the injector: 256 queries x 12 samples per image fill)
 }
 
 hipError_t forward_q8(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
