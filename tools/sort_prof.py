@@ -7,9 +7,12 @@ import MultiScaleDeformableAttention as MSDA
 
 dev = "cuda"
 B, H, D, Nq, P = 8, 8, 128, 4096, 4
-shapes = torch.tensor([(64, 64), (32, 32), (16, 16), (8, 8)], device=dev)
+lv = [(64, 64), (32, 32), (16, 16), (8, 8)]
+if len(sys.argv) > 1 and sys.argv[1] == "injector":            # ViT-Adapter injector: 512 small slices
+    B, H, D, Nq, P, lv = 32, 16, 32, 256, 4, [(32, 32), (16, 16), (8, 8)]
+shapes = torch.tensor(lv, device=dev)
 start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
-S, L = int(shapes.prod(1).sum()), 4
+S, L = int(shapes.prod(1).sum()), len(lv)
 g = torch.Generator(device=dev).manual_seed(0)
 value = torch.rand(B, S, H, D, device=dev, generator=g).bfloat16()
 loc = torch.rand(B, Nq, H, L, P, 2, device=dev, generator=g).bfloat16()
