@@ -53,12 +53,24 @@ def one_case(rng, idx):
     mask = (torch.rand(N, n, generator=g) < 0.8).float().to(DEV)
     mask[:, 0] = 1
     desc = f"#{idx} {str(dtype)[6:]} H{H} D{D} L{L} P{P} n{n} {sizes} dq{dq} N{N} Lq{Lq} nice={nice}"
+    # round 4: at most 8 queries per (sample, head) take mmfs_sample_decode (same products, the fp32 sums in another
+    # order: equal within the storage type's rounding); with MMFS_SAMPLE_DECODE=0 they stay on the in-order kernel
+    from mmfs_amd.functions.mmfs_plan_func import sample_forward_groups
+    os.environ["MMFS_SAMPLE_DECODE"] = rng.choice(["0", "1"])
+    in_order = sample_forward_groups(dtype, Lq, D, n * L, P) <= 1
+    desc += f" decode_kernel={not in_order}"
     outs = {}
     for fused in (True, False):
         m.fused_sampler = fused
         with torch.no_grad():
             outs[fused] = m(query, ref, feat, shapes, start, None, mask)
-    ok = torch.equal(outs[True], outs[False]) and bool(torch.isfinite(outs[True]).all())
+    if in_order:
+        ok = torch.equal(outs[True], outs[False])
+    else:
+        tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+        a, b = outs[True].double(), outs[False].double()
+        ok = bool(((a - b).abs().max() <= tol * b.abs().max().clamp_min(1.0)).item())
+    ok = ok and bool(torch.isfinite(outs[True]).all())
     if not ok:
         d = (outs[True].float() - outs[False].float()).abs()
         desc += f"  max diff {float(d.max()):.3e} in {int((d > 0).sum())} of {d.numel()}"
@@ -77,7 +89,7 @@ def main():
             print("FAIL", desc, flush=True)
         elif i < 10:
             print("ok  ", desc, flush=True)
-    print(f"{n_cases - bad}/{n_cases} cases bit-identical")
+    print(f"{n_cases - bad}/{n_cases} cases bit-identical (in-order kernel) / within the storage type's rounding (decode kernel)")
     sys.exit(1 if bad else 0)
 
 
