@@ -424,6 +424,10 @@ FULL = [
     ("cfg1", dict(B=2, H=8, D=32, Nq=1024, P=4, shapes=[(64, 64), (32, 32), (16, 16), (8, 8)]), torch.float32),
     ("cfg2_northstar", dict(B=8, H=8, D=128, Nq=4096, P=4, shapes=[(64, 64), (32, 32), (16, 16), (8, 8)]), torch.bfloat16),
     ("cfg5_llm_n4", dict(B=4, H=16, D=64, Nq=2048, P=8, shapes=[(32, 32), (16, 16), (8, 8)] * 4), torch.float16),
+    # the op inside BASELINE configs 3 and 4 at their batch (the decoders' real head geometry): one image per sequence --
+    # the shape whose forward is the sliced kernel by default (csrc/msda_fwd_q8.hip) -- and the image decoder's 512-px block
+    ("cfg3_llm_n1", dict(B=4, H=16, D=64, Nq=2048, P=8, shapes=[(32, 32), (16, 16), (8, 8)]), torch.bfloat16),
+    ("cfg4_sd_block", dict(B=8, H=16, D=64, Nq=4096, P=8, shapes=[(64, 64), (32, 32), (16, 16), (8, 8)]), torch.float16),
 ]
 
 
