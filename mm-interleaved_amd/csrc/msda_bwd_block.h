@@ -112,7 +112,15 @@ constexpr int kTB = 4;
 // per record, so their items hold twice / four times the records -- the same 256 KB of grad_out rows per item.  Measured,
 // r03r: 2048 at D = 128 costs the north star 18 us of reduce, 1024 at D = 64 costs the LLM shape 45 MB of fp32 partial
 // tiles each way -- and 20 us of the NEXT forward, whose inputs they push out of the memory-side cache)
-__host__ __device__ inline int tile_chunk(int D) { return MMFS_TILE_CHUNK * (D >= 128 ? 1 : D >= 64 ? 2 : 4); }
+// ... and a launch with FEW records gets shorter items: with the decoders' one-image geometry (4.9 M record visits, 7 000
+// items for 3 584 wave slots) the items of 2048 records are the long poles of the last round -- reduce 75 -> 62 us at half
+// the length (r04zt); from ~8 M visits on (4 images: 19.6 M, the image decoder's block: 26 M) the full length stands.
+__host__ __device__ inline int tile_chunk(const Dims &d)
+{
+    const int full = MMFS_TILE_CHUNK * (d.D >= 128 ? 1 : d.D >= 64 ? 2 : 4);
+    const long long visits = (long long)d.B * d.H * d.Nq * d.K * 25 / 16;
+    return (d.D == 64 && visits < 8000000LL) ? full / 2 : full;          // (heads of 32 channels: no difference either way)
+}
 
 struct TileHeader {
     uint32_t spare0[8];
@@ -155,7 +163,7 @@ constexpr uint32_t kVoidPart = 0xffffffffu;
 // items; the extra ones are queued, slice by slice.
 __device__ inline void queue_block(const TileReduceArgs &a, const Dims &d, int64_t bh, int blk, TileDesc &td, int64_t n)
 {
-    const uint32_t parts = (uint32_t)((n + tile_chunk(d.D) - 1) / tile_chunk(d.D));
+    const uint32_t parts = (uint32_t)((n + tile_chunk(d) - 1) / tile_chunk(d));
     if (parts > 1) {
         const uint32_t pb = atomicAdd(&a.th->n_partials, parts);
         const uint32_t eb = atomicAdd(&a.n_extra[bh], parts - 1);
@@ -245,7 +253,7 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
     TileDesc td;
     const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
     a.tdesc[bh * a.blocks_bound + blk] = td;
-    const uint32_t parts = (uint32_t)((n + tile_chunk(d.D) - 1) / tile_chunk(d.D));
+    const uint32_t parts = (uint32_t)((n + tile_chunk(d) - 1) / tile_chunk(d));
     if (parts > 1) {
         pd.blk = blk; pd.parts = parts;
         pd.pb = atomicAdd(&a.th->n_partials, parts);

@@ -1089,9 +1089,9 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     if (tile_reduce_supported(dtype, d)) {
         const int64_t tvisits = pts * (kTB + 1) * (kTB + 1) / (kTB * kTB);
         s.tile_blocks_bound = (int)std::min<int64_t>((int64_t)d.S / 4 + d.L + 1, 0x3fffffff);
-        s.tile_cap_partials = (uint32_t)std::min<int64_t>(2 * (tvisits / tile_chunk(d.D)) + 64, 0x3fffffff);
+        s.tile_cap_partials = (uint32_t)std::min<int64_t>(2 * (tvisits / tile_chunk(d)) + 64, 0x3fffffff);
         // queue places per (b, h) slice: twice what the slice's average share of the visits needs
-        s.tile_cap_extra = (uint32_t)std::min<int64_t>(2 * ((int64_t)d.Nq * d.L * d.P * (kTB + 1) * (kTB + 1) / (kTB * kTB) / tile_chunk(d.D)) + 16, 0x3fffffff);
+        s.tile_cap_extra = (uint32_t)std::min<int64_t>(2 * ((int64_t)d.Nq * d.L * d.P * (kTB + 1) * (kTB + 1) / (kTB * kTB) / tile_chunk(d)) + 16, 0x3fffffff);
         s.th = (TileHeader *)p;      p += up(sizeof(TileHeader));
         s.tdesc = (TileDesc *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TileDesc));
         s.titems = (TileItem *)p;    p += up((int64_t)d.B * d.H * s.tile_cap_extra * sizeof(TileItem));

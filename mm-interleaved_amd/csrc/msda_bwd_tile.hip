@@ -179,8 +179,8 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
 #pragma unroll
     for (int r = 0; r < 5; ++r) pre[r + 1] = pre[r] + td.cnt[r];
     const int n = pre[5];
-    const int e0 = it.part * tile_chunk(D);
-    const int e1 = it.whole ? n : min(n, e0 + tile_chunk(D));
+    const int e0 = it.part * tile_chunk(d);
+    const int e1 = it.whole ? n : min(n, e0 + tile_chunk(d));
     const int cnt = e1 > e0 ? e1 - e0 : 0;                        // records of this item
     const int nks = (cnt + kKS - 1) / kKS;
     const int rounds = (nks + 3) / 4;
@@ -505,7 +505,7 @@ bool tile_reduce_supported(int dtype, const Dims &d)
     if (d.L > kMaxLevels) return false;
     if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'b' || e[0] == 'p') return false;     // "block", "pixel"
     // queue entries carry (b, h) and the block in 32 bits each; grid = B*H*blocks (+ queue) workgroups
-    if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1 + 2 * ((int64_t)d.Nq * d.L * d.P * 25 / 16 / tile_chunk(d.D)) + 16) > 0x7fffffffLL) return false;
+    if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1 + 2 * ((int64_t)d.Nq * d.L * d.P * 25 / 16 / tile_chunk(d)) + 16) > 0x7fffffffLL) return false;
     // the rows are fetched through a buffer descriptor over one (b, h) slice: 31-bit byte offsets
     const int64_t es = 2;
     if ((int64_t)d.Nq * d.H * d.D * es > kMaxSlabBytes) return false;
