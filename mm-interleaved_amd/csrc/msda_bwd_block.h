@@ -106,10 +106,10 @@ __device__ __host__ inline const CTile *tiles_of(const CellHeader *h, int L) { r
 // a block of more than one item leaves fp32 partial tiles that a last small kernel adds up.
 constexpr int kTB = 4;
 #ifndef MMFS_TILE_CHUNK
-#define MMFS_TILE_CHUNK 1024
+#define MMFS_TILE_CHUNK 768      // (r04zu: 640 / 768 / 896 / 1024 / 1280 / 1536 -> north star's reduce 136 / 134 / 135 / 137 / 138 / 137 us)
 #endif
 // (records per work item: MMFS_TILE_CHUNK for heads of 128 channels; narrower heads move half / a quarter of the bytes
-// per record, so their items hold twice / four times the records -- the same 256 KB of grad_out rows per item.  Measured,
+// per record, so their items hold twice / four times the records -- the same 192 KB of grad_out rows per item.  Measured,
 // r03r: 2048 at D = 128 costs the north star 18 us of reduce, 1024 at D = 64 costs the LLM shape 45 MB of fp32 partial
 // tiles each way -- and 20 us of the NEXT forward, whose inputs they push out of the memory-side cache)
 // ... and a launch with FEW records gets shorter items: with the decoders' one-image geometry (4.9 M record visits, 7 000
