@@ -28,7 +28,7 @@ from torch import nn
 
 from ..functions import MSDeformAttnFunction
 from ..functions.linear_func import small_linear, token_linear
-from ..functions.norm_func import GatedProjectionFunction, IgnoreTokenFunction
+from ..functions.block_func import GatedProjectionFunction, IgnoreTokenFunction
 from ..functions.mmfs_plan_func import MMFSHeadsPlanFunction, MMFSPlanFunction, mmfs_plan_supported, mmfs_sample_forward
 from ..levels import CacheInvalidation, cache_epoch, hook_free, host_shapes, tensor_version
 
@@ -392,7 +392,7 @@ class MMFS(CacheInvalidation, nn.Module):
         tok = self.ignore_token.view(1, 1, self.n_heads, -1)
         if (out.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and tok.dtype == out.dtype
                 and out.dtype in (torch.float16, torch.bfloat16) and out.is_contiguous()):
-            # one product each way instead of four passes over [tokens, d_inner] tensors (functions/norm_func.py)
+            # one product each way instead of four passes over [tokens, d_inner] tensors (functions/block_func.py)
             out = IgnoreTokenFunction.apply(out.view(N * Lq, -1), tok.view(self.n_heads, -1),
                                             sink_w.reshape(N * Lq, self.n_heads)).view(N, Lq, -1)
         else:

@@ -731,7 +731,7 @@ def test_llama_layer_in_inference_mode_then_no_grad_then_training(oracle_op):
 def test_gated_projection_function_gradients(with_bias):
     """``GatedProjectionFunction`` (residual + g (x W^T + b), the gate applied to the small side of every backward product)
     against autograd's gradients of the framework statement, fp64."""
-    from mmfs_amd.functions.norm_func import GatedProjectionFunction
+    from mmfs_amd.functions.block_func import GatedProjectionFunction
     g = torch.Generator().manual_seed(2)
     mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).requires_grad_(True)
     x, W, b, gate, res = mk(2, 5, 6), mk(7, 6), (mk(7) if with_bias else None), mk(1), mk(2, 5, 7)
@@ -747,7 +747,7 @@ def test_gated_projection_function_gradients(with_bias):
 def test_ignore_token_function_gradients(token_grad):
     """``IgnoreTokenFunction`` (out + token * sink per head as one block-diagonal product each way) against autograd's
     gradients of the framework statement, fp64."""
-    from mmfs_amd.functions.norm_func import IgnoreTokenFunction
+    from mmfs_amd.functions.block_func import IgnoreTokenFunction
     g = torch.Generator().manual_seed(3)
     T, H, D = 11, 4, 6
     out = torch.randn(T, H * D, generator=g, dtype=torch.float64).requires_grad_(True)

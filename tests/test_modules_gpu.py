@@ -619,7 +619,7 @@ def test_llama_layer_with_the_fused_norm_and_schedule_matches_the_layerwise_path
 def test_gated_projection_with_the_residual_handed_over(dtype, tol, with_bias):
     """``GatedProjectionFunction``: residual + g * (x W^T + b) as one node -- the gate applied to the small side of every
     backward product -- against the framework's statement in fp64 on the same stored inputs: value and every gradient."""
-    from mmfs_amd.functions.norm_func import GatedProjectionFunction
+    from mmfs_amd.functions.block_func import GatedProjectionFunction
     g = torch.Generator().manual_seed(5)
     x = torch.randn(3, 37, 256, generator=g).to(DEV, dtype)
     W = (torch.randn(512, 256, generator=g) * 0.05).to(DEV, dtype)
@@ -674,7 +674,7 @@ def test_token_linear_weight_gradient_in_chunks(dtype, tol, T, N, K):
 def test_ignore_token_term_as_one_product(dtype, tol):
     """``IgnoreTokenFunction`` on the device, 16-bit storage with the plan's fp32 sink weights: value and gradients against
     the framework statement in fp64 on the same stored operands."""
-    from mmfs_amd.functions.norm_func import IgnoreTokenFunction
+    from mmfs_amd.functions.block_func import IgnoreTokenFunction
     g = torch.Generator().manual_seed(9)
     T, H, D = 4096, 16, 64
     out = torch.randn(T, H * D, generator=g).to(DEV, dtype)
