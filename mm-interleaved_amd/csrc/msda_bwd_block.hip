@@ -118,9 +118,10 @@ msda_bwd_prepare(const char *__restrict__ loc, char *__restrict__ loc_t, int vb_
 }
 
 // Exclusive prefix sum over a[0..n) (n <= kMaxTileCells), total left in a[n].
+template <int THREADS>
 __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
 {
-    constexpr int PER = kMaxTileCells / kThreads;
+    constexpr int PER = kMaxTileCells / THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t c[PER], v = 0;
 #pragma unroll
@@ -144,7 +145,7 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
         if (tid * PER + i < n) a[tid * PER + i] = run;
         run += c[i];
     }
-    if (tid == kThreads - 1) a[n] = run;
+    if (tid == THREADS - 1) a[n] = run;
     __syncthreads();
 }
 
@@ -194,7 +195,7 @@ template <typename T> __device__ __forceinline__ uint32_t raw_bits(T v)
 }
 template <> __device__ __forceinline__ uint32_t raw_bits<float>(float) { return 0u; }
 
-template <typename T, int MODE, int NV, bool COMPACT>
+template <typename T, int MODE, int NV, bool COMPACT, int THREADS>
 __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T *__restrict__ attn,
                                              const Dims &d, const CTile &tl, int b, int h,
                                              uint32_t *off, uint32_t *cur, void *__restrict__ list)
@@ -202,7 +203,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
     const int tw = tl.xb - tl.xa;
     const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
     if (NV == 0) {
-        for (int q = (int)threadIdx.x; q < d.Nq; q += kThreads) {
+        for (int q = (int)threadIdx.x; q < d.Nq; q += THREADS) {
             const int64_t s0 = s_first + (int64_t)q * d.P;
             for (int p = 0; p < d.P; ++p) {
                 const T lx = loc[2 * (s0 + p)], ly = loc[2 * (s0 + p) + 1], a = attn[s0 + p];
@@ -215,12 +216,12 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
     typedef Vec16<T> V;
     constexpr int VEC = V::N;
     constexpr int NVV = NV > 0 ? NV : 1;
-    for (int q0 = (int)threadIdx.x; q0 < d.Nq; q0 += kThreads * kScanUnroll) {
+    for (int q0 = (int)threadIdx.x; q0 < d.Nq; q0 += THREADS * kScanUnroll) {
         uint4 lraw[kScanUnroll][NVV];
         uint2 araw[kScanUnroll][NVV];
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int q = q0 + u * kThreads;
+            const int q = q0 + u * THREADS;
             const int64_t s0 = s_first + (int64_t)min(q, d.Nq - 1) * d.P;
 #pragma unroll
             for (int v = 0; v < NVV; ++v) {
@@ -230,7 +231,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
         }
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int q = q0 + u * kThreads;
+            const int q = q0 + u * THREADS;
             if (q >= d.Nq) break;
 #pragma unroll
             for (int v = 0; v < NVV; ++v) {
@@ -249,7 +250,7 @@ __device__ __forceinline__ void scan_samples(const T *__restrict__ loc, const T 
     }
 }
 
-// Nq <= kThreads * kScanUnroll (one trip of the scan): a thread's samples stay in its registers between the
+// Nq <= THREADS * kScanUnroll (one trip of the scan): a thread's samples stay in its registers between the
 // counting pass and the placing pass, with the cell and the RANK inside the cell the counting atomic returned
 // -- the placing pass then needs no atomic and no second read of loc / attn: slot = off[cell] + rank.
 // (The second scan with its returning LDS atomics was 12 of the workgroup's 36 kclk at the north star.)
@@ -260,7 +261,7 @@ constexpr bool kWindowRounds = MMFS_SORT_WINDOW_ROUNDS != 0;       // a kept sca
 constexpr uint32_t kNoCell = 0xffffffffu;
 constexpr int kCellBits = 13;
 static_assert(kMaxTileCells <= (1 << kCellBits), "a cell index and a rank share one word");
-template <typename T, int NV, bool COMPACT>
+template <typename T, int NV, bool COMPACT, int THREADS>
 struct KeptScan {
     typedef Vec16<T> V;
     static constexpr int VEC = V::N, SPV = V::N / 2;
@@ -271,7 +272,7 @@ struct KeptScan {
     // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits).
     static constexpr bool kKeepRaw = NV == 1;
     // G > 1: a query's samples span G * NV vectors (many points per query: the reference's own speed test has 64);
-    // "virtual query" tid + u * kThreads then stands for vectors (qv % G) * NV .. + NV of query qv / G
+    // "virtual query" tid + u * THREADS then stands for vectors (qv % G) * NV .. + NV of query qv / G
     int G = 1;
 
     // in_place: loc / attn are the op's own [B, Nq, H, L, P] arrays (a query's P samples of this (h, level) are
@@ -284,7 +285,7 @@ struct KeptScan {
         const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int qv = min((int)threadIdx.x + u * kThreads, d.Nq * G - 1);
+            const int qv = min((int)threadIdx.x + u * THREADS, d.Nq * G - 1);
             const int qq = G == 1 ? qv : qv / G;
             const int v0 = (qv - qq * G) * NV;
             const int64_t s0 = in_place ? ((((int64_t)b * d.Nq + qq) * d.H + h) * d.L + tl.level) * d.P
@@ -302,7 +303,7 @@ struct KeptScan {
         const int tw = tl.xb - tl.xa;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const int q = (int)threadIdx.x + u * kThreads;                // (virtual query)
+            const int q = (int)threadIdx.x + u * THREADS;                // (virtual query)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float l[VEC], a[VEC];
@@ -327,7 +328,7 @@ struct KeptScan {
         if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
-            const uint32_t qv = threadIdx.x + u * kThreads;
+            const uint32_t qv = threadIdx.x + u * THREADS;
             const uint32_t q = G == 1 ? qv : qv / (uint32_t)G;            // the record carries the query
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -383,8 +384,12 @@ namespace {
 #endif
 
 // ---------------------------------------------------------------- kernel A: sort by cell
-template <typename T, int NV, bool COMPACT>
-__global__ void __launch_bounds__(kThreads)
+// THREADS: 1024 lanes, or 256 for tiles of few samples (launch_sort): four workgroups per CU instead of one, so that
+// the chain of dependent round trips a tile is (header, samples, counters, the level's cursor, records) overlaps with
+// three other tiles' -- at the ViT-Adapter injector's shape (512 slices x 3 levels of ~1000 samples) a 1024-lane
+// workgroup spends 7 us on a tile whatever its size, six rounds of them (tools/sort_prof.py injector, r04zw)
+template <typename T, int NV, bool COMPACT, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
                    const CellHeader *__restrict__ hdr, const Dims d, const TileParams tp, const int cell_stride,
@@ -398,7 +403,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     __shared__ uint32_t off[kMaxTileCells + 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char win[];
     uint32_t *cur = reinterpret_cast<uint32_t *>(win);          // (the direct path's cursors: it does not use the window)
-    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ uint32_t wave_tot[THREADS / 64];
     __shared__ uint32_t region;
 
     const int bid = blockIdx.x;
@@ -431,8 +436,8 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     constexpr int KNV = NV > 0 ? NV : 1;
     // (only where the launch expects windows: into memory, the two-scan path's stores are the faster -- SD 512 px
     // geometry, 32768 samples per level: 151 us against 196)
-    const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= kThreads * kScanUnroll && win_bytes > kMaxTileCells * 4u;
-    KeptScan<T, KNV, COMPACT> ks;
+    const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= THREADS * kScanUnroll && win_bytes > kMaxTileCells * 4u;
+    KeptScan<T, KNV, COMPACT, THREADS> ks;
     ks.G = tp.vgroups;
 
     // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
@@ -444,14 +449,14 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
 
     SPROF_DECL;
     if (kept) ks.load(loc, attn, d, tl, b, h, in_place);          // (in flight while the counters are cleared)
-    for (int i = tid; i < ncell; i += kThreads) { off[i] = 0u; if (!kept) cur[i] = 0u; }
+    for (int i = tid; i < ncell; i += THREADS) { off[i] = 0u; if (!kept) cur[i] = 0u; }
     __syncthreads();
     SPROF(0);
     if (kept) ks.count(d, tl, off);
-    else scan_samples<T, kCount, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, nullptr);
+    else scan_samples<T, kCount, NV, COMPACT, THREADS>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
     SPROF(1);
-    block_exclusive_scan(off, ncell, wave_tot);
+    block_exclusive_scan<THREADS>(off, ncell, wave_tot);
     SPROF(2);
     const uint32_t total = off[ncell];
     // this tile's slice of the (b, h, level) record area: the level's tiles share Nq*P slots
@@ -464,7 +469,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     // The cell table: read by the vector-ALU reduce and, for the matrix-core one, by the slice's last workgroup
     // for the blocks on the seams between tiles -- with no seam, by nobody.
     uint2 *tab = celltab + ((int64_t)b * d.H + h) * cell_stride + tl.cbase;
-    for (int p = tid; p < (ta.th != nullptr && !seamed ? 0 : ncell); p += kThreads) {
+    for (int p = tid; p < (ta.th != nullptr && !seamed ? 0 : ncell); p += THREADS) {
         const int cg = (tl.ya + p / tw) * (tl.Wl + 1) + tl.xa + p % tw;
         // (written through, agent scope: the slice's last workgroup reads the table within this launch)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&tab[cg]),
@@ -473,7 +478,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     }
     PendingBlock pending;
     pending.blk = -1;
-    if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, kThreads);
+    if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, THREADS);
     SPROF(3);
     // (a kept scan whose records exceed the window places them window by window: the records of a window are
     // consecutive slots, so each window leaves as one coalesced copy)
@@ -484,7 +489,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
         if (COMPACT) {
             const uint2 *src = reinterpret_cast<const uint2 *>(win);
             uint2 *dst = reinterpret_cast<uint2 *>(area) + s0;
-            for (uint32_t i = tid; i < n; i += kThreads) {
+            for (uint32_t i = tid; i < n; i += THREADS) {
 #ifdef MMFS_SORT_NT_RECS
                 __builtin_nontemporal_store(*reinterpret_cast<const unsigned long long *>(&src[i]), reinterpret_cast<unsigned long long *>(&dst[i]));
 #else
@@ -494,7 +499,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
         } else {
             const uint4 *src = reinterpret_cast<const uint4 *>(win);
             uint4 *dst = reinterpret_cast<uint4 *>(area) + s0;
-            for (uint32_t i = tid; i < n; i += kThreads) dst[i] = src[i];
+            for (uint32_t i = tid; i < n; i += THREADS) dst[i] = src[i];
         }
     };
     const bool rounds = kept && !windowed && kWindowRounds;
@@ -511,9 +516,9 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
             ks.place(loc, attn, d, tl, b, h, in_place, off, windowed ? (void *)win : area);
         } else if (windowed) {
             __syncthreads();                                      // the table and the plan have read off[]; now off[] becomes the cursors
-            scan_samples<T, kScatterLds, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, win);
+            scan_samples<T, kScatterLds, NV, COMPACT, THREADS>(loc, attn, d, tl, b, h, off, cur, win);
         } else {
-            scan_samples<T, kScatter, NV, COMPACT>(loc, attn, d, tl, b, h, off, cur, area);
+            scan_samples<T, kScatter, NV, COMPACT, THREADS>(loc, attn, d, tl, b, h, off, cur, area);
         }
         if (windowed && !rounds) {
             __syncthreads();
@@ -537,7 +542,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
         __syncthreads();
         SPROF(5);
         if (arrived == (uint32_t)hdr->n_tiles - 1u)
-            plan_slice_blocks(ta, d, (int64_t)b * d.H + h, tid, kThreads);
+            plan_slice_blocks(ta, d, (int64_t)b * d.H + h, tid, THREADS);
         SPROF(6);
     }
     SPROF_WG(2);
@@ -999,6 +1004,18 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
 // One or two vectors per query (P <= 8 of 16-bit storage): G = 1, every path of the sort takes them.  More (the reference's
 // own speed test has 64 points per level): only the kept scan can, as G groups of NV vectors -- when all of them fit one
 // trip and a window exists; else NV = 0, the scalar scan.  (MMFS_SORT_MANY_POINTS=0: always the scalar scan.)
+// Tiles of few samples -- a level of a slice has Nq * P of them -- go to 256-lane workgroups (msda_bwd_cell_sort): every
+// query still has a lane of the kept scan (Nq <= 256 * kScanUnroll), one group of vectors per query, and MANY slices
+// (otherwise there is nothing to overlap with).  MMFS_SORT_SMALL=0: always 1024 lanes.
+constexpr int kSmallThreads = 256;
+bool sort_small_tiles(const Dims &d, int vgroups, int nv)
+{
+    const char *e = getenv("MMFS_SORT_SMALL");                 // (read per call: the tests hold both variants to the oracle)
+    const bool off = e && e[0] == '0';
+    return !off && nv > 0 && vgroups == 1 && (int64_t)d.Nq * d.P <= 2048 && d.Nq <= kSmallThreads * kScanUnroll &&
+           (int64_t)d.B * d.H * d.L >= 512;
+}
+
 struct KeptCfg { int nv, g; };
 KeptCfg kept_config(int es, const Dims &d, const TileParams &tp, bool compact)
 {
@@ -1173,21 +1190,23 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     // the matrix-core reduce takes 8-byte records (its support test bounds Nq by 65536), the others 16-byte ones
     const bool compact = sizeof(T) == 2 && sc.th != nullptr;
     const uint32_t win = sort_window_bytes(d, tp, compact);
-    if (compact) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, sizeof(T) == 2>),
+    auto go = [&](auto tag_compact, auto tag_threads) {
+        constexpr bool C = decltype(tag_compact)::value;
+        constexpr int THREADS = decltype(tag_threads)::value;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, C, THREADS>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
         (void)once;
-        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, sizeof(T) == 2>), dim3((unsigned)blocks), dim3(kThreads), win, st,
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, C, THREADS>), dim3((unsigned)blocks), dim3(THREADS), win, st,
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                            cell_stride_of(d), win, tile_args(sc, d));
-    } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, false>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
-        (void)once;
-        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, false>), dim3((unsigned)blocks), dim3(kThreads), win, st,
-                           (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                           cell_stride_of(d), win, tile_args(sc, d));
-    }
+    };
+    const bool small = sort_small_tiles(d, vgroups, NV);
+    typedef std::integral_constant<bool, sizeof(T) == 2> Compact;
+    typedef std::integral_constant<bool, false> Wide;
+    typedef std::integral_constant<int, kThreads> Big;
+    typedef std::integral_constant<int, kSmallThreads> Small;
+    if (compact) { if (small) go(Compact(), Small()); else go(Compact(), Big()); }
+    else { if (small) go(Wide(), Small()); else go(Wide(), Big()); }
     return hipGetLastError();
 }
 

@@ -193,6 +193,26 @@ def test_cell_sort_routes_match_oracle(route, monkeypatch):
         MSDA._ws_cache.clear()
 
 
+@pytest.mark.parametrize("variant", ["256 lanes", "1024 lanes"])
+@pytest.mark.parametrize("dtype,P,hot", [(torch.bfloat16, 4, False), (torch.float16, 8, False), (torch.float32, 4, False),
+                                         (torch.bfloat16, 4, True)])
+def test_cell_sort_of_many_small_slices(dtype, P, hot, variant, monkeypatch):
+    """Tiles of few samples in MANY slices (the ViT-Adapter injector's regime: B*H*L >= 512, Nq*P <= 2048 samples per level
+    of a slice) are sorted by 256-lane workgroups, four per CU (csrc/msda_bwd_block.hip ``sort_small_tiles``); held to the
+    oracle next to the 1024-lane variant on the same inputs (``MMFS_SORT_SMALL=0``)."""
+    import MultiScaleDeformableAttention as MSDA
+    monkeypatch.setattr(MSDA, "_ws_cache", {})
+    monkeypatch.setenv("MMFS_SORT_SMALL", "1" if variant == "256 lanes" else "0")
+    x = make_inputs(8, 16, 32, 96, P, [(16, 16), (8, 8), (4, 8), (2, 2)], seed=17, loc_range=(-0.1, 1.1), dtype=dtype)
+    x["attn"][:, ::5, :, 2] = 0.0
+    if hot:                                                     # every sample of a level in a few cells: long lists, cut items
+        x["loc"][:, :, :, 1] = (x["loc"][:, :, :, 1] * 0.05 + 0.5).to(dtype).to(torch.float64)
+    try:
+        check(run_hip(x, dtype), run_oracle(x), dtype, f"small slices, {variant}")
+    finally:
+        MSDA._ws_cache.clear()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_every_query_on_one_spot_overflows_the_block_lists(dtype):
     """The LLM path's distribution: every token samples around the SAME reference point, so a few
