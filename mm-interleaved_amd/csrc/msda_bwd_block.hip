@@ -1004,16 +1004,18 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
 // One or two vectors per query (P <= 8 of 16-bit storage): G = 1, every path of the sort takes them.  More (the reference's
 // own speed test has 64 points per level): only the kept scan can, as G groups of NV vectors -- when all of them fit one
 // trip and a window exists; else NV = 0, the scalar scan.  (MMFS_SORT_MANY_POINTS=0: always the scalar scan.)
-// Tiles of few samples -- a level of a slice has Nq * P of them -- go to 256-lane workgroups (msda_bwd_cell_sort): every
-// query still has a lane of the kept scan (Nq <= 256 * kScanUnroll), one group of vectors per query, and MANY slices
-// (otherwise there is nothing to overlap with).  MMFS_SORT_SMALL=0: always 1024 lanes.
-constexpr int kSmallThreads = 256;
-bool sort_small_tiles(const Dims &d, int vgroups, int nv)
+// Tiles of few samples -- a level of a slice has Nq * P of them -- go to 256- or 512-lane workgroups (msda_bwd_cell_sort):
+// every query still has a lane of the kept scan (Nq <= lanes * kScanUnroll), one group of vectors per query, and MANY
+// slices (otherwise there is nothing to overlap with).  MMFS_SORT_SMALL=0: always 1024 lanes.
+constexpr int kSmallThreads = 256, kMidThreads = 512;
+int sort_lanes(const Dims &d, int vgroups, int nv)
 {
-    const char *e = getenv("MMFS_SORT_SMALL");                 // (read per call: the tests hold both variants to the oracle)
-    const bool off = e && e[0] == '0';
-    return !off && nv > 0 && vgroups == 1 && (int64_t)d.Nq * d.P <= 2048 && d.Nq <= kSmallThreads * kScanUnroll &&
-           (int64_t)d.B * d.H * d.L >= 512;
+    const char *e = getenv("MMFS_SORT_SMALL");                 // (read per call: the tests hold the variants to the oracle)
+    if ((e && e[0] == '0') || nv <= 0 || vgroups != 1 || (int64_t)d.B * d.H * d.L < 512) return kThreads;
+    const int64_t samples = (int64_t)d.Nq * d.P;
+    if (samples <= 2048 && d.Nq <= kSmallThreads * kScanUnroll) return kSmallThreads;
+    if (samples <= 8192 && d.Nq <= kMidThreads * kScanUnroll) return kMidThreads;      // (two per CU: the ViT-Adapter extractor)
+    return kThreads;
 }
 
 struct KeptCfg { int nv, g; };
@@ -1200,13 +1202,14 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                            cell_stride_of(d), win, tile_args(sc, d));
     };
-    const bool small = sort_small_tiles(d, vgroups, NV);
+    const int lanes = sort_lanes(d, vgroups, NV);
     typedef std::integral_constant<bool, sizeof(T) == 2> Compact;
     typedef std::integral_constant<bool, false> Wide;
     typedef std::integral_constant<int, kThreads> Big;
+    typedef std::integral_constant<int, kMidThreads> Mid;
     typedef std::integral_constant<int, kSmallThreads> Small;
-    if (compact) { if (small) go(Compact(), Small()); else go(Compact(), Big()); }
-    else { if (small) go(Wide(), Small()); else go(Wide(), Big()); }
+    if (compact) { if (lanes == kSmallThreads) go(Compact(), Small()); else if (lanes == kMidThreads) go(Compact(), Mid()); else go(Compact(), Big()); }
+    else { if (lanes == kSmallThreads) go(Wide(), Small()); else if (lanes == kMidThreads) go(Wide(), Mid()); else go(Wide(), Big()); }
     return hipGetLastError();
 }
 

@@ -193,17 +193,18 @@ def test_cell_sort_routes_match_oracle(route, monkeypatch):
         MSDA._ws_cache.clear()
 
 
-@pytest.mark.parametrize("variant", ["256 lanes", "1024 lanes"])
-@pytest.mark.parametrize("dtype,P,hot", [(torch.bfloat16, 4, False), (torch.float16, 8, False), (torch.float32, 4, False),
-                                         (torch.bfloat16, 4, True)])
-def test_cell_sort_of_many_small_slices(dtype, P, hot, variant, monkeypatch):
-    """Tiles of few samples in MANY slices (the ViT-Adapter injector's regime: B*H*L >= 512, Nq*P <= 2048 samples per level
-    of a slice) are sorted by 256-lane workgroups, four per CU (csrc/msda_bwd_block.hip ``sort_small_tiles``); held to the
-    oracle next to the 1024-lane variant on the same inputs (``MMFS_SORT_SMALL=0``)."""
+@pytest.mark.parametrize("variant", ["fewer lanes", "1024 lanes"])
+@pytest.mark.parametrize("dtype,P,Nq,hot", [(torch.bfloat16, 4, 96, False), (torch.float16, 8, 96, False), (torch.float32, 4, 96, False),
+                                            (torch.bfloat16, 4, 96, True), (torch.bfloat16, 4, 700, False), (torch.float16, 8, 600, True)])
+def test_cell_sort_of_many_small_slices(dtype, P, Nq, hot, variant, monkeypatch):
+    """Tiles of few samples in MANY slices (the ViT-Adapter's regime: B*H*L >= 512; Nq*P <= 2048 samples per level of a
+    slice: 256-lane sort workgroups, four per CU -- the injector; <= 8192: 512 lanes, two per CU -- the extractor;
+    csrc/msda_bwd_block.hip ``sort_lanes``), held to the oracle next to the 1024-lane variant on the same inputs
+    (``MMFS_SORT_SMALL=0``)."""
     import MultiScaleDeformableAttention as MSDA
     monkeypatch.setattr(MSDA, "_ws_cache", {})
-    monkeypatch.setenv("MMFS_SORT_SMALL", "1" if variant == "256 lanes" else "0")
-    x = make_inputs(8, 16, 32, 96, P, [(16, 16), (8, 8), (4, 8), (2, 2)], seed=17, loc_range=(-0.1, 1.1), dtype=dtype)
+    monkeypatch.setenv("MMFS_SORT_SMALL", "1" if variant == "fewer lanes" else "0")
+    x = make_inputs(8, 16, 32, Nq, P, [(16, 16), (8, 8), (4, 8), (2, 2)], seed=17, loc_range=(-0.1, 1.1), dtype=dtype)
     x["attn"][:, ::5, :, 2] = 0.0
     if hot:                                                     # every sample of a level in a few cells: long lists, cut items
         x["loc"][:, :, :, 1] = (x["loc"][:, :, :, 1] * 0.05 + 0.5).to(dtype).to(torch.float64)
