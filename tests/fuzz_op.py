@@ -37,6 +37,13 @@ def one_case(rng, idx):
         B, H, D, P = rng.randint(1, 2), rng.choice([4, 8, 16]), rng.choice([32, 64, 128]), rng.choice([4, 8])
         shapes = [(rng.randint(1, 64), rng.randint(1, 64)) for _ in range(L)]
         Nq = rng.choice([1024, 3000, 4097])
+    elif rng.random() < 0.08:      # many small slices (the encoders' regime): the cell sort's 256- / 512-lane workgroups
+        B, H, D, P = rng.choice([8, 16]), 16, 32, rng.choice([4, 8])
+        L = rng.choice([2, 4])
+        shapes = [(rng.randint(1, 16), rng.randint(1, 16)) for _ in range(L)]
+        Nq = rng.choice([33, 130, 600])
+        if dtype == torch.float64:
+            dtype = torch.bfloat16
     elif B * Nq * H * L * P * D > 6e7:
         Nq = 33 if P < 32 else 130
     g = torch.Generator().manual_seed(idx)
@@ -82,6 +89,7 @@ def one_case(rng, idx):
     else:
         os.environ.pop("MMFS_SORT_WINDOW_KB", None)
     os.environ["MMFS_SORT_MANY_POINTS"] = rng.choice(["0", "1", "1"])
+    os.environ["MMFS_SORT_SMALL"] = rng.choice(["0", "1", "1"])
     # round 4: the forward's third kernel wherever it is supported (the library's own choice takes it only where the whole
     # pyramid is resident), next to the library's choice and the two older kernels
     MSDA._fwd_algo = rng.choice(["auto", "auto", "slices", "slices", "gather", "lds"])
