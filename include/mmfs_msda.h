@@ -121,6 +121,12 @@ int mmfs_msda_forward(int dtype,
  *                16x16 + 8x8: 101 KB) is sampled by the matrix cores in tiles of 8 queries, the rest by row gather.
  * MMFS_FWD_SLICES on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
 #define MMFS_FWD_SLICES 4u
+/*   query waves  csrc/msda_fwd_wq.hip (round 5): 16-bit storage, D = 128, L <= 64.  A wave works on one query at a time;
+ *                a sample's four pixel rows -- one wave-wide load, from memory or from the LDS image of the levels that
+ *                fit -- are the B operand of ONE matrix-core product whose A operand carries the four bilinear weights
+ *                on a diagonal (no unpack, no multiply-add in the vector ALU).  The default for that shape.
+ * MMFS_FWD_QUERY_WAVES on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
+#define MMFS_FWD_QUERY_WAVES 8u
 int mmfs_msda_forward_flags(int dtype,
                             const void *value, const int64_t *shapes, const int64_t *start,
                             const void *loc, const void *attn, void *out,

@@ -281,7 +281,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 # tests / measurements: which formulation of the forward runs (include/mmfs_msda.h, mmfs_msda_forward_flags):
 # "auto" | "gather" (csrc/msda_fwd.hip) | "lds" (csrc/msda_fwd_mma.hip; unsupported shapes raise)
 _fwd_algo = "auto"
-_FWD_FLAGS = {"auto": 0, "gather": 1, "lds": 2, "slices": 4}        # "slices": csrc/msda_fwd_q8.hip
+_FWD_FLAGS = {"auto": 0, "gather": 1, "lds": 2, "slices": 4, "waves": 8}        # "slices": csrc/msda_fwd_q8.hip; "waves": msda_fwd_wq.hip
 
 
 # flags of mmfs_msda_backward (include/mmfs_msda.h)

@@ -104,7 +104,8 @@ int mmfs_msda_forward_flags(int dtype, const void *value, const int64_t *shapes,
         return MMFS_E_ALIGN;
     if ((flags & MMFS_FWD_LDS_LEVELS) && !mmfs::fwd_mma_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
     if ((flags & MMFS_FWD_SLICES) && !mmfs::fwd_q8_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
-    const int algo = (flags & MMFS_FWD_SLICES) ? 3 : (flags & MMFS_FWD_LDS_LEVELS) ? 2 : (flags & MMFS_FWD_ROW_GATHER) ? 1 : 0;
+    if ((flags & MMFS_FWD_QUERY_WAVES) && !mmfs::fwd_wq_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
+    const int algo = (flags & MMFS_FWD_QUERY_WAVES) ? 4 : (flags & MMFS_FWD_SLICES) ? 3 : (flags & MMFS_FWD_LDS_LEVELS) ? 2 : (flags & MMFS_FWD_ROW_GATHER) ? 1 : 0;
     return (int)mmfs::forward(dtype, value, shapes, start, loc, attn, out, d, st, algo);
 }
 

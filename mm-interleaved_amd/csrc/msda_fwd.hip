@@ -324,6 +324,8 @@ static hipError_t dispatch_fwd(const void *value, const int64_t *shapes, const i
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st, int algo)
 {
+    if (algo == 4 || (algo == 0 && fwd_wq_applies(dtype, d)))
+        return forward_wq(dtype, value, shapes, start, loc, attn, out, d, st);
     if (algo == 3 || (algo == 0 && fwd_q8_applies(dtype, d)))
         return forward_q8(dtype, value, shapes, start, loc, attn, out, d, st);
     if (algo == 2 || (algo == 0 && fwd_mma_applies(dtype, d)))

@@ -10,7 +10,8 @@ namespace mmfs {
 
 // dtype codes are enum mmfs_dtype of include/mmfs_msda.h
 // algo: 0 the library chooses, 1 row gather (msda_fwd.hip), 2 LDS-resident levels (msda_fwd_mma.hip; the
-// caller has checked fwd_mma_supported), 3 slices of 32 channels (msda_fwd_q8.hip; fwd_q8_supported)
+// caller has checked fwd_mma_supported), 3 slices of 32 channels (msda_fwd_q8.hip; fwd_q8_supported), 4 a wave per
+// query (msda_fwd_wq.hip; fwd_wq_supported)
 hipError_t forward(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                    const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st, int algo = 0);
 
@@ -26,6 +27,13 @@ hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, cons
 bool fwd_q8_supported(int dtype, const Dims &d);
 bool fwd_q8_applies(int dtype, const Dims &d);
 hipError_t forward_q8(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                      const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
+
+// Fourth formulation of the forward for 16-bit storage, D = 128: a wave per query, the bilinear weights on the diagonal
+// of the matrix cores' A operand, the pixel rows as loaded (memory or LDS) as the B operand.      [msda_fwd_wq.hip]
+bool fwd_wq_supported(int dtype, const Dims &d);
+bool fwd_wq_applies(int dtype, const Dims &d);
+hipError_t forward_wq(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
                       const void *loc, const void *attn, void *out, const Dims &d, hipStream_t st);
 
 // Location / attention-weight gradients (always) and, when scatter is true, grad_value

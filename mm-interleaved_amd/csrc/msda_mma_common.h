@@ -42,6 +42,15 @@ template <> struct FwdMma<bf16_t> {
         hi = h >> 16;
         lo = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(w - __uint_as_float(h)));
     }
+    // the same two parts, each in BOTH halves of a word (msda_fwd_wq.hip: the lane's mask picks the half)
+    static __device__ __forceinline__ void split_dup(float w, uint32_t &hi2, uint32_t &lo2) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const uint32_t b = __float_as_uint(w);
+        hi2 = __builtin_amdgcn_perm(b, b, 0x03020302u);                  // (bytes 2, 3 of w twice)
+        const float r = w - __uint_as_float(b & 0xffff0000u);
+        bf2 p; p[0] = (__bf16)r; p[1] = (__bf16)r;
+        lo2 = __builtin_bit_cast(uint32_t, p);
+    }
 };
 template <> struct FwdMma<half_t> {
     static __device__ __forceinline__ f32x4 run(const s16x8 &a, const s16x8 &b, const f32x4 &c) {
@@ -53,6 +62,16 @@ template <> struct FwdMma<half_t> {
         const _Float16 l = (_Float16)(c - (float)h);
         hi = (uint32_t)__builtin_bit_cast(uint16_t, h);
         lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
+    }
+    static __device__ __forceinline__ void split_dup(float w, uint32_t &hi2, uint32_t &lo2) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const float c = w != w ? w : fminf(fmaxf(w, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        const _Float16 l = (_Float16)(c - (float)h);
+        h2 ph; ph[0] = h; ph[1] = h;
+        h2 pl; pl[0] = l; pl[1] = l;
+        hi2 = __builtin_bit_cast(uint32_t, ph);
+        lo2 = __builtin_bit_cast(uint32_t, pl);
     }
 };
 

@@ -702,7 +702,7 @@ def test_sliced_forward_is_the_default_where_the_whole_pyramid_is_resident():
     x = make_inputs(1, 16, 64, 200, 8, [(64, 64)] + llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)   # 64 x 64 does not fit
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
     x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # heads of 128 channels
-    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "lds")) == 0.0
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
 
 
 def test_sliced_forward_non_finite_rows_stay_inside_their_tile():
@@ -768,14 +768,14 @@ def test_persistent_workgroups_compute_what_one_workgroup_per_run_does(shape, mo
     assert max_abs(res["default"][0].double().cpu().numpy(), want) <= TOL[torch.bfloat16] * max(1.0, float(np.abs(want).max()))
 
 
-def test_lds_levels_forward_is_the_default_for_long_runs(monkeypatch):
-    """From 4096 samples per (b, h) slab on (and at least 64 queries), 16-bit heads of 128 channels take the LDS-resident
-    formulation (and the autograd function's outputs and gradients still match the oracle on such a shape); below, the
-    row gather."""
+def test_query_wave_forward_is_the_default_for_long_runs(monkeypatch):
+    """From 4096 samples per (b, h) slab on (and at least 64 queries), 16-bit heads of 128 channels take the wave-per-query
+    formulation (round 5; rounds 3-4: the LDS-resident one of msda_fwd_mma.hip) -- and the autograd function's outputs and
+    gradients still match the oracle on such a shape; below, the row gather."""
     x = make_inputs(1, 4, 128, 100, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0     # 1200 samples
     x = make_inputs(1, 4, 128, 352, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
-    a, g = run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "lds")
+    a, g = run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")
     assert max_abs(a, g) == 0.0
     assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0        # (a different summation order: not bit-equal)
     check(run_hip(x, torch.bfloat16), run_oracle(x), torch.bfloat16, "auto-routed")
@@ -1085,3 +1085,85 @@ def test_value_plan_hosted_by_the_taps_kernel(dtype, monkeypatch):
         monkeypatch.setenv("MMFS_PREPARE_IN_TAPS", setting)
         for _ in range(2):
             check(run_hip(x, dtype, use_autograd=False, register=True), want, dtype, f"plan in dense taps = {setting}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The forward's fourth formulation (csrc/msda_fwd_wq.hip, round 5): a wave per query; a sample's four pixel rows -- one
+# wave-wide load from memory or from the LDS image -- are the B operand of ONE matrix-core product whose A operand carries
+# the four bilinear weights on a diagonal.  Heads of 128 channels, 16-bit storage; the default at the north-star shape.
+WAVE_CASES = [
+    # B, H, D, Nq, P, shapes                                           what it exercises
+    (1, 8, 128, 64, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),         # the north-star pyramid: two levels resident, K = 16
+    (1, 8, 128, 700, 4, [(64, 64), (32, 32), (16, 16), (8, 8)]),        # three runs of queries per slab, the last ragged
+    (2, 3, 128, 333, 4, [(16, 16), (8, 8), (20, 20), (5, 7)]),          # every level resident, ragged run, H not a power of two
+    (1, 2, 128, 70, 3, [(9, 5), (40, 40), (3, 3), (1, 1), (2, 9)]),     # K = 15: a ragged chunk; tails of the batches of four
+    (1, 4, 128, 50, 4, [(70, 70), (50, 50)]),                           # nothing fits: every product's rows from memory
+    (3, 8, 128, 1, 4, [(16, 16), (8, 8)]),                              # one query (decode)
+    (1, 2, 128, 90, 8, [(64, 64), (32, 32), (16, 16), (8, 8)]),         # K = 32: two chunks per query, the sums carried across
+    (1, 2, 128, 40, 2, [(3, 3)] * 60),                                  # L = 60, K = 120: eight chunks, everything resident
+    (1, 2, 128, 33, 5, [(32, 32), (16, 16), (8, 8)] * 4),               # 12 levels, K = 60: three full chunks and a ragged one; some levels resident
+    (2, 1, 128, 5000, 4, [(24, 24), (12, 12), (6, 6)]),                 # many runs per slab
+]
+
+
+@pytest.mark.parametrize("case", WAVE_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in WAVE_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_query_wave_forward_matches_oracle(case, dtype):
+    B, H, D, Nq, P, shapes = case
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=23, loc_range=(-0.15, 1.15), dtype=dtype)
+    x["loc"][0, 0, 0, 0, 0, 0] = float("nan")            # non-finite locations contribute nothing
+    x["loc"][0, Nq // 2, 1 % H, -1, 0, 1] = float("inf")
+    x["attn"][0, Nq - 1, 0, -1] = 0.0                     # zero weights read nothing
+    x["loc"][0, Nq // 3, 0, 0, -1] = torch.tensor([0.0, 1.0])            # a corner of the map: three of four corners outside
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    got = run_fwd(x, dtype, "waves")
+    scale = max(1.0, float(np.abs(want).max()))
+    assert max_abs(got, want) <= TOL[dtype] * scale, f"{case[:5]}: {max_abs(got, want):.3e}"
+    # and against the row-gather kernel: fp32 sums in another order, the weights as hi + lo 16-bit parts
+    ref = run_fwd(x, dtype, "gather")
+    assert max_abs(got, ref) <= 0.5 * TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_query_wave_forward_non_finite_values_stay_in_their_channel(dtype):
+    """The product's zero weights multiply the other channels of a sampled row (0 x Inf = NaN inside the 8-channel group of
+    a lane).  The kernel tests every query's sums and recomputes a query with a non-finite one channel by channel
+    (wq::exact_query): element for element the reference's result (cuh:58-81, :275-299) -- an Inf / NaN in ONE channel
+    of a row reaches that channel of the queries that sample the row with a valid corner, nothing else."""
+    shapes = [(64, 64), (4, 4), (2, 2)]                   # level 0 does not fit in LDS (rows from memory), the others do
+    B, H, D, Nq, P = 1, 2, 128, 600, 2
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=5, loc_range=(0.05, 0.95), dtype=dtype)
+    value = x["value"]
+    value[0, 65 * 20, 0, 3] = float("inf")                # level 0, single channels: pixel (20, 20)
+    value[0, 65 * 20 + 1, 0, 100] = float("-inf")         # ... (20, 21)
+    value[0, 65 * 10, 1, 77] = float("nan")
+    value[0, 4096 + 5, 1, 64] = float("nan")              # level 1
+    value[0, 4096 + 16 + 1, 0, 127] = float("inf")        # level 2
+    value[0, 65 * 30, 1, :] = float("nan")                # a whole row of level 0
+    x["attn"][0, 3, 0] = 0.0                              # a query that reads nothing at all in head 0
+    x["loc"][0, 5, 0] = 2.0                               # ... and one whose samples all fail the range test
+    x["loc"][0, 7, 0, 0, 0] = torch.tensor([20.5 / 64, 20.5 / 64])      # exactly on pixel (20, 20) in every arithmetic: its right
+                                                                        # neighbour weighs 0 x -Inf = NaN, as in the reference
+    want = msda_oracle.forward(value, x["shapes"], x["start"], x["loc"], x["attn"])
+    got = run_fwd(x, dtype, "waves")
+    fin_w, fin_g = np.isfinite(want), np.isfinite(got)
+    # (the library reads nothing where the attention weight is exactly 0, DESIGN 4.1: query 3 of head 0 is finite here)
+    want3 = want.reshape(Nq, H, D)[3, 0]
+    if not np.isfinite(want3).all():
+        fin_w.reshape(Nq, H, D)[3, 0] = True; want.reshape(Nq, H, D)[3, 0] = 0.0
+    assert (fin_w == fin_g).all(), np.argwhere(fin_w != fin_g)[:10]
+    assert (~fin_w).any() and fin_w.any()
+    n_bad_queries = int((~fin_w.reshape(Nq, H, D)).any(-1).sum())
+    assert 0 < n_bad_queries < Nq * H                      # (the 2 x 2 level's non-finite pixel is seen by most queries)
+    scale = max(1.0, float(np.abs(want[fin_w]).max()))
+    assert np.abs(got[fin_w] - want[fin_w]).max() <= TOL[dtype] * scale
+    assert (np.isnan(want) == np.isnan(got)).all()         # NaN vs +-Inf as the reference has them
+    assert (want[np.isinf(want)] == got[np.isinf(want)]).all()
+    ref = run_fwd(x, dtype, "gather")                     # the row gather agrees element for element on what is finite
+    assert (np.isfinite(ref) == fin_g).all()
+
+
+def test_query_wave_forward_is_the_default_at_the_north_star_shape():
+    llm = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
