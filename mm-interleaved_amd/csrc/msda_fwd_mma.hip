@@ -149,6 +149,8 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
     for (int step = 0; step < n_steps; ++step) {
+        // (as msda_fwd_wq.hip, r05f: the wave that is behind the others of its SIMD issues first)
+        { const int left = n_steps - 1 - step; if (left >= 3) __builtin_amdgcn_s_setprio(3); else if (left == 2) __builtin_amdgcn_s_setprio(2); else if (left == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         const int q0 = q_first + (step / n_chunks) * (kMmaWaves * QPW);
         const int chunk = step % n_chunks;
         const int k0 = chunk * kChunk;
