@@ -374,6 +374,15 @@ msda_fwd_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         if (chunk == n_chunks - 1) {
             const int q = q0 + qi;
             if (q < d.Nq) {
+                // (a non-finite sum: the lane's 8 channels again with the reference's arithmetic -- the products carry the
+                //  weights as hi + lo parts, and Inf x hi + Inf x lo is NaN where the reference has Inf; round 5)
+                float nf = acc[0] * 0.f;
+#pragma unroll
+                for (int i = 1; i < VEC; ++i) nf = fmaf(acc[i], 0.f, nf);
+                if (nf != nf) {
+                    const uint32_t s0q = (uint32_t)q * q_stride;
+                    exact_lane8<T>(tab, rsrc, row_bytes, loc_wg + 2 * (size_t)s0q, attn_wg + (size_t)s0q, d.K, d.P, lane_off, acc);
+                }
                 T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + lig * VEC;
                 store16_stream(o, V::pack(acc));             // (the output is not read again in the step: r03j)
             }

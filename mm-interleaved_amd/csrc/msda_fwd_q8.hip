@@ -205,6 +205,40 @@ __device__ __forceinline__ void fill_image(const int *tab, unsigned char *smem, 
     __syncthreads();
 }
 
+// Eight channels of one query, recomputed with the reference's per-channel arithmetic (cuh:275-299): fp32 multiply-add of
+// every element, corners outside the map skipped, a sample that fails the range test or carries a zero attention weight
+// reads nothing.  What a tile with a non-finite sum is redone with (round 5): a product multiplies the rows of EIGHT
+// queries with a block-diagonal weight tile, so a non-finite value turns the zeros of the other queries' weights into NaN
+// -- the reference keeps it with the queries that sample it.  A tile's sums are finite unless something non-finite was
+// multiplied, and then every query of the tile is recomputed here: element for element the reference's result.
+template <typename T>
+__device__ __forceinline__ void exact8(const uint4 *ktab, __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes,
+                                       const uint16_t *loc_q, const uint16_t *attn_q, int K, uint32_t piece_off, float (&acc)[8])
+{
+    typedef Vec16<T> V;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const uint4 ku = ktab[2 * k + 1];
+        const int lstart = (int)ku.x, Wl = (int)ku.y, Hl = (int)ku.z;
+        const float lx = to_f32(__builtin_bit_cast(T, loc_q[2 * k])), ly = to_f32(__builtin_bit_cast(T, loc_q[2 * k + 1]));
+        const float a = to_f32(__builtin_bit_cast(T, attn_q[k]));
+        const Tap<float> t = locate<float>(lx, ly, Hl, Wl, lstart);
+        if (a == 0.f) continue;
+        const float gy = 1.f - t.fy, gx = 1.f - t.fx;
+        const float w[4] = {gy * gx * a, gy * t.fx * a, t.fy * gx * a, t.fy * t.fx * a};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (t.row[c] < 0) continue;
+            const uint4 raw = buffer_load16(rsrc, (uint32_t)t.row[c] * row_bytes + piece_off);
+            float v[8];
+            V::unpack(raw, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(w[c], v[i], acc[i]);
+        }
+    }
+}
+
 }  // namespace q8
 
 template <typename T>
@@ -521,7 +555,15 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
                 s0.x += a0.x + b0.x; s0.y += a0.y + b0.y; s0.z += a0.z + b0.z; s0.w += a0.w + b0.w;
                 s1.x += a1.x + b1.x; s1.y += a1.y + b1.y; s1.z += a1.z + b1.z; s1.w += a1.w + b1.w;
             }
-            const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            // (a non-finite sum anywhere in the tile: every query of it channel by channel, see q8::exact8)
+            float nf = v[0] * 0.f;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) nf = fmaf(v[e], 0.f, nf);
+            if (__builtin_amdgcn_ballot_w64(nf != nf) != 0ull) {
+                const uint32_t s0q = (uint32_t)q * q_stride;
+                exact8<T>(ktab, rsrc, row_bytes, loc_wg + 2 * (size_t)s0q, attn_wg + (size_t)s0q, K, (uint32_t)(lane & 3) * 16u, v);
+            }
             T *o = out + (((int64_t)b * d.Nq + q) * d.H + h) * d.D + sl * kCS + (lane & 3) * 8;
             store16_stream(o, V::pack(v));
         }

@@ -145,40 +145,16 @@ __device__ __forceinline__ void fill_wait()
     __syncthreads();
 }
 
-// A query whose sums came out non-finite, recomputed with the reference's per-channel arithmetic (cuh:275-299): fp32
-// multiply-add of every element, corners outside the map skipped, a sample that fails the range test or carries a zero
-// attention weight reads nothing (as in every formulation of this library).  16 lanes x 8 channels; the other
-// lanes of the wave compute the same and do not store.  Not a tuned path.
+// A query whose sums came out non-finite, recomputed channel by channel (exact_lane8, msda_mma_common.h): 16 lanes x 8
+// channels; the other lanes of the wave compute the same and do not store.
 template <typename T, int D>
 __device__ __forceinline__ void exact_query(const int *tab, __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes,
-                                         const uint16_t *loc_q, const uint16_t *attn_q, int K, int P, T *out_row, int lane)
+                                            const uint16_t *loc_q, const uint16_t *attn_q, int K, int P, T *out_row, int lane)
 {
-    typedef Vec16<T> V;
     static_assert(D == 128, "16 lanes x 8 channels");
-    const uint32_t lane_off = (uint32_t)(lane & 15) * 16u;
     float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const int l = k / P;
-        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], lstart = tab[kTabInts * l + 2];
-        const float lx = to_f32(__builtin_bit_cast(T, loc_q[2 * k])), ly = to_f32(__builtin_bit_cast(T, loc_q[2 * k + 1]));
-        const float a = to_f32(__builtin_bit_cast(T, attn_q[k]));
-        const Tap<float> t = locate<float>(lx, ly, Hl, Wl, lstart);
-        if (a == 0.f) continue;
-        const float gy = 1.f - t.fy, gx = 1.f - t.fx;
-        const float w[4] = {gy * gx * a, gy * t.fx * a, t.fy * gx * a, t.fy * t.fx * a};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (t.row[c] < 0) continue;
-            const uint4 raw = buffer_load16(rsrc, (uint32_t)t.row[c] * row_bytes + lane_off);
-            float v[8];
-            V::unpack(raw, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(w[c], v[i], acc[i]);
-        }
-    }
-    if (lane < 16) store16_stream(out_row + (lane & 15) * 8, V::pack(acc));
+    exact_lane8<T>(tab, rsrc, row_bytes, loc_q, attn_q, K, P, (uint32_t)(lane & 15) * 16u, acc);
+    if (lane < 16) store16_stream(out_row + (lane & 15) * 8, Vec16<T>::pack(acc));
 }
 
 }  // namespace wq

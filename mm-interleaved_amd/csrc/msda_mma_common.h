@@ -117,6 +117,42 @@ template <int CTRL> __device__ __forceinline__ float dpp_move(float v)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Eight channels (one 16-byte piece, piece_off bytes into the head's row) of one query with the reference's per-channel
+// arithmetic (cuh:275-299): fp32 multiply-add of every element, corners outside the map skipped, a sample that fails the
+// range test or carries a zero attention weight reads nothing (as in every formulation of this library).
+// What the matrix-core forwards redo a result with that came out non-finite: their products carry the weights as
+// hi + lo 16-bit parts (Inf x hi + Inf x lo is NaN when lo is zero or negative) and multiply zero weights with the rows
+// they are handed (0 x Inf), the reference does neither -- recomputed, the result is the reference's element for element.
+// tab: the level table in LDS (kTabInts ints per level: H, W, first pixel, ...).  Not a tuned path.
+template <typename T>
+__device__ __forceinline__ void exact_lane8(const int *tab, __amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes,
+                                            const uint16_t *loc_q, const uint16_t *attn_q, int K, int P, uint32_t piece_off,
+                                            float (&acc)[8])
+{
+    typedef Vec16<T> V;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int l = k / P;
+        const int Hl = tab[kTabInts * l], Wl = tab[kTabInts * l + 1], lstart = tab[kTabInts * l + 2];
+        const float lx = to_f32(__builtin_bit_cast(T, loc_q[2 * k])), ly = to_f32(__builtin_bit_cast(T, loc_q[2 * k + 1]));
+        const float a = to_f32(__builtin_bit_cast(T, attn_q[k]));
+        const Tap<float> t = locate<float>(lx, ly, Hl, Wl, lstart);
+        if (a == 0.f) continue;
+        const float gy = 1.f - t.fy, gx = 1.f - t.fx;
+        const float w[4] = {gy * gx * a, gy * t.fx * a, t.fy * gx * a, t.fy * t.fx * a};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (t.row[c] < 0) continue;
+            const uint4 raw = buffer_load16(rsrc, (uint32_t)t.row[c] * row_bytes + piece_off);
+            float v[8];
+            V::unpack(raw, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(w[c], v[i], acc[i]);
+        }
+    }
+}
+
 // Workgroups of a launch.  Few runs of queries (< 2 per CU): one workgroup per run, dealt by the dispatcher.  Else the
 // kernels are PERSISTENT: one workgroup per CU, runs dealt w, w + n, ... -- n a multiple of H, so that run -> head -> XCD
 // stays what the head's slab in the XCD's L2 expects, and at any moment an XCD's workgroups cover 32 consecutive runs of

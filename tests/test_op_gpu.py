@@ -705,32 +705,52 @@ def test_sliced_forward_is_the_default_where_the_whole_pyramid_is_resident():
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
 
 
-def test_sliced_forward_non_finite_rows_stay_inside_their_tile():
-    """A product of the sliced forward multiplies the rows of EIGHT queries with a block-diagonal weight tile: a
-    non-finite value row turns the zeros of the other queries' weights into NaN, so it reaches the queries of its
-    8-query tile (documented deviation: the reference, and the other two formulations, keep it with the queries that
-    sample it, cuh:58-81) -- and no query of another tile, no other head, and nothing at all through corners outside
-    the map, zero weights or samples that fail the range test."""
-    sh, start = level_tables([(4, 4), (2, 2)])
-    H, Nq, D = 2, 24, 64
-    value = torch.ones(1, 20, H, D, dtype=torch.float64)
-    value[0, 5, 0] = float("inf")                         # pixel (1, 1) of level 0, head 0
-    value[0, 16, 1] = float("nan")                        # pixel (0, 0) of level 1, head 1
-    loc = torch.full((1, Nq, H, 2, 2, 2), 0.875, dtype=torch.float64)
-    attn = torch.full((1, Nq, H, 2, 2), 0.25, dtype=torch.float64)
-    loc[0, 3, 0, 0, 0] = torch.tensor([0.375, 0.375])     # query 3, head 0 touches pixel (1, 1) of level 0
-    loc[0, 15, 1, 1, 1] = torch.tensor([0.25, 0.25])      # query 15, head 1 touches pixel (0, 0) of level 1
-    loc[0, 17, 0, 0, 1] = torch.tensor([0.375, 0.375]); attn[0, 17, 0, 0, 1] = 0.0    # zero weight: reads nothing
-    loc[0, 18, 0, 0, 1] = torch.tensor([0.375, 1.5])      # fails the range test: reads nothing
-    x = dict(value=value, shapes=sh, start=start, loc=loc, attn=attn)
-    got = run_fwd(x, torch.bfloat16, "slices").reshape(Nq, H, D)
-    bad = ~np.isfinite(got).all(-1)
-    assert bad[3, 0] and bad[15, 1]
-    allowed = np.zeros((Nq, H), dtype=bool)
-    allowed[0:8, 0] = True; allowed[8:16, 1] = True       # the tiles of queries 3 (head 0) and 15 (head 1)
-    assert not (bad & ~allowed).any(), np.argwhere(bad & ~allowed)
-    fine = got[~bad]
-    assert np.isfinite(fine).all()
+def _non_finite_element_case(dtype, D, algo, H=2):
+    """Single non-finite ELEMENTS (and one whole row) of `value` in a level that is read from memory and in two that are
+    LDS-resident; the forced formulation's output against the oracle element for element: which outputs are finite, NaN
+    vs +-Inf, and the finite values (cuh:58-81, :275-299: a non-finite element reaches its own channel of the queries that
+    sample its row with a valid corner, nothing else)."""
+    shapes = [(64, 64), (4, 4), (2, 2)]                   # level 0 does not fit in LDS (rows from memory), the others do
+    B, Nq, P = 1, 600, 2
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=5, loc_range=(0.05, 0.95), dtype=dtype)
+    value = x["value"]
+    value[0, 65 * 20, 0, 3] = float("inf")                # level 0, single channels: pixel (20, 20)
+    value[0, 65 * 20 + 1, 0, D - 28] = float("-inf")      # ... (20, 21)
+    value[0, 65 * 10, 1, D // 2 + 13] = float("nan")
+    value[0, 4096 + 5, 1, D // 2] = float("nan")          # level 1
+    value[0, 4096 + 16 + 1, 0, D - 1] = float("inf")      # level 2
+    value[0, 65 * 30, 1, :] = float("nan")                # a whole row of level 0
+    x["attn"][0, 3, 0] = 0.0                              # a query that reads nothing at all in head 0
+    x["loc"][0, 5, 0] = 2.0                               # ... and one whose samples all fail the range test
+    x["loc"][0, 7, 0, 0, 0] = torch.tensor([20.5 / 64, 20.5 / 64])      # exactly on pixel (20, 20) in every arithmetic: its right
+                                                                        # neighbour weighs 0 x -Inf = NaN, as in the reference
+    want = msda_oracle.forward(value, x["shapes"], x["start"], x["loc"], x["attn"])
+    got = run_fwd(x, dtype, algo)
+    fin_w, fin_g = np.isfinite(want), np.isfinite(got)
+    # (the library reads nothing where the attention weight is exactly 0, DESIGN 4.1: query 3 of head 0 is finite here)
+    want3 = want.reshape(Nq, H, D)[3, 0]
+    if not np.isfinite(want3).all():
+        fin_w.reshape(Nq, H, D)[3, 0] = True; want.reshape(Nq, H, D)[3, 0] = 0.0
+    assert (fin_w == fin_g).all(), np.argwhere(fin_w != fin_g)[:10]
+    assert (~fin_w).any() and fin_w.any()
+    n_bad_queries = int((~fin_w.reshape(Nq, H, D)).any(-1).sum())
+    assert 0 < n_bad_queries < Nq * H                      # (the 2 x 2 level's non-finite pixel is seen by most queries)
+    scale = max(1.0, float(np.abs(want[fin_w]).max()))
+    assert np.abs(got[fin_w] - want[fin_w]).max() <= TOL[dtype] * scale
+    assert (np.isnan(want) == np.isnan(got)).all()         # NaN vs +-Inf as the reference has them
+    assert (want[np.isinf(want)] == got[np.isinf(want)]).all()
+    ref = run_fwd(x, dtype, "gather")                     # the row gather agrees element for element on what is finite
+    assert (np.isfinite(ref) == fin_g).all()
+
+
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sliced_forward_non_finite_values_stay_with_their_queries(D, dtype):
+    """A product of the sliced forward multiplies the rows of EIGHT queries with a block-diagonal weight tile: a non-finite
+    value row turns the zeros of the other queries' weights into NaN.  Round 4 documented that as a deviation (a non-finite
+    row reached the up to 8 queries of its tile); round 5: a tile with a non-finite sum is recomputed channel by channel
+    (q8::exact8), and the result is the reference's element for element (cuh:58-81) -- as for the other formulations."""
+    _non_finite_element_case(dtype, D, "slices")
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8192), (1, 16, 4096 * 3 + 77), (3, 4, 300)])
@@ -1130,37 +1150,13 @@ def test_query_wave_forward_non_finite_values_stay_in_their_channel(dtype):
     a lane).  The kernel tests every query's sums and recomputes a query with a non-finite one channel by channel
     (wq::exact_query): element for element the reference's result (cuh:58-81, :275-299) -- an Inf / NaN in ONE channel
     of a row reaches that channel of the queries that sample the row with a valid corner, nothing else."""
-    shapes = [(64, 64), (4, 4), (2, 2)]                   # level 0 does not fit in LDS (rows from memory), the others do
-    B, H, D, Nq, P = 1, 2, 128, 600, 2
-    x = make_inputs(B, H, D, Nq, P, shapes, seed=5, loc_range=(0.05, 0.95), dtype=dtype)
-    value = x["value"]
-    value[0, 65 * 20, 0, 3] = float("inf")                # level 0, single channels: pixel (20, 20)
-    value[0, 65 * 20 + 1, 0, 100] = float("-inf")         # ... (20, 21)
-    value[0, 65 * 10, 1, 77] = float("nan")
-    value[0, 4096 + 5, 1, 64] = float("nan")              # level 1
-    value[0, 4096 + 16 + 1, 0, 127] = float("inf")        # level 2
-    value[0, 65 * 30, 1, :] = float("nan")                # a whole row of level 0
-    x["attn"][0, 3, 0] = 0.0                              # a query that reads nothing at all in head 0
-    x["loc"][0, 5, 0] = 2.0                               # ... and one whose samples all fail the range test
-    x["loc"][0, 7, 0, 0, 0] = torch.tensor([20.5 / 64, 20.5 / 64])      # exactly on pixel (20, 20) in every arithmetic: its right
-                                                                        # neighbour weighs 0 x -Inf = NaN, as in the reference
-    want = msda_oracle.forward(value, x["shapes"], x["start"], x["loc"], x["attn"])
-    got = run_fwd(x, dtype, "waves")
-    fin_w, fin_g = np.isfinite(want), np.isfinite(got)
-    # (the library reads nothing where the attention weight is exactly 0, DESIGN 4.1: query 3 of head 0 is finite here)
-    want3 = want.reshape(Nq, H, D)[3, 0]
-    if not np.isfinite(want3).all():
-        fin_w.reshape(Nq, H, D)[3, 0] = True; want.reshape(Nq, H, D)[3, 0] = 0.0
-    assert (fin_w == fin_g).all(), np.argwhere(fin_w != fin_g)[:10]
-    assert (~fin_w).any() and fin_w.any()
-    n_bad_queries = int((~fin_w.reshape(Nq, H, D)).any(-1).sum())
-    assert 0 < n_bad_queries < Nq * H                      # (the 2 x 2 level's non-finite pixel is seen by most queries)
-    scale = max(1.0, float(np.abs(want[fin_w]).max()))
-    assert np.abs(got[fin_w] - want[fin_w]).max() <= TOL[dtype] * scale
-    assert (np.isnan(want) == np.isnan(got)).all()         # NaN vs +-Inf as the reference has them
-    assert (want[np.isinf(want)] == got[np.isinf(want)]).all()
-    ref = run_fwd(x, dtype, "gather")                     # the row gather agrees element for element on what is finite
-    assert (np.isfinite(ref) == fin_g).all()
+    _non_finite_element_case(dtype, 128, "waves")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_lds_levels_forward_non_finite_elements_match_the_reference(D):
+    """The same element-level case through the LDS-resident formulation (one product per query: msda_fwd_mma.hip)."""
+    _non_finite_element_case(torch.bfloat16, D, "lds")
 
 
 def test_query_wave_forward_is_the_default_at_the_north_star_shape():
