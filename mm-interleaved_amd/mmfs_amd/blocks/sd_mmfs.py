@@ -294,8 +294,31 @@ class MMFSNet(CacheInvalidation, nn.Module):
     # the checkpoints, and hand every block its projection as a checkpoint input (kept through the step, not recomputed).
     # The reference recomputes LayerNorm + projection inside every checkpoint to save memory -- 13 bank-sized tensors,
     # 1.16 GB at B = 8 in bf16: a quarter of a percent of this GPU's 288 GB -- and pays 26 forward projections and 13
-    # weight-gradient GEMMs of the worst shape for it.  False: the round-3 schedule.
-    project_once_in_training = True
+    # weight-gradient GEMMs of the worst shape for it.  False: the round-3 schedule (the reference's
+    # memory behaviour); True: always; "auto" (default, round 5 / ADVICE r4): only while the kept projections are a small part
+    # of the device memory that is free when the step starts (``project_once_budget`` of it) -- on a smaller part, or with
+    # a bank of many images, the step falls back to recomputing inside the checkpoints instead of running out of memory.
+    project_once_in_training = "auto"
+    project_once_budget = 0.125
+
+    def _project_once(self, mmfs_features):
+        """Whether this training step keeps all blocks' projections of the bank (see ``project_once_in_training``)."""
+        mode = self.project_once_in_training
+        if mode is True or mode is False:
+            return mode
+        if isinstance(mmfs_features, ProjectedFeatures):
+            return True                                    # (the caller made them: they exist already)
+        feats = mmfs_features
+        try:
+            ref = feats[0]
+            pixels = sum(int(f.shape[-1]) * int(f.shape[-2]) for f in feats)
+            n_tok = int(ref.shape[0]) * int(ref.shape[1]) * pixels
+            width = max(int(b.mmfs.value_proj.out_features) for b in self._blocks())
+            need = len(list(self._blocks())) * n_tok * width * ref.element_size()
+            free = torch.cuda.mem_get_info(ref.device)[0] if ref.is_cuda else 0
+        except Exception:
+            return False
+        return need <= self.project_once_budget * free
 
     def __init__(self, input_channel, block_out_channels, layers_per_block, downsample_factor=1,
                  n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]):
@@ -394,12 +417,13 @@ class MMFSNet(CacheInvalidation, nn.Module):
         assert len(down_block_res_samples) == len(self.mmfs_down_blocks)
         proj = mmfs_features if isinstance(mmfs_features, ProjectedFeatures) else None
         # Under gradient checkpointing the reference recomputes feat_norm + value_proj inside every block's
-        # checkpoint and keeps none of them; handing each block a projected bank as a checkpoint INPUT would
-        # keep all 13 bank-sized tensors alive through the whole step -- on exactly the path where
-        # checkpointing was meant to save memory.  Training with checkpointing recomputes every block's projection as
-        # the reference does (the un-affined normalisation alone is shared: below).
+        # checkpoint and keeps none of them; handing each block a projected bank as a checkpoint INPUT keeps all 13
+        # bank-sized tensors alive through the whole step.  That is what ``project_once_in_training`` does when they are a
+        # small part of the free memory (1.16 GB at B = 8: 26 projections and 13 weight-gradient GEMMs saved); else training
+        # with checkpointing recomputes every block's projection as the reference does (the un-affined normalisation
+        # alone is shared: below).
         ckpt = self.training and torch.is_grad_enabled() and any(b.gradient_checkpointing for b in self._blocks())
-        if ckpt and self.project_once_in_training:
+        if ckpt and proj is None and self._project_once(mmfs_features):
             ckpt = False                                   # (the projections become checkpoint inputs: below)
         if proj is None and self.fused_schedule and self._can_fuse() and not ckpt:
             keep = self.cache_projected_features and not torch.is_grad_enabled() and not self.training

@@ -214,6 +214,10 @@ class MMFS(CacheInvalidation, nn.Module):
                 # both tables as one GEMM on the stacked weights; the plan's Function reads the two column ranges
                 res = (F.linear(table, cat_w), None, aw_w, aw_b, cat_w, cat_b, None, None)
             else:
+                # (the offsets' table was left out above on the assumption that the heads stack; they do not when the two
+                # Linear layers differ in dtype or the offsets have no bias: ADVICE r4)
+                if off_tab is None:
+                    off_tab = F.linear(table, self.sampling_offsets.weight)
                 res = (off_tab, F.linear(table, aw_w), aw_w, aw_b, cat_w, cat_b, fold_w, fold_b)
         else:
             res = (off_tab, F.linear(table, self.attention_weights.weight), None, None, None, None, None, None)   # [max_img, H*L*(P+1)]
@@ -254,7 +258,12 @@ class MMFS(CacheInvalidation, nn.Module):
                     off_q, att_q = self.sampling_offsets(q), F.linear(q, aw_w, aw_b)
             if att_tab is None:               # (with gradients: both tables as the column ranges of one GEMM's result)
                 tabs = off_tab
-                if both is not None and sampler is None and tabs.dtype == both.dtype:
+                # (the kernels read the stacked rows in 16-byte vectors: both column ranges have to start and stride on
+                # 16 bytes -- P = 4 in 16-bit storage with H * (2 + L) odd does not; then the sliced, packed path: ADVICE r4)
+                es = both.element_size() if both is not None else 1
+                vec_ok = (both is not None and (both.shape[-1] * es) % 16 == 0 and (H * P * 2 * es) % 16 == 0
+                          and both.data_ptr() % 16 == 0 and tabs.data_ptr() % 16 == 0)
+                if vec_ok and sampler is None and tabs.dtype == both.dtype:
                     return MMFSHeadsPlanFunction.apply(both, tabs, relpos, reference_points[:, :, 0, :],
                                                        input_spatial_shapes, self.scale_ratios, H, L, P)
                 off_tab, att_tab = tabs[:, :H * P * 2], tabs[:, H * P * 2:]
