@@ -364,6 +364,28 @@ def make_block_goldens():
     arrays.update({f"new_res.{i}": r for i, r in enumerate(new_res)})
     arrays.update({f"feat.{i}": r for i, r in enumerate(feats)})
     arrays.update({"param." + k: v for k, v in net.state_dict().items()})
+    # ... and a TRAINING step of the reference (round 5): gradient checkpointing on in every block
+    # (sd_mmfs.py:138-141), cotangents for all seven outputs -> the gradient of every input and of EVERY parameter.  (Drawn
+    # after everything above: the arrays of the forward fixture keep their values.)
+    for blk in list(net.mmfs_down_blocks) + [net.mmfs_mid_block]:
+        blk.gradient_checkpointing = True
+    net.train()
+    res_t = [r.clone().requires_grad_(True) for r in res]
+    mid_t = mid.clone().requires_grad_(True)
+    feats_t = [f.clone().requires_grad_(True) for f in feats]
+    out_mid, out_res = net(mid_t, res_t, feats_t, ms_mask)
+    cot_mid = torch.randn(out_mid.shape, generator=gen).to(dt)
+    cot_res = [torch.randn(r.shape, generator=gen).to(dt) for r in out_res]
+    loss = (out_mid * cot_mid).sum()
+    for r, c in zip(out_res, cot_res):
+        loss = loss + (r * c).sum()
+    loss.backward()
+    assert float((out_mid - new_mid).abs().max()) == 0.0
+    arrays.update({"train.cot_mid": cot_mid, "train.grad_mid": mid_t.grad})
+    arrays.update({f"train.cot_res.{i}": c for i, c in enumerate(cot_res)})
+    arrays.update({f"train.grad_res.{i}": r.grad for i, r in enumerate(res_t)})
+    arrays.update({f"train.grad_feat.{i}": f.grad for i, f in enumerate(feats_t)})
+    arrays.update({"train.grad." + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
     save("block_sd_mmfs_net", **arrays)
 
 

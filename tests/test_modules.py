@@ -228,6 +228,53 @@ def test_sd_mmfs_net_fused_schedule_equals_the_references(oracle_op):
         close(b["gparam"][k], a["gparam"][k], 1e-9)
 
 
+def _net_training_step(net, z, dtype=torch.float64, dev="cpu"):
+    """One training step of the tiny net on the fixture's inputs and cotangents -> outputs, input grads, parameter grads."""
+    conv = lambda a: T(a, dtype).to(dev) if np.asarray(a).dtype.kind == "f" else T(a).to(dev)
+    res = [conv(z[f"res.{i}"]).requires_grad_(True) for i in range(6)]
+    feats = [conv(z[f"feat.{i}"]).requires_grad_(True) for i in range(3)]
+    mid = conv(z["mid"]).requires_grad_(True)
+    new_mid, new_res = net(mid, res, feats, conv(z["ms_mask"]))
+    loss = (new_mid * conv(z["train.cot_mid"])).sum()
+    for i, r in enumerate(new_res):
+        loss = loss + (r * conv(z[f"train.cot_res.{i}"])).sum()
+    loss.backward()
+    return dict(mid=new_mid.detach(), res=[r.detach() for r in new_res], gmid=mid.grad, gres=[r.grad for r in res],
+                gfeat=[f.grad for f in feats], gparam={k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+
+
+@pytest.mark.parametrize("schedule", ["reference", "shared_bank", "project_once"])
+def test_sd_mmfs_net_training_step_matches_the_reference_gradients(oracle_op, schedule):
+    """the training ASSEMBLY against the reference itself, not against last round's schedule.  The
+    fixture carries a training step of the reference's MMFSNet (gradient checkpointing on in every block,
+    sd_mmfs.py:138-141): cotangents for the seven outputs, the gradient of every input and of all 119 parameters.  Each of
+    the build's training schedules -- the reference's own (LayerNorm + projection inside every checkpoint), the shared
+    un-affined normalisation, the bank projected once for all blocks outside the checkpoints (the default where memory
+    allows) -- reproduces them in fp64."""
+    from mmfs_amd.blocks import MMFSNet
+    z = load_golden("block_sd_mmfs_net")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2, downsample_factor=8, n_levels=3,
+                      n_points=2, gradient_checkpointing=True, spatial_shapes=[64, 32, 16]).double()
+    load_params(net, z)
+    net.train()
+    net.share_normalised_bank = schedule != "reference"
+    net.fused_schedule = schedule != "reference"
+    net.project_once_in_training = schedule == "project_once"
+    got = _net_training_step(net, z)
+    close(got["mid"], z["new_mid"], 1e-11)
+    for i in range(6):
+        close(got["res"][i], z[f"new_res.{i}"], 1e-11)
+        close(got["gres"][i], z[f"train.grad_res.{i}"], 1e-10)
+    close(got["gmid"], z["train.grad_mid"], 1e-10)
+    for i in range(3):
+        close(got["gfeat"][i], z[f"train.grad_feat.{i}"], 1e-9)
+    want = {k[len("train.grad."):]: v for k, v in z.items() if k.startswith("train.grad.")}
+    assert sorted(got["gparam"]) == sorted(want) and len(want) == 119
+    for k, v in want.items():
+        close(got["gparam"][k], v, 1e-9)
+
+
 def test_sd_mmfs_net_shares_the_normalised_bank_under_checkpointing(oracle_op):
     """Training with gradient checkpointing: the bank is normalised once without the affine and every block folds
     its own affine into the projection it recomputes inside its checkpoint (MMFSNet.share_normalised_bank) --

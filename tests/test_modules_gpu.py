@@ -276,6 +276,36 @@ def test_blocks_on_gpu_match_reference():
     for i, r in enumerate(res):
         assert rel_err(r, z[f"new_res.{i}"]) <= 2e-5
 
+    # ... and a TRAINING step of it -- checkpointing on, the default schedule (bank projected once: _ProjectAll, stacked heads,
+    # fused plan kernels, HIP op forward + recompute + backward) -- against the reference's gradients of every input and every
+    # parameter (round 5: VERDICT r4 next 6; the fixture's training arrays come from the imported reference, make_golden.py)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = load_params(MMFSNet(input_channel=32, block_out_channels=[16, 24], layers_per_block=2,
+                                  downsample_factor=8, n_levels=3, n_points=2, gradient_checkpointing=True,
+                                  spatial_shapes=[64, 32, 16]), z).to(DEV)
+    net.train()
+    for once in (True, False):
+        net.project_once_in_training = once
+        net.zero_grad(set_to_none=True)
+        res_t = [T(z[f"res.{i}"], torch.float32).requires_grad_(True) for i in range(6)]
+        feats_t = [T(z[f"feat.{i}"], torch.float32).requires_grad_(True) for i in range(3)]
+        mid_t = T(z["mid"], torch.float32).requires_grad_(True)
+        new_mid, new_res = net(mid_t, res_t, feats_t, T(z["ms_mask"], None))
+        loss = (new_mid * T(z["train.cot_mid"], torch.float32)).sum()
+        for i, r in enumerate(new_res):
+            loss = loss + (r * T(z[f"train.cot_res.{i}"], torch.float32)).sum()
+        loss.backward()
+        assert rel_err(new_mid, z["new_mid"]) <= 2e-5 and rel_err(mid_t.grad, z["train.grad_mid"]) <= 1e-4
+        for i in range(6):
+            assert rel_err(res_t[i].grad, z[f"train.grad_res.{i}"]) <= 1e-4, i
+        for i in range(3):
+            assert rel_err(feats_t[i].grad, z[f"train.grad_feat.{i}"]) <= 1e-4, i
+        want = {k[len("train.grad."):]: v for k, v in z.items() if k.startswith("train.grad.")}
+        got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        assert sorted(got) == sorted(want) and len(want) == 119
+        for k, v in want.items():
+            assert rel_err(got[k], v) <= 2e-4, f"{k} (project_once={once}): {rel_err(got[k], v):.3e}"
+
 
 def test_mmfs_forward_issues_no_host_sync():
     """The reference stalls the stream >= 4 times per MMFS call; this one must not."""
@@ -696,37 +726,122 @@ def test_ignore_token_term_as_one_product(dtype, tol):
 
 
 @pytest.mark.gpu
-def test_llama_layer_training_step_with_the_residual_handed_over():
+def test_llama_layer_training_step_with_the_residual_handed_over(oracle_op_cpu):
     """``layer(x, ..., residual=x)`` with gradients (norm + residual and gate + residual as one Function each, the heads
-    stacked) against ``x + layer(x, ...)`` with ``stack_heads_in_training = False`` -- the round-3 statement -- in bf16:
-    output and every gradient within 16-bit rounding of each other."""
-    import types
+    stacked: round 4's training path) in fp32 on the GPU against ``x + layer(x, ...)`` of the same module in fp64 on the CPU
+    with the C oracle as its op -- output, input gradients and EVERY parameter gradient (round 5, VERDICT r4 next 6: the
+    round-4 test compared the path with round 3's in bf16)."""
+    import copy, types
     from mmfs_amd.blocks import LlamaMMFSAttention
     cfg = types.SimpleNamespace(hidden_size=512, num_attention_heads=8, rms_norm_eps=1e-6, max_position_embeddings=64,
                                 image_embed_dim=128, spatial_shapes=[8, 4, 2])
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        l = LlamaMMFSAttention(cfg, 0).to(DEV, torch.bfloat16).train()
+        ref = LlamaMMFSAttention(cfg, 0).double().train()
     with torch.no_grad():
-        l.gate.fill_(0.7)
-        l.attn.sampling_offsets.weight.normal_(0, 0.02)
+        ref.gate.fill_(0.7)
+        ref.attn.sampling_offsets.weight.normal_(0, 0.02)
+        ref.attn.attention_weights.weight.normal_(0, 0.02)
+    ref.attn.stack_heads_in_training = False                # (the plain statement on the reference side)
+    gpu = copy.deepcopy(ref).float().to(DEV).train()
+    gpu.attn.stack_heads_in_training = True
     B, Lq, n, hw = 2, 33, 2, 64 + 16 + 4
-    hidden = torch.randn(B, Lq, 512, device=DEV, dtype=torch.bfloat16)
-    feats = torch.randn(B, n, hw, 128, device=DEV, dtype=torch.bfloat16)
-    mask = torch.ones(B, Lq, n, device=DEV)
-    go = torch.randn(B, Lq, 512, device=DEV, dtype=torch.bfloat16)
-    res = {}
-    for new in (True, False):
-        l.attn.stack_heads_in_training = new
-        l.zero_grad(set_to_none=True)
-        x = hidden.clone().requires_grad_(True)
-        y = l(x, feats, mask, residual=x) if new else x + l(x, feats, mask)
-        y.backward(go)
-        res[new] = [y.detach().float(), x.grad.float()] + [p.grad.float() for p in l.parameters() if p.grad is not None]
-    assert len(res[True]) == len(res[False]) >= 10
-    for i, (a, b) in enumerate(zip(res[True], res[False])):
-        assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b).clamp_min(1e-12)) <= 2e-2, i
-        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) <= 8e-2, i
+    g = torch.Generator().manual_seed(1)
+    hidden = torch.randn(B, Lq, 512, generator=g, dtype=torch.float64)
+    feats = torch.randn(B, n, hw, 128, generator=g, dtype=torch.float64)
+    mask = torch.ones(B, Lq, n, dtype=torch.float64)
+    mask[0, :10, 1] = 0.0                                  # (an image the first tokens cannot see)
+    go = torch.randn(B, Lq, 512, generator=g, dtype=torch.float64)
+    res = []
+    for mod, dev, dt, new in ((ref, "cpu", torch.float64, False), (gpu, DEV, torch.float32, True)):
+        x = hidden.clone().to(dev, dt).requires_grad_(True)
+        f = feats.clone().to(dev, dt).requires_grad_(True)
+        y = mod(x, f, mask.to(dev, dt), residual=x) if new else x + mod(x, f, mask.to(dev, dt))
+        y.backward(go.to(dev, dt))
+        res.append(dict(out=y.detach().double().cpu(), gx=x.grad.double().cpu(), gf=f.grad.double().cpu(),
+                        **{"p." + k: p.grad.double().cpu() for k, p in mod.named_parameters() if p.grad is not None}))
+    want, got = res
+    assert sorted(want) == sorted(got) and len(want) >= 13
+    for k in want:
+        err = float((got[k] - want[k]).abs().max() / max(1.0, float(want[k].abs().max())))
+        assert err <= 1e-4, f"{k}: {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_mmfs_net_training_step_at_512px_geometry(oracle_op_cpu):
+    """BASELINE config 4 as a TRAINING step (round 5): the 13-block MMFSNet at the 512-px geometry, gradient
+    checkpointing on, the default schedule (bank projected once for all blocks, stacked heads, fused plan kernels, the HIP
+    op forward + recompute + backward), fp32 on the GPU -- against the same net in fp64 on the CPU with the C oracle as its
+    op and the reference's schedule: all 13 outputs, the gradients of every input and of every parameter."""
+    import copy
+    from mmfs_amd.blocks import MMFSNet
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = MMFSNet(input_channel=1024, block_out_channels=[320, 640, 1280, 1280], layers_per_block=2,
+                      n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]).double()
+    with torch.no_grad():
+        for blk in ref._blocks():
+            blk.conv.weight.normal_(0, 0.02)
+            blk.mmfs.sampling_offsets.weight.normal_(0, 0.01)
+            blk.mmfs.attention_weights.weight.normal_(0, 0.02)
+    ref.train()
+    gpu = copy.deepcopy(ref).float().to(DEV).train()
+    ref.fused_schedule = ref.share_normalised_bank = False; ref.project_once_in_training = False      # (the reference's schedule)
+    for blk in ref._blocks():
+        blk.gradient_checkpointing = False                 # (fp64 on the CPU: no need to recompute)
+    g = torch.Generator().manual_seed(6)
+    geom = list(zip([320] * 4 + [640] * 3 + [1280] * 5, [64] * 3 + [32] * 3 + [16] * 3 + [8] * 3))
+    res_in = [torch.randn(1, c, s, s, generator=g, dtype=torch.float64) for c, s in geom]
+    mid = torch.randn(1, 1280, 8, 8, generator=g, dtype=torch.float64)
+    feats = [torch.randn(1, 1, 1024, s, s, generator=g, dtype=torch.float64) for s in (64, 32, 16, 8)]
+    cots = [torch.randn(1, 1280, 8, 8, generator=g, dtype=torch.float64)] + [torch.randn(1, c, s, s, generator=g, dtype=torch.float64) for c, s in geom]
+    mask = torch.ones(1, 1, dtype=torch.long)
+    outs = []
+    for mod, dev, dt in ((ref, "cpu", torch.float64), (gpu, DEV, torch.float32)):
+        m_in = mid.detach().clone().to(dev, dt).requires_grad_(True)
+        r_in = [r.detach().clone().to(dev, dt).requires_grad_(True) for r in res_in]
+        f_in = [f.detach().clone().to(dev, dt).requires_grad_(True) for f in feats]
+        m, rr = mod(m_in, r_in, f_in, mask.to(dev))
+        loss = (m * cots[0].to(dev, dt)).sum()
+        for r, c in zip(rr, cots[1:]):
+            loss = loss + (r * c.to(dev, dt)).sum()
+        loss.backward()
+        d = {"out.mid": m.detach(), "g.mid": m_in.grad}
+        d.update({f"out.res{i}": r.detach() for i, r in enumerate(rr)})
+        d.update({f"g.res{i}": r.grad for i, r in enumerate(r_in)})
+        d.update({f"g.feat{i}": f.grad for i, f in enumerate(f_in)})
+        d.update({"p." + k: p.grad for k, p in mod.named_parameters() if p.grad is not None})
+        outs.append({k: v.double().cpu() for k, v in d.items()})
+    want, got = outs
+    assert sorted(want) == sorted(got) and sum(k.startswith("p.") for k in want) >= 13 * 15
+    # Bars.  Outputs are continuous in everything: max-abs.  Gradients go through grad_loc, which is DISCONTINUOUS where a
+    # sample's pixel coordinate crosses an integer (DESIGN 2: fp32 lands on the other side of a crossing about once per 1e5
+    # samples -- this step has 2 M samples per block at the first stage); a flipped sample changes the gradient of ITS query
+    # row by O(1) of that row and nothing else.  So: the relative L2 error of every gradient tensor, and max-abs over all but
+    # the few rows a flip can reach (0.1 % of the elements).
+    worst = {}
+    for k in want:
+        a, b = got[k], want[k]
+        scale = max(1.0, float(b.abs().max()))
+        if k.startswith("out."):
+            worst[k] = float((a - b).abs().max()) / scale
+            assert worst[k] <= 1e-4, f"{k}: {worst[k]:.3e}"
+            continue
+        l2 = float(torch.linalg.norm(a - b) / torch.linalg.norm(b).clamp_min(1e-30))
+        diff = (a - b).abs().flatten()
+        kth = max(1, int(diff.numel() * 0.999))
+        q999 = float(diff.kthvalue(kth).values) / scale
+        worst[k] = max(l2, q999)
+        if k.startswith("p."):
+            # (a parameter's gradient sums over every query, the flipped ones included, and the sum of a norm weight or of an
+            # offsets' Linear layer cancels to a fraction of its terms: a handful of flips shows as 1e-3 of such a tensor.
+            # Every tensor within 1e-2 -- a missing or doubled term is O(1) --, and the bulk of them far below: after the loop)
+            assert l2 <= 1e-2, f"{k}: relative L2 {l2:.3e}"
+            worst[k] = l2
+        else:
+            assert l2 <= 2e-4 and q999 <= 1e-4, f"{k}: relative L2 {l2:.3e}, 99.9th percentile {q999:.3e}"
+    pe = sorted(v for k, v in worst.items() if k.startswith("p."))
+    assert pe[len(pe) // 2] <= 1e-4 and pe[int(len(pe) * 0.9)] <= 1e-3, (pe[len(pe) // 2], pe[int(len(pe) * 0.9)], pe[-1])
 
 
 # ---------------------------------------------------------------- layout kernels around the image decoder's block
