@@ -325,15 +325,29 @@ msda_fwd_wq(const T *__restrict__ value, const int64_t *__restrict__ shapes,
                 // (a valid corner of weight 0 still multiplies its row, as in the reference: 0 x Inf is NaN there too)
                 weighs = ok[0] || ok[1] || ok[2] || ok[3];
             }
-            const unsigned long long bl_g = __builtin_amdgcn_ballot_w64(weighs && !in_lds);
-            const unsigned long long bl_l = __builtin_amdgcn_ballot_w64(weighs && in_lds);
+            // Which samples get a record.  Samples that contribute nothing (outside the map, a zero attention weight) are
+            // left out and a query's records COMPACTED -- but only when that leaves the group regular: the same samples live
+            // in all four queries (an image no token of the group can see: whole levels drop out, half the work).  A ragged
+            // pattern (samples over the border here and there) would send the group down the generic, unpipelined path for a
+            // handful of skipped samples (clustered locations: 180 us against 122, r05v): then every sample keeps its place,
+            // the dead ones as records of zero weight that point at the row of zeros / past the slab's end.
+            const unsigned long long st_g = __builtin_amdgcn_ballot_w64(k_ok && !in_lds), st_l = __builtin_amdgcn_ballot_w64(k_ok && in_lds);
+            unsigned long long bl_g = __builtin_amdgcn_ballot_w64(weighs && !in_lds);
+            unsigned long long bl_l = __builtin_amdgcn_ballot_w64(weighs && in_lds);
+            const bool same4 = bl_g == (bl_g & 0xffffull) * 0x0001000100010001ull && bl_l == (bl_l & 0xffffull) * 0x0001000100010001ull;
+            const bool compact = same4 || (bl_g == st_g && bl_l == st_l);
+            if (!compact) { bl_g = st_g; bl_l = st_l; }
+            const bool writes = compact ? weighs : k_ok;
             live_g = bl_g; live_l = bl_l;
             // records of a query: the live row-gather samples from the bottom, the live LDS samples from the top
             const uint32_t mine_g = (uint32_t)(bl_g >> (16 * sq)) & 0xffffu, mine_l = (uint32_t)(bl_l >> (16 * sq)) & 0xffffu;
             const uint32_t below = (1u << kk) - 1u;
             const int ridx = in_lds ? kChunk - 1 - __builtin_popcount(mine_l & below) : __builtin_popcount(mine_g & below);
             wave_sync();                                                  // the previous step's records are consumed
-            if (weighs) {
+            if (writes) {
+                // [corner][sample]: load u of a batch carries the four corners of its sample u.  (The other way round -- lane
+                // group j = corner u of sample j, four rows of four different samples per load, three 16-byte stores here --
+                // measured the same on uniform locations, r05w, and costs the generic path a select per lane.)
                 uint32_t *dst = reinterpret_cast<uint32_t *>(wrec + sq * QS + (ridx >> 2) * BS + (ridx & 3) * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -560,7 +574,10 @@ bool fwd_wq_applies(int dtype, const Dims &d)
     if (algo && algo[0] != 'w') return false;
     if (!fwd_wq_supported(dtype, d)) return false;
     if (algo && algo[0] == 'w') return true;
-    return d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;                      // (an image fill per run of queries: as fwd_mma_applies)
+    // one chunk of samples per query (K <= 16: the north-star shape): the straight-line pipeline.  Longer sample lists run
+    // chunk by chunk through the generic path and measured slower than msda_fwd_mma (the reference's speed-test shape,
+    // K = 128: 156 vs 101 us, r05v): they keep the LDS-resident formulation
+    return d.K <= kChunk && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;       // (an image fill per run of queries: as fwd_mma_applies)
 }
 
 hipError_t forward_wq(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
