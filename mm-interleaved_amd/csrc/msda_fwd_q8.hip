@@ -325,6 +325,11 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
     QPROF(0);                                                             // table / barrier + image fill (incl. waiting for the slowest wave)
 
     for (int tile = 0; tile < n_tiles; ++tile) {
+#ifndef Q8_NO_SETPRIO
+        // (as msda_fwd_wq.hip, r05f: the wave that is behind the others of its SIMD -- more tiles left -- issues first, so that
+        // the workgroup's waves reach the barrier in front of the next image fill together)
+        { const int left = n_tiles - 1 - tile; if (left >= 3) __builtin_amdgcn_s_setprio(3); else if (left == 2) __builtin_amdgcn_s_setprio(2); else if (left == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
         const int q0 = q_first + tile * (kMmaWaves * kQT);
         f32x4 acc[2];
         float accv[8];
