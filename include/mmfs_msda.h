@@ -36,7 +36,11 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 10  /* 10: + mmfs_sample_forward_groups, mmfs_linear_small_add, mmfs_plan_forward_heads / mmfs_plan_backward_heads; mmfs_sample_forward* serve at most 8 queries per (sample,
+#define MMFS_MSDA_ABI_VERSION 11  /* 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
+                                   *     heads of 128 channels with one chunk of samples per query -- the north-star shape); every
+                                   *     matrix-core forward returns the reference's Inf / NaN element for element (a non-finite sum
+                                   *     is recomputed channel by channel)
+                                   * 10: + mmfs_sample_forward_groups, mmfs_linear_small_add, mmfs_plan_forward_heads / mmfs_plan_backward_heads; mmfs_sample_forward* serve at most 8 queries per (sample,
                                    *     head) -- a decode step -- with a workgroup per query (same products, another order of
                                    *     the fp32 sums: see there)
                                    * 9: + MMFS_FWD_SLICES (the forward's third formulation, csrc/msda_fwd_q8.hip);
@@ -110,8 +114,9 @@ int mmfs_msda_forward(int dtype,
  *   LDS levels   (csrc/msda_fwd_mma.hip)  16-bit storage, D in {64, 128}, L <= 64: the levels of the pyramid
  *                that fit in the CU's LDS (smallest first, decided on the device from the table) are copied
  *                there once per workgroup and sampled by the matrix cores, the others by row gather.
- * flags = 0 picks LDS levels for heads of 128 channels when a (b, h) slab has at least 64 queries and 4096 samples (heads of
- * 64 channels measured no faster that way and stay on the row gather unless MMFS_FWD_LDS_LEVELS asks).
+ * flags = 0 (rounds 3-4) picked LDS levels for heads of 128 channels when a (b, h) slab has at least 64 queries and 4096 samples;
+ * round 5: such shapes with at most 16 samples per query take "query waves" (below), longer sample lists keep LDS levels (heads of
+ * 64 channels measured no faster that way and stay on the row gather / the slices unless MMFS_FWD_LDS_LEVELS asks).
  * MMFS_FWD_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED.
  */
 #define MMFS_FWD_ROW_GATHER 1u

@@ -37,7 +37,9 @@ names = {"msda_fwd_vec": "msda_fwd", "msda_bwd_value_reduce": "msda_bwd_value_re
          # round 3: LDS-resident levels on the matrix cores (forward; all-levels taps)
          "msda_fwd_mma": "msda_fwd", "msda_taps_mma": "msda_bwd_taps",
          # round 4: the sliced forward (heads of 32 / 64 channels, whole pyramid resident)
-         "msda_fwd_q8": "msda_fwd"}
+         "msda_fwd_q8": "msda_fwd",
+         # round 5: a wave per query, weights on the diagonal of the A operand (the north star's forward)
+         "msda_fwd_wq": "msda_fwd"}
 traffic = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
     kern, _, rest = line.partition(": ")
