@@ -56,6 +56,29 @@ __device__ __forceinline__ void group_sum4_row(float (&d)[4], int lig)
     d[3] = mv(t, std::integral_constant<int, 0x10C>());   // row_shl:12 -> lane 12
 }
 
+// The same for 8-lane groups (heads of 64 channels: two groups per DPP row): half-row mirror, a quad swap, a lane swap; the
+// totals in the group's lane 0 (lanes 0 and 8 of the row).
+__device__ __forceinline__ void group_sum4_half(float (&d)[4], int lig)
+{
+    const bool hi = (lig & 4) != 0, odd = (lig & 2) != 0;
+    auto mv = [](float v, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    // lanes 0-3 keep (d0, d1), lanes 4-7 keep (d2, d3); partner = 7 - lane within the group
+    const float k0 = hi ? d[2] : d[0], k1 = hi ? d[3] : d[1];
+    const float s0 = hi ? d[0] : d[2], s1 = hi ? d[1] : d[3];
+    const float r0 = k0 + mv(s0, std::integral_constant<int, 0x141>());
+    const float r1 = k1 + mv(s1, std::integral_constant<int, 0x141>());
+    // lanes with bit 1 clear keep the first, the others the second; partner = lane ^ 2
+    const float k = odd ? r1 : r0, s = odd ? r0 : r1;
+    float t = k + mv(s, std::integral_constant<int, 0x4E>());
+    t = dpp_add<0xB1>(t);                            // lane ^ 1: lane pair p of the group now holds the total of d[p]
+    d[0] = t;
+    d[1] = mv(t, std::integral_constant<int, 0x102>());   // row_shl:2 -> lane 0 reads lane 2
+    d[2] = mv(t, std::integral_constant<int, 0x104>());   // row_shl:4 -> lane 4
+    d[3] = mv(t, std::integral_constant<int, 0x106>());   // row_shl:6 -> lane 6
+}
+
 // Dot product of two 16-byte channel vectors, fp32 result.  The taps kernel is VALU-bound (94 % busy
 // at the north-star shape, rocprofv3 SQ_ACTIVE_INST_VALU): unpacking 16-bit channels costs one
 // instruction per element and the multiply-adds another 0.5-1.  For 16-bit storage the packed dot

@@ -51,7 +51,8 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     typedef MmaGeom<D, GSH> G;
     typedef FwdMma<T> M;
     constexpr int NKS = D / 32;                                           // K steps of a product (32 channels each)
-    static_assert(D == 128, "taps on the matrix cores: heads of 128 channels (four queries per wave)");
+    static_assert(D == 128 || D == 64, "taps on the matrix cores: heads of 128 / 64 channels (four / eight queries per wave)");
+    constexpr int PS = QPW / 4;                                           // staging / store passes (64 lanes = 4 queries x 16 samples)
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     int *tab = reinterpret_cast<int *>(smem);
     unsigned char *img = smem + G::IMG0;
@@ -94,17 +95,22 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     T *ga_wg = grad_attn + (((int64_t)b * d.Nq * d.H + h) * d.K);
     const uint32_t q_stride = (uint32_t)d.H * (uint32_t)d.K;
     // (the next step's sample words are requested while this step gathers; kept RAW until they are used)
-    uint32_t pf_w0 = 0u, pf_w1 = 0u, pf_a = 0u;
+    uint32_t pf_w0[PS], pf_w1[PS], pf_a[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) pf_w0[ps] = pf_w1[ps] = pf_a[ps] = 0u;
     auto prefetch = [&](int step) {
-        const int q = q_first + (step / n_chunks) * (kMmaWaves * QPW) + (lane >> 4);
         const int k = (step % n_chunks) * kChunk + kk;
-        pf_w0 = pf_w1 = pf_a = 0u;
-        if (step < n_steps && k < d.K && q < d.Nq) {
-            const uint32_t s = (uint32_t)q * q_stride + (uint32_t)k;
-            const uint16_t *lw = loc_wg + 2 * (size_t)s;
-            if (pair_ok) pf_w0 = *reinterpret_cast<const uint32_t *>(lw);
-            else { pf_w0 = lw[0]; pf_w1 = lw[1]; }
-            pf_a = attn_wg[s];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const int q = q_first + (step / n_chunks) * (kMmaWaves * QPW) + ps * 4 + (lane >> 4);
+            pf_w0[ps] = pf_w1[ps] = pf_a[ps] = 0u;
+            if (step < n_steps && k < d.K && q < d.Nq) {
+                const uint32_t s = (uint32_t)q * q_stride + (uint32_t)k;
+                const uint16_t *lw = loc_wg + 2 * (size_t)s;
+                if (pair_ok) pf_w0[ps] = *reinterpret_cast<const uint32_t *>(lw);
+                else { pf_w0[ps] = lw[0]; pf_w1[ps] = lw[1]; }
+                pf_a[ps] = attn_wg[s];
+            }
         }
     };
     prefetch(0);
@@ -147,8 +153,10 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
         }
         // ---- stage: one sample per lane
         uint32_t live = 0u;
-        {
-            const int sq = lane >> 4;
+        uint4 st_r0[PS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const int sq = ps * 4 + (lane >> 4);
             const int q = q0 + sq;
             // (a row-gather sample that reads nothing must not read row 0 either when the wave walks its tap for
             // another query: "outside" offsets, whose loads return zeros -> zero dots)
@@ -156,10 +164,10 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
             uint4 r1 = make_uint4(0u, 0u, 0u, 0u);
             bool reads = false;
             if (k_ok && q < d.Nq) {
-                asm volatile("" : "+v"(pf_w0), "+v"(pf_w1), "+v"(pf_a));
-                const uint32_t xb = pair_ok ? (pf_w0 & 0xffffu) : pf_w0, yb = pair_ok ? (pf_w0 >> 16) : pf_w1;
+                asm volatile("" : "+v"(pf_w0[ps]), "+v"(pf_w1[ps]), "+v"(pf_a[ps]));
+                const uint32_t xb = pair_ok ? (pf_w0[ps] & 0xffffu) : pf_w0[ps], yb = pair_ok ? (pf_w0[ps] >> 16) : pf_w1[ps];
                 const float lx = to_f32(__builtin_bit_cast(T, (uint16_t)xb)), ly = to_f32(__builtin_bit_cast(T, (uint16_t)yb));
-                const float a = to_f32(__builtin_bit_cast(T, (uint16_t)pf_a));
+                const float a = to_f32(__builtin_bit_cast(T, (uint16_t)pf_a[ps]));
                 const float y = ly * (float)Hl - 0.5f, x = lx * (float)Wl - 0.5f;
                 const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)Hl) && (x < (float)Wl);
                 const float yf = floorf(y), xf = floorf(x);
@@ -186,13 +194,19 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 }
             }
             const unsigned long long bl = __builtin_amdgcn_ballot_w64(reads);
-            live = (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
-            // a tap no query of the wave reads is never walked: its records keep what is written here -- zero dots
-            if (!in_lds && !((live >> kk) & 1u)) r0 = make_uint4(0u, 0u, 0u, 0u);
+            live |= (uint32_t)(bl | (bl >> 16) | (bl >> 32) | (bl >> 48)) & 0xffffu;
+            st_r0[ps] = r0;
             if (k_ok) {
                 uint4 *dst = reinterpret_cast<uint4 *>(wrec + sq * G::QSTRIDE + ridx * 32);
-                dst[0] = r0; dst[1] = r1;
+                dst[1] = r1;
             }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            // a tap no query of the wave reads is never walked: its records keep what is written here -- zero dots
+            uint4 r0 = st_r0[ps];
+            if (!in_lds && !((live >> kk) & 1u)) r0 = make_uint4(0u, 0u, 0u, 0u);
+            if (k_ok) *reinterpret_cast<uint4 *>(wrec + (ps * 4 + (lane >> 4)) * G::QSTRIDE + ridx * 32) = r0;
         }
         wave_sync();
         if (chunk == 0) {
@@ -256,7 +270,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 float dot[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dot[c] = RowDot<T>::run(graw, raw[c]);
-                group_sum4_row(dot, lig);                                 // totals in the group's lane 0
+                if (LPI == 16) group_sum4_row(dot, lig); else group_sum4_half(dot, lig);     // totals in the group's lane 0
                 if (lig == 0)
                     recs[2 * gi] = make_uint4(__float_as_uint(dot[0]), __float_as_uint(dot[1]), __float_as_uint(dot[2]), __float_as_uint(dot[3]));
                 __builtin_amdgcn_sched_barrier(0);
@@ -303,8 +317,9 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
 
         // ---- per-sample algebra of the reference (cuh:119-161) on the four corner dots, one lane per sample;
         // coalesced stores of this chunk's grad_attn / grad_loc
-        {
-            const int sq = lane >> 4;
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const int sq = ps * 4 + (lane >> 4);
             const int q = q0 + sq;
             if (k_ok && q < d.Nq) {
                 const uint4 *rec = reinterpret_cast<const uint4 *>(wrec + sq * G::QSTRIDE + ridx * 32);
@@ -363,7 +378,7 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
 bool taps_mma_supported(int dtype, const Dims &d)
 {
     if (dtype != 1 && dtype != 2) return false;
-    if (d.D != 128) return false;
+    if (d.D != 128 && d.D != 64) return false;
     if (d.L > kMmaMaxLevels || d.K <= 0) return false;
     if ((int64_t)d.Nq * d.H * d.K >= (1LL << 30)) return false;            // 32-bit sample offsets inside a (b, h) slab
     return (int64_t)d.S * d.H * d.D * 2 <= kMaxSlabBytes;
@@ -375,6 +390,7 @@ bool taps_mma_applies(int dtype, const Dims &d)
     if (d.taps_algo == 1 || (d.taps_algo == 0 && algo && algo[0] == 'v')) return false;
     if (!taps_mma_supported(dtype, d)) return false;
     if (d.taps_algo == 2 || (algo && algo[0] == 'm')) return true;
+    if (d.D != 128) return false;                              // (heads of 64 channels: round 5, opt-in until measured -- below)
     return d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;          // (as fwd_mma_applies: samples per image fill; speed-test shape 139 -> 102 us)
 }
 
@@ -382,6 +398,10 @@ hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes
                              const void *loc, const void *attn, const void *grad_out, void *grad_loc, void *grad_attn,
                              const Dims &d, hipStream_t st, const blk::PrepareJob *job)
 {
+    if (d.D == 64) {
+        if (dtype == 1) return launch_taps_mma<half_t, 64>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
+        return launch_taps_mma<bf16_t, 64>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
+    }
     if (dtype == 1) return launch_taps_mma<half_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
     return launch_taps_mma<bf16_t, 128>(value, shapes, start, loc, attn, grad_out, grad_loc, grad_attn, d, st, job);
 }

@@ -915,6 +915,12 @@ TAPS_LDS_CASES = [
     (3, 8, 128, 1, 4, [(16, 16), (8, 8)]),                              # one query
     (1, 2, 128, 300, 8, [(32, 32), (16, 16), (8, 8)] * 2),              # K = 48: three chunks per query group
     (2, 8, 128, 128, 64, [(16, 16), (8, 8)]),                           # the reference's speed-test shape: K = 128, all resident
+    # heads of 64 channels (round 5): eight queries per wave, two staging passes, 8-lane dot groups
+    (2, 16, 64, 200, 8, [(64, 64), (32, 32), (16, 16), (8, 8)]),        # the image decoder's geometry: K = 32, 16^2 + 8^2 resident
+    (1, 16, 64, 300, 8, [(32, 32), (16, 16), (8, 8)] * 4),              # the LLM's, four images: K = 96; the 8^2 maps and one 16^2 fit
+    (1, 2, 64, 70, 3, [(9, 5), (40, 40), (3, 3), (1, 1), (2, 9)]),      # K = 15: ragged chunk, ragged last tile, degenerate levels
+    (3, 4, 64, 5, 4, [(16, 16), (8, 8)]),                               # five queries: a ragged group of eight
+    (1, 2, 64, 50, 4, [(70, 70), (50, 50)]),                            # nothing fits
 ]
 
 
