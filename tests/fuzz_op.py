@@ -20,6 +20,7 @@ TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfl
 
 
 BIG = False
+WAVES = False      # round 5: every case a 16-bit head of 128 channels through the forward's fourth kernel (csrc/msda_fwd_wq.hip)
 
 
 def one_case(rng, idx):
@@ -28,6 +29,9 @@ def one_case(rng, idx):
     H = rng.choice([1, 2, 3, 4, 8, 16])
     D = rng.choice([8, 16, 24, 32, 64, 64, 128, 128, 256])
     P = rng.choice([1, 2, 3, 4, 4, 8, 8, 16, 32, 64])
+    if WAVES:
+        dtype, D = rng.choice([torch.float16, torch.bfloat16]), 128
+        P = rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 16])
     L = rng.randint(1, 6)
     shapes = [(rng.randint(1, 24), rng.randint(1, 24)) for _ in range(L)]
     if rng.random() < 0.3:
@@ -93,6 +97,8 @@ def one_case(rng, idx):
     # round 4: the forward's third kernel wherever it is supported (the library's own choice takes it only where the whole
     # pyramid is resident), next to the library's choice and the two older kernels
     MSDA._fwd_algo = rng.choice(["auto", "auto", "slices", "slices", "gather", "lds"])
+    if WAVES:
+        MSDA._fwd_algo = "waves"
     MSDA._ws_cache.clear()
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
     desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
