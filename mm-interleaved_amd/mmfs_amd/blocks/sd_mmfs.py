@@ -311,14 +311,24 @@ class MMFSNet(CacheInvalidation, nn.Module):
         feats = mmfs_features
         try:
             ref = feats[0]
+            # (decided once per bank geometry: the driver call that asks for the free memory does not belong in every
+            # step, and not inside a stream capture -- mmfs_amd.graphs.GraphedTrainingStep warms up eagerly first)
+            key = (tuple(tuple(f.shape) for f in feats), ref.dtype, str(ref.device), self.project_once_budget)
+            memo = self.__dict__.get("_project_once_memo")
+            if memo is not None and memo[0] == key:
+                return memo[1]
             pixels = sum(int(f.shape[-1]) * int(f.shape[-2]) for f in feats)
             n_tok = int(ref.shape[0]) * int(ref.shape[1]) * pixels
             width = max(int(b.mmfs.value_proj.out_features) for b in self._blocks())
             need = len(list(self._blocks())) * n_tok * width * ref.element_size()
-            free = torch.cuda.mem_get_info(ref.device)[0] if ref.is_cuda else 0
+            if ref.is_cuda and torch.cuda.is_current_stream_capturing():
+                return True                                # (a capture without a warm-up step: the round-4 default)
+            free = torch.cuda.mem_get_info(ref.device)[0] if ref.is_cuda else (1 << 62)
+            res = need <= self.project_once_budget * free
+            self.__dict__["_project_once_memo"] = (key, res)
+            return res
         except Exception:
             return False
-        return need <= self.project_once_budget * free
 
     def __init__(self, input_channel, block_out_channels, layers_per_block, downsample_factor=1,
                  n_levels=4, n_points=8, gradient_checkpointing=True, spatial_shapes=[64, 32, 16, 8]):
