@@ -1171,3 +1171,34 @@ def test_query_wave_forward_is_the_default_at_the_north_star_shape():
     llm = [(64, 64), (32, 32), (16, 16), (8, 8)]
     x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
+
+
+@pytest.mark.parametrize("algo", ["waves", "lds", "slices", "gather"])
+def test_forward_formulations_take_locations_that_start_on_an_odd_element(algo):
+    """``sampling_loc`` / ``attn_weight`` as views that start one 16-bit element into their storage (a slice of a larger
+    buffer: contiguous, 2-byte aligned, NOT 4-byte aligned): the kernels read an (x, y) pair as one 4-byte word only when the
+    base allows it (``pair_ok``), else as two halfwords -- the same results either way."""
+    import MultiScaleDeformableAttention as MSDA
+    B, H, D, Nq, P, shapes = 1, 4, 128, 300, 4, [(40, 40), (16, 16), (8, 8), (5, 3)]
+    x = make_inputs(B, H, D, Nq, P, shapes, seed=31, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    dev = lambda t: t.to(DEV, torch.bfloat16) if t.is_floating_point() else t.to(DEV)
+    value, sh, st, loc, attn = (dev(x[k]) for k in ("value", "shapes", "start", "loc", "attn"))
+
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 4 == 2
+        return v
+
+    old = MSDA._fwd_algo
+    MSDA._fwd_algo = algo
+    try:
+        a = MSDA.ms_deform_attn_forward(value, sh, st, loc, attn, 1)
+        b = MSDA.ms_deform_attn_forward(value, sh, st, shifted(loc), shifted(attn), 1)
+        torch.cuda.synchronize()
+    finally:
+        MSDA._fwd_algo = old
+    assert torch.equal(a, b)
+    want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
+    assert max_abs(a.double().cpu().numpy(), want) <= TOL[torch.bfloat16]
