@@ -34,6 +34,21 @@ namespace mmfs {
 
 using namespace mma;
 
+// Development aid (tools/exp_build.sh tapsprof "-DMMFS_PROFILE_TAPS"; tools/taps_prof.py): shader clocks per phase of a wave
+#ifdef MMFS_PROFILE_TAPS
+constexpr int kTProfSlots = 4096;
+__device__ unsigned long long g_taps_prof[kTProfSlots * 8];
+#define APROF_DECL unsigned long long aprof_c = __builtin_readcyclecounter(), aprof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define APROF(i) do { const unsigned long long tn = __builtin_readcyclecounter(); aprof_t[i] += tn - aprof_c; aprof_c = tn; } while (0)
+#define APROF_COUNT(i, v) do { aprof_t[i] += (unsigned long long)(v); } while (0)
+#define APROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_taps_prof[(blockIdx.x % kTProfSlots) * 8 + i_], aprof_t[i_]); } while (0)
+#else
+#define APROF_DECL do {} while (0)
+#define APROF(i) do {} while (0)
+#define APROF_COUNT(i, v) do {} while (0)
+#define APROF_FLUSH() do {} while (0)
+#endif
+
 #ifndef MMFS_TAPS_CHAINS
 #define MMFS_TAPS_CHAINS 1      // measured (r03h): 1: 144.7 us, 2: 152.4 us (the second chain's registers spill)
 #endif
@@ -63,6 +78,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     const int L = d.L;
     const int64_t HD = (int64_t)d.H * d.D;
     const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    APROF_DECL;
     build_level_table<D>(tab, img, shapes, start, L, tid, img_budget);
     // one run per workgroup, or persistent workgroups (persistent_grid, msda_mma_common.h)
     for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
@@ -116,7 +132,9 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
     prefetch(0);
     // ---- the run's image
     if (run != (int)blockIdx.x) __syncthreads();                          // every wave is done with the previous image
+    APROF(0);                                                             // run setup + barrier
     fill_image<D, false>(tab, img, rsrc, row_bytes, L, d.S, tid);         // natural channel order
+    APROF(1);                                                             // image fill
     uint4 graw = make_uint4(0u, 0u, 0u, 0u);                              // this lane's 16 bytes of its query's grad_out row
     s16x8 Bf[NKS];                                                        // B operand: the wave's queries, all of D
 
@@ -209,6 +227,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
             if (k_ok) *reinterpret_cast<uint4 *>(wrec + (ps * 4 + (lane >> 4)) * G::QSTRIDE + ridx * 32) = r0;
         }
         wave_sync();
+        APROF(2);                                                         // stage
         if (chunk == 0) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
@@ -282,8 +301,10 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 issue(r0, g0); issue(r1, g1); issue(r2, g2); issue(r3, g3);
                 prefetch(step + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                APROF(3);                                                 // first issues + next requests
                 mma_phase();
                 __builtin_amdgcn_sched_barrier(0);
+                APROF(4);                                                 // matrix-core phase
                 for (int i = 4; i < n_live; i += 4) {
                     consume(r0, g0); issue(r0, g0);
                     consume(r1, g1); issue(r1, g1);
@@ -291,6 +312,7 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                     consume(r3, g3); issue(r3, g3);
                 }
                 consume(r0, g0); consume(r1, g1); consume(r2, g2); consume(r3, g3);
+                APROF(5);                                                 // gather loop
             } else {
                 prefetch(step + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -335,8 +357,11 @@ msda_taps_mma(const T *__restrict__ value, const int64_t *__restrict__ shapes, c
                 store_xy(gl_wg, (int64_t)s, pair_ok, (float)Wl * dw * a, (float)Hl * dh * a);
             }
         }
+        APROF(6);                                                         // per-sample algebra + stores
     }
+    APROF_COUNT(7, n_steps);
     }   // runs
+    APROF_FLUSH();
     // ---- the opening launch of the grad_value half, hosted here (one launch less per backward): the FIRST workgroup
     // clears the sort's cursors and plans it; its LDS is free by now.  (One workgroup per run: it is done long before the
     // kernel is.  Persistent workgroups all end together and the plan is 4 us of one of them: a workgroup of its own
@@ -407,3 +432,19 @@ hipError_t backward_taps_mma(int dtype, const void *value, const int64_t *shapes
 }
 
 }  // namespace mmfs
+
+#ifdef MMFS_PROFILE_TAPS
+extern "C" int mmfs_debug_taps_profile(unsigned long long *out, int reset)
+{
+    static unsigned long long host[mmfs::kTProfSlots * 8];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(mmfs::g_taps_prof), sizeof(host));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int s = 0; s < mmfs::kTProfSlots; ++s)
+        for (int i = 0; i < 8; ++i) out[i] += host[s * 8 + i];
+    if (e == hipSuccess && reset) {
+        for (auto &v : host) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_taps_prof), host, sizeof(host));
+    }
+    return (int)e;
+}
+#endif
