@@ -115,7 +115,8 @@ int mmfs_msda_forward(int dtype,
  *                that fit in the CU's LDS (smallest first, decided on the device from the table) are copied
  *                there once per workgroup and sampled by the matrix cores, the others by row gather.
  * flags = 0 (rounds 3-4) picked LDS levels for heads of 128 channels when a (b, h) slab has at least 64 queries and 4096 samples;
- * round 5: such shapes with at most 16 samples per query take "query waves" (below), longer sample lists keep LDS levels (heads of
+ * round 5: such shapes with at most 16 samples per query take "query waves" (below), longer sample lists keep LDS levels -- both only
+ * in launches that give every CU two runs of (256, 128 or 64) queries, else the row gather, which fills the chip better -- (heads of
  * 64 channels measured no faster that way and stay on the row gather / the slices unless MMFS_FWD_LDS_LEVELS asks).
  * MMFS_FWD_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED.
  */

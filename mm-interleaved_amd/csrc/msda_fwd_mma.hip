@@ -409,11 +409,9 @@ static hipError_t launch_mma(const void *value, const int64_t *shapes, const int
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(G::IMG0 + 1024, env_kb * 1024)) : kLdsTotal;
     // queries per workgroup: the image fill (up to IMG_BUDGET bytes through the texture path) is paid per workgroup,
     // so runs are long; but the grid should still be a few workgroups per CU for the tail
-    int q_per_wg = 256;
     static const int env_q = getenv("MMFS_FWD_MMA_QPW") ? atoi(getenv("MMFS_FWD_MMA_QPW")) : 0;
-    if (env_q > 0) q_per_wg = env_q;
     const int unit = kMmaWaves * G::QPW;
-    q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
+    const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
     const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -445,7 +443,7 @@ bool fwd_mma_applies(int dtype, const Dims &d)
     // they stay on msda_fwd_vec unless asked for (MMFS_FWD_LDS_LEVELS / MMFS_FWD_ALGO=mma)
     // (r03ac: what matters is the samples a workgroup sees per image fill -- the reference's speed-test shape, 128 queries
     // of 128 samples, runs 132 -> 91 us this way; 128 queries of 16 samples do not pay)
-    return d.D == 128 && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;
+    return d.D == 128 && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096 && enough_runs(d);       // (round 5: + two runs per CU, r05ac)
 }
 
 hipError_t forward_mma(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

@@ -539,11 +539,9 @@ static hipError_t launch_wq(const void *value, const int64_t *shapes, const int6
     if (once2 != hipSuccess) return once2;
     static const int env_kb = getenv("MMFS_FWD_WQ_LDS_KB") ? atoi(getenv("MMFS_FWD_WQ_LDS_KB")) : 0;       // tuning / tests
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(G::IMG0 + 1024, env_kb * 1024)) : kLdsTotal;
-    int q_per_wg = 256;
     static const int env_q = getenv("MMFS_FWD_WQ_QPW") ? atoi(getenv("MMFS_FWD_WQ_QPW")) : 0;
-    if (env_q > 0) q_per_wg = env_q;
     const int unit = kMmaWaves * wq::kGroup;
-    q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
+    const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
     const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -577,7 +575,8 @@ bool fwd_wq_applies(int dtype, const Dims &d)
     // one chunk of samples per query (K <= 16: the north-star shape): the straight-line pipeline.  Longer sample lists run
     // chunk by chunk through the generic path and measured slower than msda_fwd_mma (the reference's speed-test shape,
     // K = 128: 156 vs 101 us, r05v): they keep the LDS-resident formulation
-    return d.K <= kChunk && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096;       // (an image fill per run of queries: as fwd_mma_applies)
+    // ... and only launches that give every CU two runs of queries (enough_runs, msda_mma_common.h: r05ac)
+    return d.K <= kChunk && d.Nq >= 64 && (int64_t)d.Nq * d.K >= 4096 && enough_runs(d);
 }
 
 hipError_t forward_wq(int dtype, const void *value, const int64_t *shapes, const int64_t *start,

@@ -179,6 +179,35 @@ inline int64_t persistent_grid(int64_t runs, int H)
     return cus;
 }
 
+// Queries per run (= per image fill) of the LDS-resident kernels.  256 where that still leaves two runs per CU (the north star:
+// 1024 runs); fewer queries than that per (b, h) slab and the runs are shortened -- 128, then 64 -- so that the launch keeps
+// filling the chip: at B * H = 64 slabs and 1024 queries, runs of 256 are ONE workgroup per CU (forward 48.6 us, the row
+// gather 44.7), runs of 128 two (39.1 us); at 256 queries runs of 256 left three quarters of the CUs idle (32 us against the
+// row gather's 17: r05ac).  enough_runs: even the shortest runs do not give every CU two -- such launches stay on the row gather.
+inline int device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+inline int pick_queries_per_run(const Dims &d, int unit, int env_q)
+{
+    int q = 256;
+    if (env_q > 0) q = env_q;
+    else {
+        const int64_t slabs = (int64_t)d.B * d.H, want = 2 * (int64_t)device_cus();
+        while (q > 64 && slabs * ((d.Nq + q - 1) / q) < want) q >>= 1;
+    }
+    return std::max(unit, (q + unit - 1) / unit * unit);
+}
+inline bool enough_runs(const Dims &d)
+{
+    return (int64_t)d.B * d.H * ((d.Nq + 63) / 64) >= 2 * (int64_t)device_cus();
+}
+
 // Level table -> LDS, and which levels live in the image: smallest first (ties: lower index), while they fit
 // behind the zero row.  Call from every thread of the workgroup; ends with a barrier.
 template <int D>

@@ -385,11 +385,9 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_taps_mma<T, D>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     if (once != hipSuccess) return once;
-    int q_per_wg = 256;
     static const int env_q = getenv("MMFS_TAPS_MMA_QPW") ? atoi(getenv("MMFS_TAPS_MMA_QPW")) : 0;
-    if (env_q > 0) q_per_wg = env_q;
     const int unit = kMmaWaves * G::QPW;
-    q_per_wg = std::max(unit, (q_per_wg + unit - 1) / unit * unit);
+    const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
     const int64_t runs = (int64_t)d.B * d.q_tiles * d.H;
     if (runs > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -703,7 +703,7 @@ def test_sliced_forward_is_the_default_where_the_whole_pyramid_is_resident():
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
     x = make_inputs(1, 16, 64, 200, 8, [(64, 64)] + llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)   # 64 x 64 does not fit
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
-    x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # heads of 128 channels
+    x = make_inputs(8, 8, 128, 512, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # heads of 128 channels, 512 runs of 64
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
 
 
@@ -793,10 +793,14 @@ def test_persistent_workgroups_compute_what_one_workgroup_per_run_does(shape, mo
 def test_query_wave_forward_is_the_default_for_long_runs(monkeypatch):
     """From 4096 samples per (b, h) slab on (and at least 64 queries), 16-bit heads of 128 channels take the wave-per-query
     formulation (round 5; rounds 3-4: the LDS-resident one of msda_fwd_mma.hip) -- and the autograd function's outputs and
-    gradients still match the oracle on such a shape; below, the row gather."""
+    gradients still match the oracle on such a shape; below, the row gather.  Round 5 (r05ac): and only launches that give every
+    CU two runs of queries -- 1024-lane workgroups that each fill an LDS image do not fill the chip otherwise (at the north
+    star's dimensions and 256 queries the row gather is twice as fast); runs are 256 queries, or 128 / 64 for fewer queries."""
     x = make_inputs(1, 4, 128, 100, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0     # 1200 samples
     x = make_inputs(1, 4, 128, 352, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0     # 4 slabs: 24 runs of 64
+    x = make_inputs(8, 8, 128, 520, 4, [(24, 24), (16, 16), (8, 8)], seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
     a, g = run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")
     assert max_abs(a, g) == 0.0
     assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0        # (a different summation order: not bit-equal)
@@ -1169,8 +1173,10 @@ def test_lds_levels_forward_non_finite_elements_match_the_reference(D):
 
 def test_query_wave_forward_is_the_default_at_the_north_star_shape():
     llm = [(64, 64), (32, 32), (16, 16), (8, 8)]
-    x = make_inputs(1, 8, 128, 352, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    x = make_inputs(8, 8, 128, 1024, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)    # (runs of 128 queries: 512 of them)
     assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "waves")) == 0.0
+    x = make_inputs(8, 8, 128, 256, 4, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # 256 runs of 64: the row gather
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
 
 
 @pytest.mark.parametrize("algo", ["waves", "lds", "slices", "gather"])
