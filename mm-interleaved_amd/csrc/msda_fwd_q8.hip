@@ -648,6 +648,12 @@ bool fwd_q8_applies(int dtype, const Dims &d)
     // ViT-Adapter's injector (42 -> 35 us).  With a row-gather level left (the image decoder's 64x64: 335 vs 339 us; the
     // LLM's 4 images: 234 vs 222) it does not pay, and heads of 128 channels pay the per-sample arithmetic four times
     // (north star: 196 us against msda_fwd_mma's 128).
+    // Round 5 (r05ae, tools/fwd_nq.py): and only launches with enough queries per CU -- a run is one 1024-lane workgroup and an
+    // image fill.  At the LLM layer's geometry (64 slabs x 2 slices) 2048 queries: 49.6 us against the row gather's 63.2, but
+    // 1024 queries: 41.5 against 31.2, 512: 23.0 against 18.5 (BASELINE config 3 runs 128 / 512 / 2048 tokens); the injector
+    // (512 slabs of 256 queries, one slice): 33 against 39, at 128 queries 26.7 against 25.3.
+    const int64_t per_cu = (int64_t)d.B * d.H * (d.D / q8::kCS) * d.Nq / device_cus();
+    if (per_cu < (d.D <= 32 ? 384 : 768)) return false;
     return d.D <= 64 && q8_all_resident_likely(d) && d.S >= 512 && d.Nq >= 128 && (int64_t)d.Nq * d.K >= 3072;      // (the injector: 256 queries x 12 samples per image fill)
 }
 

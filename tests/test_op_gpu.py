@@ -690,13 +690,18 @@ def test_sliced_forward_is_the_default_where_the_whole_pyramid_is_resident():
     """Heads of 32 / 64 channels whose levels all fit in the image (judged from S on the host: the entry point sees
     device pointers only) take the sliced formulation by default from 128 queries and 3072 samples per (b, h) on -- the
     LLM layer's real geometry with one image, the ViT-Adapter's injector (256 queries x 3 levels x 4 points, heads of
-    32 channels); heads of 128 channels, shapes with a level left to the row gather, and short runs keep what they had."""
+    32 channels); heads of 128 channels, shapes with a level left to the row gather, and short runs keep what they had.
+    Round 5 (r05ae): and only launches with enough queries per CU (768 query-slices at heads of 64 channels, 384 at 32) -- at
+    the LLM layer's geometry 2048 tokens take it (49.6 us against the row gather's 63.2), 1024 and 512 do not (41.5 / 23.0
+    against 31.2 / 18.5)."""
     llm = [(32, 32), (16, 16), (8, 8)]
-    x = make_inputs(1, 16, 64, 200, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)
+    x = make_inputs(4, 16, 64, 2048, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)    # BASELINE config 3 at 2048 tokens
     a = run_fwd(x, torch.bfloat16, "auto")
     assert max_abs(a, run_fwd(x, torch.bfloat16, "slices")) == 0.0
     assert max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0         # (another summation order: not bit-equal)
-    x = make_inputs(2, 16, 32, 256, 4, llm, seed=6, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # the injector's shape
+    x = make_inputs(4, 16, 64, 512, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # ... at 512 tokens: the row gather
+    assert max_abs(run_fwd(x, torch.bfloat16, "auto"), run_fwd(x, torch.bfloat16, "gather")) == 0.0
+    x = make_inputs(32, 16, 32, 256, 4, llm, seed=6, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)    # the injector's shape and batch
     a = run_fwd(x, torch.bfloat16, "auto")
     assert max_abs(a, run_fwd(x, torch.bfloat16, "slices")) == 0.0 and max_abs(a, run_fwd(x, torch.bfloat16, "gather")) > 0.0
     x = make_inputs(1, 16, 64, 100, 8, llm, seed=5, loc_range=(-0.1, 1.1), dtype=torch.bfloat16)     # fewer than 128 queries
