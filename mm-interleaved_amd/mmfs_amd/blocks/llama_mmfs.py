@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions.norm_func import rmsnorm, rmsnorm_supported
+from ..graphed import graphed_call
 from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
 from ..modules.mmfs import MMFS, FoldedLinear
 
@@ -30,6 +31,7 @@ class MMFSRMSNorm(nn.Module):
         self.variance_epsilon = eps
 
     fused = True          # one gfx950 kernel each way where it applies (csrc/mmfs_norm.hip); off: framework ops
+    _behaviour_flags = ("fused", "variance_epsilon")
 
     def forward(self, x):
         if self.fused and rmsnorm_supported(x, self.weight):
@@ -67,6 +69,8 @@ def deform_inputs(hidden_states, vision_hidden_states, spatial_shapes=((16, 16),
 
 
 class LlamaMMFSAttention(CacheInvalidation, nn.Module):
+    _behaviour_flags = ("fold_gate", "spatial_shapes")      # (part of a recorded call's key: mmfs_amd/graphed.py)
+
     def __init__(self, config, layer_idx):
         super().__init__()
         self.layer_idx = layer_idx
@@ -97,6 +101,7 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
         self.norm1 = MMFSRMSNorm(config.hidden_size, eps=eps)
         self.norm2 = MMFSRMSNorm(self.vision_hidden_size, eps=eps)
         self.fold_gate = True                     # no-grad calls: tanh(gate) folded into the output projection (forward)
+        self.graph_training_calls = True          # training mode: calls of a repeating shape replay HIP graphs (forward)
         self._gate_fold = FoldedLinear()
 
     def forward(self, hidden_states, vision_hidden_states=None, cross_attention_mask=None, value=None, image_ranks=None,
@@ -108,6 +113,16 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
         ``image_ranks`` (another): ``LlamaMMFSSchedule.image_ranks(cross_attention_mask, Lq)``, made once per step.
         ``residual`` (a third) [B, Lq, hidden]: the result is ``residual + layer(...)`` -- the decoder layer's own next
         statement (modeling_llama_mmfs.py:700-717), which without gradients rides in the output projection's kernel."""
+        if self.graph_training_calls and self.training:
+            # a training step's call as HIP graphs once its shapes have been seen a few times (mmfs_amd/graphed.py) -- the
+            # forward with its saved activations, the backward; and the no-grad forward of a checkpointing caller
+            res = graphed_call(self, self._forward, (hidden_states, vision_hidden_states, cross_attention_mask, value,
+                                                     image_ranks, residual), recompute=False)
+            if res is not NotImplemented:
+                return res
+        return self._forward(hidden_states, vision_hidden_states, cross_attention_mask, value, image_ranks, residual)
+
+    def _forward(self, hidden_states, vision_hidden_states, cross_attention_mask, value, image_ranks, residual):
         hidden_states = self.norm1(hidden_states)
         if value is None:
             vision_hidden_states = self.norm2(vision_hidden_states)

@@ -19,6 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
+from ..graphed import graphed_call
 from ..functions.linear_func import _split_k, token_linear
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
 from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
@@ -129,6 +130,11 @@ class _ProjectAll(torch.autograd.Function):
 class MMFSBlock(CacheInvalidation, nn.Module):
     layout_kernels_in_training = True
     fold_conv = True
+    # a checkpointed call as two HIP graphs -- the forward, and "forward again + backward" -- once its shapes have been
+    # seen a few times (mmfs_amd/graphed.py): the eager training step of the unchanged trainer is bound by the host
+    # otherwise (4 075 launches per step at BASELINE config 4).  False: ``torch.utils.checkpoint`` always.
+    graph_checkpoints = True
+    _behaviour_flags = ("layout_kernels_in_training", "fold_conv", "gradient_checkpointing")      # (part of a recorded call's key)
 
     def __init__(self, attn_dim=1024, query_dim=320, feat_dim=1024, num_heads=16, n_points=8,
                  n_levels=1, deform_ratio=1.0, norm_layer=partial(nn.LayerNorm, eps=1e-6),
@@ -256,6 +262,11 @@ class MMFSBlock(CacheInvalidation, nn.Module):
             # (``residual`` is an input the caller holds anyway -- for ``MMFSNet`` the sample itself)
             # (no random numbers inside: nothing of the generator's state to save -- which would also be a host round
             # trip that a HIP-graph capture of the step refuses)
+            if self.graph_checkpoints:
+                res = graphed_call(self, self._inner, (sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
+                                                       residual, normed), recompute=True)
+                if res is not NotImplemented:
+                    return res
             return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
                                  normed, use_reentrant=False, preserve_rng_state=False)
         return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual, normed)

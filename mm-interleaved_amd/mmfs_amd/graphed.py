@@ -1,0 +1,352 @@
+"""HIP graphs behind a block's ``forward`` -- the eager training step stops being bound by the host (round 5).
+
+The reference's trainer calls the blocks eagerly and under gradient checkpointing (sd_mmfs.py:138-141: every ``MMFSBlock``;
+modeling_llama_mmfs.py:700-717: the decoder layer around every ``LlamaMMFSAttention``).  A block is 40-120 small launches
+each way; at BASELINE config 4 the 13 blocks' step is 4 075 launches that the host issues in 34-40 ms while their kernels
+take 23 (profiles/r05zz_module_bench.jsonl).  ``GraphedTrainingStep`` (mmfs_amd/graphs.py) removes that by recording the
+WHOLE step, which needs the caller to restructure its loop.  This module does it behind the unchanged call:
+
+  * ``graphed_call(owner, fn, args, recompute)`` is what ``MMFSBlock.forward`` / ``LlamaMMFSAttention.forward`` run their
+    body through.  Calls are told apart by a KEY -- shapes, strides, dtypes and ``requires_grad`` of the tensor arguments,
+    the other arguments by value, the module's parameters by address (and by version where a result could be baked in),
+    grad mode, training mode, the package's cache epoch.  The first ``capture_after`` calls with a key run eagerly (they
+    are also the warm-up a capture needs); the next one records HIP graphs over static buffers; from then on a call is:
+    copy the arguments into the buffers, one graph launch, clone the result.
+  * with gradients it is an ``autograd.Function`` whose inputs are the tensor arguments AND the module's parameters, so
+    parameter gradients reach ``p.grad`` (and any hook on it: DDP, DeepSpeed) the ordinary way.  ``recompute=True``
+    (the checkpointed blocks): the forward graph runs without autograd and keeps nothing, the backward graph is
+    "forward with autograd + backward" -- what ``torch.utils.checkpoint`` does, as one launch.  ``recompute=False``:
+    the forward graph is recorded WITH autograd, its saved activations live in the graph's private pool, the backward
+    graph is the backward alone (``torch.cuda.make_graphed_callables``' scheme, per call and lazily).
+  * nothing is assumed about the caller's order of calls.  Every static buffer counts its writes, and the Function saves
+    the caller's own tensors (they are alive anyway).  A backward whose input buffers were written since its forward
+    (two forwards before the first backward; a shared bank buffer another module used) copies the caller's tensors in
+    again before it replays; one whose saved ACTIVATIONS are gone (``recompute=False`` and a later forward of the same
+    key) does not replay at all: it recomputes eagerly from the caller's tensors -- slower, never wrong.
+  * a capture that fails (an op that synchronises, an allocation refused) marks the key as refused: eager from then on.
+
+Not used (the caller's plain path runs): CPU tensors, inside another capture, under autocast / inference mode / an active
+``TorchDispatchMode`` or the shim's launch-event log (someone is counting ops: let them see the ops),
+``mmfs_amd.graphed.enabled = False``.
+"""
+import weakref
+
+import torch
+
+import MultiScaleDeformableAttention as MSDA
+
+from .levels import cache_epoch, tensor_version
+
+enabled = True
+capture_after = 2            # eager calls with a key before it is recorded
+max_entries = 4              # recorded keys per module (least recently used goes first)
+stage_bytes = 4 << 20        # read-only tensor arguments at least this large share ONE static copy across modules
+
+_pools = {}                  # device index -> graph memory pool shared by the recompute-mode graphs
+_stages = {}                 # (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument
+stats = {"captures": 0, "replays": 0, "eager_backward": 0, "refused": 0}
+
+
+class _Static:
+    """A buffer recorded graphs read.  ``gen`` counts its writes."""
+    __slots__ = ("t", "gen", "src", "ver")
+
+    def __init__(self, like, requires_grad=False):
+        self.t = torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=like.device)
+        if requires_grad:
+            self.t.requires_grad_(True)
+        self.gen, self.src, self.ver = 0, None, None
+
+    def load(self, x, shared):
+        if shared:
+            # the same tensor object, unmodified: the 13 blocks of a net are handed one bank
+            if self.src is not None and self.src() is x and self.ver == tensor_version(x):
+                return self.gen
+            self.src, self.ver = weakref.ref(x), tensor_version(x)
+        with torch.no_grad():
+            self.t.copy_(x)
+        self.gen += 1
+        return self.gen
+
+
+def _pool(dev):
+    p = _pools.get(dev.index)
+    if p is None:
+        p = _pools[dev.index] = torch.cuda.graph_pool_handle()
+    return p
+
+
+def _hashable(a):
+    if a is None or isinstance(a, (bool, int, float, str, torch.dtype)):
+        return a
+    if isinstance(a, (tuple, list)):
+        return tuple(_hashable(v) for v in a)
+    raise TypeError(type(a))
+
+
+class _Table(dict):
+    """A module's recorded calls.  Lives in the module's ``__dict__``; a copy or a pickle of the module starts empty."""
+
+    def __deepcopy__(self, memo):
+        return _Table()
+
+    def __reduce__(self):
+        return (_Table, ())
+
+
+class _Entry:
+    def __init__(self, key):
+        self.key, self.seen, self.state, self.tick = key, 0, 0, 0       # state: 0 counting, 1 recorded, -1 refused
+
+    # ---- what a call looks like: positions of the tensor arguments in ``args`` (an argument passed twice is one input)
+    def bind(self, fn, args, params, recompute, need_grad):
+        self.fn, self.recompute, self.need_grad = fn, recompute, need_grad
+        self.template = [None if isinstance(a, torch.Tensor) else a for a in args]     # (the call's tensors are not kept)
+        self.slots, self.dyn_pos, seen = [], [], {}
+        for i, a in enumerate(args):
+            if isinstance(a, torch.Tensor):
+                j = seen.get(id(a))
+                if j is None:
+                    j = seen[id(a)] = len(self.dyn_pos)
+                    self.dyn_pos.append(i)
+                self.slots.append((i, j))
+        self.params = [p for p in params if p.requires_grad] if need_grad else []
+
+    def call_args(self, dyn):
+        out = list(self.template)
+        for i, j in self.slots:
+            out[i] = dyn[j]
+        return out
+
+    def dyn_of(self, args):
+        return [args[i] for i in self.dyn_pos]
+
+    # ---- recording
+    def capture(self, args):
+        dyn = self.dyn_of(args)
+        dev = dyn[0].device
+        self.req = [bool(x.requires_grad) and self.need_grad for x in dyn]
+        self.shared = [(not x.requires_grad) and x.numel() * x.element_size() >= stage_bytes for x in dyn]
+        self.static = []
+        for j, (x, rq, sh) in enumerate(zip(dyn, self.req, self.shared)):
+            if sh:
+                # (keyed by the argument's place too: a call's bank and its normalised bank have one shape)
+                k = (j, tuple(x.shape), tuple(x.stride()), x.dtype, x.device)
+                s = _stages.get(k)
+                if s is None:
+                    s = _stages[k] = _Static(x)
+            else:
+                s = _Static(x, rq and not self.recompute)
+            self.static.append(s)
+        self.load(dyn)
+        ins = [s.t for s in self.static]
+        pool = _pool(dev) if self.recompute else torch.cuda.graph_pool_handle()
+        self.run_gen = 0
+        # one run of everything that will be recorded, on a side stream (library handles, workspaces, kept tables)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if self.need_grad:
+                outs, lv = self._with_grad(ins)
+                gout = [torch.zeros_like(o) for o in outs]
+                self._grads(outs, lv, gout)
+                del outs, lv
+            else:
+                with torch.no_grad():
+                    outs = self._outs(self.fn(*self.call_args(ins)))
+                del outs
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.fwd = torch.cuda.CUDAGraph()
+        if not self.need_grad or self.recompute:
+            with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode="thread_local"):
+                with torch.no_grad():
+                    outs = self._outs(self.fn(*self.call_args(ins)))
+            self.out = [o.detach() for o in outs]
+            del outs
+        if self.need_grad:
+            self.bwd = torch.cuda.CUDAGraph()
+            if self.recompute:
+                self.gout = [torch.zeros_like(o) for o in self.out]
+                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode="thread_local"):
+                    outs, lv = self._with_grad(ins)
+                    grads = self._grads(outs, lv, self.gout)
+            else:
+                with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode="thread_local"):
+                    outs, lv = self._with_grad(ins, leaves=ins)
+                self.out = [o.detach() for o in outs]
+                self.gout = [torch.zeros_like(o) for o in self.out]
+                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode="thread_local"):
+                    grads = self._grads(outs, lv, self.gout)
+            del outs, lv
+            self.gin = list(grads)                 # aligned with [inputs that want a gradient] + params
+        self.state = 1
+        stats["captures"] += 1
+
+    def _outs(self, res):
+        self.single = isinstance(res, torch.Tensor)
+        return [res] if self.single else list(res)
+
+    def _with_grad(self, ins, leaves=None):
+        with torch.enable_grad():
+            lv = leaves if leaves is not None else [x.detach().requires_grad_(rq) for x, rq in zip(ins, self.req)]
+            outs = self._outs(self.fn(*self.call_args(lv)))
+        return outs, lv
+
+    def _grads(self, outs, lv, gout):
+        wrt = [x for x, rq in zip(lv, self.req) if rq] + self.params
+        pick = [(o, g) for o, g in zip(outs, gout) if o.requires_grad]
+        if not pick or not wrt:
+            return [None] * len(wrt)
+        return torch.autograd.grad([o for o, _ in pick], wrt, [g for _, g in pick], allow_unused=True)
+
+    # ---- a call
+    def load(self, dyn):
+        return tuple(s.load(x, sh) for s, x, sh in zip(self.static, dyn, self.shared))
+
+    def forward(self, dyn):
+        gens = self.load(dyn)
+        self.run_gen += 1
+        self.fwd.replay()
+        stats["replays"] += 1
+        return gens, [o.clone() for o in self.out]
+
+    def result(self, outs):
+        return outs[0] if self.single else tuple(outs)
+
+    def replayable(self, run_gen):
+        """Whether the backward graph can serve the call whose forward was replay ``run_gen``: always when it recomputes
+        (it needs the inputs only); else only while no later forward has overwritten the activations it saved."""
+        return self.state == 1 and (self.recompute or run_gen == self.run_gen)
+
+    def backward(self, dyn, gens, gouts):
+        for s, x, sh, g in zip(self.static, dyn, self.shared, gens):
+            if s.gen != g:                         # (written since this call's forward: the caller's tensor again)
+                s.load(x, sh)
+        with torch.no_grad():
+            for buf, g in zip(self.gout, gouts):
+                if g is None:
+                    buf.zero_()
+                else:
+                    buf.copy_(g)
+        self.bwd.replay()
+        stats["replays"] += 1
+        return self.gin
+
+    def eager_backward(self, dyn, gouts):
+        """The way back without the graphs (their buffers moved on since this call's forward): recompute from the
+        caller's tensors, as ``torch.utils.checkpoint`` would."""
+        stats["eager_backward"] += 1
+        outs, lv = self._with_grad(list(dyn))
+        gout = [torch.zeros_like(o) if g is None else g for o, g in zip(outs, gouts)]
+        return list(self._grads(outs, lv, gout))
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, entry, n_dyn, *flat):
+        dyn = flat[:n_dyn]
+        gens, outs = entry.forward(dyn)
+        ctx.entry, ctx.gens, ctx.run_gen = entry, gens, entry.run_gen
+        ctx.save_for_backward(*dyn)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        e = ctx.entry
+        if e.replayable(ctx.run_gen):
+            grads = e.backward(ctx.saved_tensors, ctx.gens, gouts)
+        else:
+            grads = e.eager_backward(ctx.saved_tensors, gouts)
+        it = iter(grads)
+        gin = [next(it) if rq else None for rq in e.req]
+        return (None, None) + tuple(gin) + tuple(it)
+
+
+def _eligible(args):
+    if not enabled or not torch.cuda.is_available():
+        return None
+    first = None
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda or (first is not None and a.device != first.device):
+                return None
+            if first is None:
+                first = a
+    if first is None or torch.is_autocast_enabled() or torch.is_inference_mode_enabled():
+        return None
+    if MSDA._event_log is not None:                    # (someone brackets every launch with events: bench.py's kernel pass)
+        return None
+    depth = getattr(torch._C, "_len_torch_dispatch_stack", None)
+    if (depth is not None and depth() > 0) or torch.cuda.is_current_stream_capturing():
+        return None
+    return first
+
+
+def _key(owner, args, recompute, grad):
+    parts = [recompute, grad, owner.training, cache_epoch()]
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            parts.append((tuple(a.shape), tuple(a.stride()), a.dtype, a.requires_grad and grad))
+        else:
+            parts.append(_hashable(a))
+    ident = {}
+    for i, a in enumerate(args):                       # which arguments are the same tensor
+        if isinstance(a, torch.Tensor):
+            parts.append(ident.setdefault(id(a), i))
+    for p in owner.parameters():
+        # a trainable parameter is read at its address every replay; a frozen one (and any, without gradients) may have
+        # been baked into something the recorded kernels read: its version counts too
+        parts.append((p.data_ptr(), p.dtype, p.requires_grad,
+                      tensor_version(p) if (not grad or not p.requires_grad) else -2))
+    for b in owner.buffers():
+        parts.append((b.data_ptr(), b.dtype, tensor_version(b)))
+    for m in owner.modules():                          # the switches that choose a module's path (``_behaviour_flags``)
+        for f in getattr(type(m), "_behaviour_flags", ()):
+            parts.append(_hashable(getattr(m, f, None)))
+    return tuple(parts)
+
+
+def graphed_call(owner, fn, args, recompute):
+    """``fn(*args)`` through recorded HIP graphs when this call's key has them; ``NotImplemented`` when the caller should
+    run its plain path (not eligible, still counting, refused).  ``owner``: the module whose parameters ``fn`` reads."""
+    if _eligible(args) is None:
+        return NotImplemented
+    grad = torch.is_grad_enabled()
+    try:
+        key = _key(owner, args, recompute, grad)
+    except TypeError:
+        return NotImplemented
+    table = owner.__dict__.get("_graphed")
+    if table is None:
+        table = owner.__dict__["_graphed"] = _Table()
+    e = table.get(key)
+    if e is None:
+        e = table[key] = _Entry(key)
+        if len(table) > 4 * max_entries:               # (keys that never came back)
+            for k in [k for k, v in table.items() if v.state != 1 and v is not e][:len(table) // 2]:
+                del table[k]
+    e.seen += 1
+    owner.__dict__["_graphed_tick"] = e.tick = owner.__dict__.get("_graphed_tick", 0) + 1
+    if e.state == 0 and e.seen > capture_after:
+        params = list(owner.parameters())
+        need = grad and (any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
+                         or any(p.requires_grad for p in params))
+        try:
+            e.bind(fn, args, params, recompute, need)
+            e.capture(args)
+            live = [v for v in table.values() if v.state == 1]
+            if len(live) > max_entries:
+                old = min((v for v in live if v is not e), key=lambda v: v.tick)
+                del table[old.key]
+        except Exception:
+            e.state = -1
+            stats["refused"] += 1
+            for name in ("fwd", "bwd", "out", "gout", "gin", "static"):
+                e.__dict__.pop(name, None)
+    if e.state != 1:
+        return NotImplemented
+    dyn = e.dyn_of(args)
+    if not e.need_grad:
+        return e.result(e.forward(dyn)[1])
+    return e.result(list(_GraphedFn.apply(e, len(dyn), *dyn, *e.params)))

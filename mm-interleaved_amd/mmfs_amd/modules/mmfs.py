@@ -71,6 +71,10 @@ class FoldedLinear:
 
 
 class MMFS(CacheInvalidation, nn.Module):
+    # the switches that choose this module's path: part of the key of a recorded call (mmfs_amd/graphed.py)
+    _behaviour_flags = ("stack_heads_in_training", "fused_plan", "fold_query_projection", "fused_sampler", "im2col_step",
+                        "max_num_image_per_seq")
+
     def __init__(
         self,
         layer_idx=0,
