@@ -32,6 +32,7 @@ Not used (the caller's plain path runs): CPU tensors, inside another capture, un
 import weakref
 
 import torch
+from torch.nn.utils import stateless
 
 import MultiScaleDeformableAttention as MSDA
 
@@ -41,6 +42,9 @@ enabled = True
 capture_after = 2            # eager calls with a key before it is recorded
 max_entries = 4              # recorded keys per module (least recently used goes first)
 stage_bytes = 4 << 20        # read-only tensor arguments at least this large share ONE static copy across modules
+share_pool = True            # the recompute-mode graphs of all modules record into one memory pool (their transients overlap)
+capture_error_mode = "thread_local"
+trace = None                 # a callable(str): debugging aid
 
 _pools = {}                  # device index -> graph memory pool shared by the recompute-mode graphs
 _stages = {}                 # (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument
@@ -67,6 +71,11 @@ class _Static:
             self.t.copy_(x)
         self.gen += 1
         return self.gen
+
+
+def _t(msg):
+    if trace is not None:
+        trace(msg)
 
 
 def _pool(dev):
@@ -99,8 +108,8 @@ class _Entry:
         self.key, self.seen, self.state, self.tick = key, 0, 0, 0       # state: 0 counting, 1 recorded, -1 refused
 
     # ---- what a call looks like: positions of the tensor arguments in ``args`` (an argument passed twice is one input)
-    def bind(self, fn, args, params, recompute, need_grad):
-        self.fn, self.recompute, self.need_grad = fn, recompute, need_grad
+    def bind(self, owner, fn, args, recompute, need_grad):
+        self.owner, self.fn, self.recompute, self.need_grad = owner, fn, recompute, need_grad
         self.template = [None if isinstance(a, torch.Tensor) else a for a in args]     # (the call's tensors are not kept)
         self.slots, self.dyn_pos, seen = [], [], {}
         for i, a in enumerate(args):
@@ -110,7 +119,8 @@ class _Entry:
                     j = seen[id(a)] = len(self.dyn_pos)
                     self.dyn_pos.append(i)
                 self.slots.append((i, j))
-        self.params = [p for p in params if p.requires_grad] if need_grad else []
+        named = [(k, p) for k, p in owner.named_parameters() if p.requires_grad] if need_grad else []
+        self.names, self.params = [k for k, _ in named], [p for _, p in named]
 
     def call_args(self, dyn):
         out = list(self.template)
@@ -140,45 +150,56 @@ class _Entry:
             self.static.append(s)
         self.load(dyn)
         ins = [s.t for s in self.static]
-        pool = _pool(dev) if self.recompute else torch.cuda.graph_pool_handle()
+        pool = _pool(dev) if (self.recompute and share_pool) else torch.cuda.graph_pool_handle()
         self.run_gen = 0
         # one run of everything that will be recorded, on a side stream (library handles, workspaces, kept tables)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             if self.need_grad:
-                outs, lv = self._with_grad(ins)
+                outs, lv, pal = self._with_grad(ins)
                 gout = [torch.zeros_like(o) for o in outs]
-                self._grads(outs, lv, gout)
-                del outs, lv
+                self._grads(outs, lv, pal, gout)
+                del outs, lv, pal
             else:
                 with torch.no_grad():
                     outs = self._outs(self.fn(*self.call_args(ins)))
                 del outs
         torch.cuda.current_stream(dev).wait_stream(side)
+        _t("warm-up done")
         self.fwd = torch.cuda.CUDAGraph()
         if not self.need_grad or self.recompute:
-            with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode=capture_error_mode):
                 with torch.no_grad():
                     outs = self._outs(self.fn(*self.call_args(ins)))
             self.out = [o.detach() for o in outs]
             del outs
+            _t("forward recorded")
         if self.need_grad:
             self.bwd = torch.cuda.CUDAGraph()
             if self.recompute:
                 self.gout = [torch.zeros_like(o) for o in self.out]
-                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode="thread_local"):
-                    outs, lv = self._with_grad(ins)
-                    grads = self._grads(outs, lv, self.gout)
+                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode=capture_error_mode):
+                    _t("backward: recording")
+                    outs, lv, pal = self._with_grad(ins)
+                    _t("backward: forward part issued")
+                    try:
+                        grads = self._grads(outs, lv, pal, self.gout)
+                    except BaseException as ex:
+                        import traceback
+                        _t("backward: FAILED " + "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))[-3000:])
+                        raise
+                    _t("backward: issued")
             else:
-                with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode="thread_local"):
-                    outs, lv = self._with_grad(ins, leaves=ins)
+                with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode=capture_error_mode):
+                    outs, lv, pal = self._with_grad(ins, leaves=ins)
                 self.out = [o.detach() for o in outs]
                 self.gout = [torch.zeros_like(o) for o in self.out]
-                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode="thread_local"):
-                    grads = self._grads(outs, lv, self.gout)
-            del outs, lv
+                with torch.cuda.graph(self.bwd, pool=pool, capture_error_mode=capture_error_mode):
+                    grads = self._grads(outs, lv, pal, self.gout)
+            del outs, lv, pal
             self.gin = list(grads)                 # aligned with [inputs that want a gradient] + params
+            _t("backward recorded")
         self.state = 1
         stats["captures"] += 1
 
@@ -187,13 +208,22 @@ class _Entry:
         return [res] if self.single else list(res)
 
     def _with_grad(self, ins, leaves=None):
+        """``fn`` with autograd on fresh leaves: detached views of the inputs, and ALIASES of the module's parameters
+        (swapped in for the call, ``torch.func.functional_call``'s mechanism).  Not the parameters themselves: a
+        parameter's gradient-accumulation node lives as long as any graph that used it -- a trainer's ``loss`` of the
+        previous step is still alive when the next forward runs -- and belongs to the stream it was made on, normally the
+        legacy default stream; a backward pass RECORDED on a capturing stream that ends at such a node fails
+        ("operation would make the legacy stream depend on a capturing blocking stream"), and ending that capture
+        takes the process down inside the HIP runtime (r05g3-5)."""
         with torch.enable_grad():
             lv = leaves if leaves is not None else [x.detach().requires_grad_(rq) for x, rq in zip(ins, self.req)]
-            outs = self._outs(self.fn(*self.call_args(lv)))
-        return outs, lv
+            pal = [p.detach().requires_grad_(True) for p in self.params]
+            with stateless._reparametrize_module(self.owner, dict(zip(self.names, pal))):
+                outs = self._outs(self.fn(*self.call_args(lv)))
+        return outs, lv, pal
 
-    def _grads(self, outs, lv, gout):
-        wrt = [x for x, rq in zip(lv, self.req) if rq] + self.params
+    def _grads(self, outs, lv, pal, gout):
+        wrt = [x for x, rq in zip(lv, self.req) if rq] + pal
         pick = [(o, g) for o, g in zip(outs, gout) if o.requires_grad]
         if not pick or not wrt:
             return [None] * len(wrt)
@@ -230,15 +260,18 @@ class _Entry:
                     buf.copy_(g)
         self.bwd.replay()
         stats["replays"] += 1
-        return self.gin
+        # copies: the graphs of all modules share one pool, and what is an OUTPUT here may be a transient of a graph that
+        # was recorded earlier -- whose next replay (the previous block's backward) comes before autograd has consumed
+        # this gradient (a projected bank's: at the very end of the backward pass)
+        return [None if g is None else g.clone() for g in self.gin]
 
     def eager_backward(self, dyn, gouts):
         """The way back without the graphs (their buffers moved on since this call's forward): recompute from the
         caller's tensors, as ``torch.utils.checkpoint`` would."""
         stats["eager_backward"] += 1
-        outs, lv = self._with_grad(list(dyn))
+        outs, lv, pal = self._with_grad(list(dyn))
         gout = [torch.zeros_like(o) if g is None else g for o, g in zip(outs, gouts)]
-        return list(self._grads(outs, lv, gout))
+        return list(self._grads(outs, lv, pal, gout))
 
 
 class _GraphedFn(torch.autograd.Function):
@@ -329,11 +362,10 @@ def graphed_call(owner, fn, args, recompute):
     e.seen += 1
     owner.__dict__["_graphed_tick"] = e.tick = owner.__dict__.get("_graphed_tick", 0) + 1
     if e.state == 0 and e.seen > capture_after:
-        params = list(owner.parameters())
         need = grad and (any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
-                         or any(p.requires_grad for p in params))
+                         or any(p.requires_grad for p in owner.parameters()))
         try:
-            e.bind(fn, args, params, recompute, need)
+            e.bind(owner, fn, args, recompute, need)
             e.capture(args)
             live = [v for v in table.values() if v.state == 1]
             if len(live) > max_entries:
