@@ -29,6 +29,7 @@ Not used (the caller's plain path runs): CPU tensors, inside another capture, un
 ``TorchDispatchMode`` or the shim's launch-event log (someone is counting ops: let them see the ops),
 ``mmfs_amd.graphed.enabled = False``.
 """
+import gc
 import weakref
 
 import torch
@@ -46,7 +47,7 @@ share_pool = True            # the recompute-mode graphs of all modules record i
 capture_error_mode = "thread_local"
 trace = None                 # a callable(str): debugging aid
 
-_pools = {}                  # device index -> graph memory pool shared by the recompute-mode graphs
+_pools = {}                  # device index -> (graph memory pool shared by the recompute-mode graphs, the entries recorded into it)
 _stages = {}                 # (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument
 stats = {"captures": 0, "replays": 0, "eager_backward": 0, "refused": 0}
 
@@ -79,10 +80,26 @@ def _t(msg):
 
 
 def _pool(dev):
+    """The shared pool and the set of entries whose graphs keep it alive.  A handle whose graphs have all been destroyed
+    (the model was deleted) names a pool the allocator has released: recording into it again fails inside
+    ``capture_begin`` -- after the generator has been put into capture mode, which then stays on (r05g6-8) -- so a pool
+    nobody holds any more is replaced by a fresh one."""
     p = _pools.get(dev.index)
-    if p is None:
-        p = _pools[dev.index] = torch.cuda.graph_pool_handle()
+    if p is None or len(p[1]) == 0:
+        p = _pools[dev.index] = (torch.cuda.graph_pool_handle(), weakref.WeakSet())
     return p
+
+
+def _reset_generator(dev):
+    """A capture that failed before it began leaves the default generator in capture mode (every later random number
+    raises "Offset increment outside graph capture"); the next successful capture takes it out again: make one."""
+    try:
+        x = torch.zeros(8, device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode=capture_error_mode):
+            x.add_(1.0)
+    except Exception:
+        pass
 
 
 def _hashable(a):
@@ -150,7 +167,11 @@ class _Entry:
             self.static.append(s)
         self.load(dyn)
         ins = [s.t for s in self.static]
-        pool = _pool(dev) if (self.recompute and share_pool) else torch.cuda.graph_pool_handle()
+        holders = None
+        if self.recompute and share_pool:
+            pool, holders = _pool(dev)
+        else:
+            pool = torch.cuda.graph_pool_handle()
         self.run_gen = 0
         # one run of everything that will be recorded, on a side stream (library handles, workspaces, kept tables)
         side = torch.cuda.Stream(device=dev)
@@ -200,6 +221,8 @@ class _Entry:
             del outs, lv, pal
             self.gin = list(grads)                 # aligned with [inputs that want a gradient] + params
             _t("backward recorded")
+        if holders is not None:
+            holders.add(self)
         self.state = 1
         stats["captures"] += 1
 
@@ -364,6 +387,10 @@ def graphed_call(owner, fn, args, recompute):
     if e.state == 0 and e.seen > capture_after:
         need = grad and (any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
                          or any(p.requires_grad for p in owner.parameters()))
+        # (no garbage collection while a stream records: a dead module's graphs destroyed in the middle of a capture
+        # are driver calls a capture does not allow)
+        collecting = gc.isenabled()
+        gc.disable()
         try:
             e.bind(owner, fn, args, recompute, need)
             e.capture(args)
@@ -371,11 +398,17 @@ def graphed_call(owner, fn, args, recompute):
             if len(live) > max_entries:
                 old = min((v for v in live if v is not e), key=lambda v: v.tick)
                 del table[old.key]
-        except Exception:
+        except Exception as ex:
             e.state = -1
+            e.error = repr(ex)
             stats["refused"] += 1
             for name in ("fwd", "bwd", "out", "gout", "gin", "static"):
                 e.__dict__.pop(name, None)
+            _t("refused: " + e.error[:500])
+            _reset_generator(args[e.dyn_pos[0]].device if getattr(e, "dyn_pos", None) else torch.device("cuda"))
+        finally:
+            if collecting:
+                gc.enable()
     if e.state != 1:
         return NotImplemented
     dyn = e.dyn_of(args)
