@@ -15,7 +15,8 @@ WHOLE step, which needs the caller to restructure its loop.  This module does it
   * with gradients it is an ``autograd.Function`` whose inputs are the tensor arguments AND the module's parameters, so
     parameter gradients reach ``p.grad`` (and any hook on it: DDP, DeepSpeed) the ordinary way.  ``recompute=True``
     (the checkpointed blocks): the forward graph runs without autograd and keeps nothing, the backward graph is
-    "forward with autograd + backward" -- what ``torch.utils.checkpoint`` does, as one launch.  ``recompute=False``:
+    "forward with autograd + backward" -- what ``torch.utils.checkpoint`` does, as one launch (and like its forward, the
+    recorded one runs the with-gradients formulation of the modules: a replayed call returns the eager call's bits).  ``recompute=False``:
     the forward graph is recorded WITH autograd, its saved activations live in the graph's private pool, the backward
     graph is the backward alone (``torch.cuda.make_graphed_callables``' scheme, per call and lazily).
   * nothing is assumed about the caller's order of calls.  Every static buffer counts its writes, and the Function saves
@@ -168,7 +169,8 @@ class _Entry:
         self.load(dyn)
         ins = [s.t for s in self.static]
         holders = None
-        if self.recompute and share_pool:
+        self.pooled = self.recompute and share_pool
+        if self.pooled:
             pool, holders = _pool(dev)
         else:
             pool = torch.cuda.graph_pool_handle()
@@ -189,13 +191,21 @@ class _Entry:
         torch.cuda.current_stream(dev).wait_stream(side)
         _t("warm-up done")
         self.fwd = torch.cuda.CUDAGraph()
-        if not self.need_grad or self.recompute:
+        if not self.need_grad:
             with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode=capture_error_mode):
                 with torch.no_grad():
                     outs = self._outs(self.fn(*self.call_args(ins)))
             self.out = [o.detach() for o in outs]
             del outs
-            _t("forward recorded")
+        elif self.recompute:
+            # the forward of a non-reentrant checkpoint runs WITH autograd (its saved tensors are dropped, not its
+            # formulation changed): the same kernels here, so that a replayed call returns the eager call's bits
+            # (the modules' no-grad formulations round at other points: one 16-bit step apart, r05g9)
+            with torch.cuda.graph(self.fwd, pool=pool, capture_error_mode=capture_error_mode):
+                outs, lv, pal = self._with_grad(ins)
+            self.out = [o.detach() for o in outs]
+            del outs, lv, pal
+        _t("forward recorded")
         if self.need_grad:
             self.bwd = torch.cuda.CUDAGraph()
             if self.recompute:
@@ -286,7 +296,7 @@ class _Entry:
         # copies: the graphs of all modules share one pool, and what is an OUTPUT here may be a transient of a graph that
         # was recorded earlier -- whose next replay (the previous block's backward) comes before autograd has consumed
         # this gradient (a projected bank's: at the very end of the backward pass)
-        return [None if g is None else g.clone() for g in self.gin]
+        return [None if g is None else g.clone() for g in self.gin] if self.pooled else self.gin
 
     def eager_backward(self, dyn, gouts):
         """The way back without the graphs (their buffers moved on since this call's forward): recompute from the

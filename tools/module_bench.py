@@ -195,10 +195,18 @@ def cfg3():
                 gstep[0] = GraphedTrainingStep(stack_fn, [hidden.clone().requires_grad_(True)], [torch.ones_like(hidden)],
                                                [p for l in layers for p in l.parameters()])
             gstep[0]([hidden], [torch.ones_like(hidden)])
+        def train_plain():
+            from mmfs_amd import graphed
+            graphed.enabled = False
+            try:
+                train()
+            finally:
+                graphed.enabled = True
         cases = [("forward", fwd, False), ("forward, shared normalisation + batched value projection", lambda: fwd_sched(False), False),
                  ("forward, projected bank kept across calls (decode / generation)", lambda: fwd_sched(True), False),
                  ("forward, projected bank kept, HIP-graph replay", lambda: graphed(hidden), False),      # (replays what the line above runs)
-                 ("forward+backward", train, True),
+                 ("forward+backward, every launch issued by the host (mmfs_amd.graphed.enabled = False: rounds 1-4)", train_plain, True),
+                 ("forward+backward (round 5 default: a layer's call replays two HIP graphs from its third identical call on)", train, True),
                  ("forward+backward, shared normalisation + batched value projection, residual handed to the layer", train_sched, True),
                  ("forward+backward, whole step replayed as ONE HIP graph", train_graphed, True)]
         for label, fn, bwd in cases:
@@ -264,7 +272,17 @@ def cfg4():
         m, rr = net_t(mid.clone().requires_grad_(True), r, feats, mask)
         (m.float().sum() + sum(x.float().sum() for x in rr)).backward()
 
-    cases.append(("training step (forward + backward, gradient checkpointing; bank projected once for all blocks: round 4 default)", train_step,
+    def train_step_plain():
+        from mmfs_amd import graphed
+        graphed.enabled = False
+        try:
+            train_step()
+        finally:
+            graphed.enabled = True
+    cases.append(("training step, every launch issued by the host (gradient checkpointing; bank projected once; mmfs_amd.graphed.enabled = False: round 4's default)",
+                  train_step_plain, 3 * (flops + flops_proj) + flops + flops_proj, True))
+    cases.append(("training step (forward + backward, gradient checkpointing; bank projected once for all blocks; round 5 default: every block's "
+                  "checkpointed call replays two HIP graphs from its third identical call on)", train_step,
                   3 * (flops + flops_proj) + flops + flops_proj, True))
 
     def train_step_r3():
