@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 11  /* 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
+#define MMFS_MSDA_ABI_VERSION 12  /* 12: + mmfs_env_reload / mmfs_env_knob (the environment knobs are one table, read once); 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
                                    *     heads of 128 channels with one chunk of samples per query -- the north-star shape); every
                                    *     matrix-core forward returns the reference's Inf / NaN element for element (a non-finite sum
                                    *     is recomputed channel by channel)
@@ -540,6 +540,16 @@ int mmfs_linear_small(int dtype, const void *x, const void *weight, const void *
  * rounded to the storage type, THEN added and rounded again: the bits of the framework's two kernels. */
 int mmfs_linear_small_add(int dtype, const void *x, const void *weight, const void *bias, const void *residual, void *y,
                           int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldr, void *stream);
+
+/* ---- the library's environment knobs (csrc/msda_env.h) --------------------------------------------------------------------
+ * Every MMFS_* variable the library reads is a tuning / test hook (which formulation runs, how a launch is cut; none changes a
+ * result).  They are ONE table, read once at the first use; no launch path calls getenv().  (The reference has no counterpart:
+ * its extension reads no environment, ops/src/vision.cpp:14-15.)
+ *   mmfs_env_reload: read the environment again (a test that flips a knob inside one process says so).
+ *   mmfs_env_knob:   entry ``index`` of the table (0 ... until MMFS_E_DIMS): its name, one line of documentation, and the value
+ *                    the library holds for it (NULL: unset).  Any of the three pointers may be NULL. */
+void mmfs_env_reload(void);
+int mmfs_env_knob(int index, const char **name, const char **doc, const char **value);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 11
+_ABI_VERSION = 12
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -84,6 +84,11 @@ _lib.mmfs_msda_backward_hybrid.argtypes = [_int] + [_vp] * 12 + [_i64] * 8 + [ct
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
+_lib.mmfs_env_reload.restype = None
+_lib.mmfs_env_reload.argtypes = []
+_lib.mmfs_env_knob.restype = _int
+_lib.mmfs_env_knob.argtypes = [_int] + [ctypes.POINTER(ctypes.c_char_p)] * 3
+
 if _lib.mmfs_msda_abi_version() != _ABI_VERSION:
     raise ImportError(f"{_LIB_PATH}: ABI version {_lib.mmfs_msda_abi_version()} != {_ABI_VERSION}")
 
@@ -93,6 +98,23 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.floa
 
 def library_path():
     return _LIB_PATH
+
+
+def reload_env():
+    """The library reads its ``MMFS_*`` tuning / test knobs ONCE (csrc/msda_env.h); a process that changes one afterwards
+    (the tests do, to hold every formulation to the oracle) says so here.  Also drops what this module derived from them."""
+    _lib.mmfs_env_reload()
+    _ws_cache.clear()
+
+
+def env_knobs():
+    """[(name, documentation, value or None)] -- the library's whole table of environment knobs."""
+    out, i = [], 0
+    name, doc, val = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_char_p()
+    while _lib.mmfs_env_knob(i, ctypes.byref(name), ctypes.byref(doc), ctypes.byref(val)) == 0:
+        out.append((name.value.decode(), doc.value.decode(), None if val.value is None else val.value.decode()))
+        i += 1
+    return out
 
 
 def build_info():

@@ -10,6 +10,7 @@
 // instructions (two exact 16-bit products + fp32 accumulate per lane and instruction: no unpacking), one butterfly per
 // (row, token) at the end, bias added in fp32, ONE rounding to the storage type -- what the library's epilogue does.
 #include "../../include/mmfs_msda.h"
+#include "msda_env.h"
 #include "msda_device.h"
 #include "msda_dots.h"
 #include <cstdlib>
@@ -125,11 +126,11 @@ int mmfs_linear_small_add(int dtype, const void *x, const void *weight, const vo
     if (ldx < K || ldy < N || (residual && ldr < N)) return MMFS_E_DIMS;
     if (((uintptr_t)x | (uintptr_t)weight) % 16 || (ldx * 2) % 16) return MMFS_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    static const int env_rows = getenv("MMFS_LIN_ROWS") ? atoi(getenv("MMFS_LIN_ROWS")) : 0;
-    static const int env_unroll = getenv("MMFS_LIN_UNROLL") ? atoi(getenv("MMFS_LIN_UNROLL")) : 0;
+    const int env_rows = mmfs::knob_int(mmfs::K_LIN_ROWS, 0);
+    const int env_unroll = mmfs::knob_int(mmfs::K_LIN_UNROLL, 0);
     const int rows = env_rows == 1 || env_rows == 2 ? env_rows : 1;             // (r03bv: 1 row per wave, 8 pieces in flight)
     const int unroll = env_unroll == 4 || env_unroll == 8 ? env_unroll : 8;
-    static const int early = getenv("MMFS_LIN_EARLY") ? atoi(getenv("MMFS_LIN_EARLY")) : 1;               // tuning
+    const int early = mmfs::knob_int(mmfs::K_LIN_EARLY, 1);               // tuning
     const int per_wg = (kLinThreads / 64) * rows;
     const dim3 grid((unsigned)((N + per_wg - 1) / per_wg));
     const int mt = M <= 4 ? 4 : 8;

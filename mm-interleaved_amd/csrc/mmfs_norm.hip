@@ -14,6 +14,7 @@
 // the gain's gradient is summed per lane over the wave's rows, over the workgroup's waves in LDS, and leaves as
 // one fp32 atomic per column and workgroup.
 #include "../../include/mmfs_msda.h"
+#include "msda_env.h"
 #include "msda_device.h"
 #include <cstdlib>
 #include <algorithm>
@@ -258,7 +259,7 @@ static int rmsnorm_backward_impl(int dtype, const void *grad_y, const void *x, c
 int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const void *weight, const float *rstd,
                           void *grad_x, float *grad_weight_f32, int64_t rows, int64_t C, void *stream)
 {
-    static const int env_grid = getenv("MMFS_NORM_BWD_GRID") ? atoi(getenv("MMFS_NORM_BWD_GRID")) : 0;      // tuning
+    const int env_grid = mmfs::knob_int(mmfs::K_NORM_BWD_GRID, 0);      // tuning
     // (few workgroups: the atomics on the gain gradient are what this entry point spends its time on)
     const int grid = std::min(mmfs::norm_grid(rows), env_grid > 0 ? env_grid : 128);
     return rmsnorm_backward_impl(dtype, grad_y, x, weight, rstd, grad_x, grad_weight_f32, rows, C, grid, 0, stream);
@@ -266,7 +267,7 @@ int mmfs_rmsnorm_backward(int dtype, const void *grad_y, const void *x, const vo
 
 int mmfs_rmsnorm_backward_partials_rows(int64_t rows)
 {
-    static const int env_grid = getenv("MMFS_NORM_BWD_GRID") ? atoi(getenv("MMFS_NORM_BWD_GRID")) : 0;      // tuning
+    const int env_grid = mmfs::knob_int(mmfs::K_NORM_BWD_GRID, 0);      // tuning
     return rows <= 0 ? 0 : std::min(mmfs::norm_grid(rows), env_grid > 0 ? env_grid : 512);
 }
 

@@ -21,6 +21,7 @@
 // queries and keeps the gradient of the lane's table row in registers (the relative position of
 // an image changes at most once per image along the sequence), flushing it with a few float atomics.
 #include "../../include/mmfs_msda.h"
+#include "msda_env.h"
 #include "msda_device.h"
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -719,7 +720,7 @@ mmfs_sample_decode(const T *__restrict__ value, const int64_t *__restrict__ shap
 // lane groups that share a query's samples: 1 = mmfs_sample_fwd (sums in sample order, bit-identical to plan + op)
 int sample_groups(int64_t Lq, int64_t K, int64_t nL, int lpi)
 {
-    const char *e = getenv("MMFS_SAMPLE_DECODE");           // (read per call: the tests hold both kernels to the same goldens)
+    const char *e = mmfs::knob_str(mmfs::K_SAMPLE_DECODE);   // (the tests hold both kernels to the same goldens)
     if ((e && e[0] == '0') || Lq > kDecodeMaxQ || K > kDecodeMaxK || nL > 64 || lpi > 32) return 1;
     return 64 / lpi;
 }

@@ -16,6 +16,7 @@
 //   * ``tokens_add``: the way back, y[b, c, p] = round(tok[b, p, c] + res[b, c, p]) through the same tile.
 // Bytes-bound: each reads its input once and writes its output once.
 #include "../../include/mmfs_msda.h"
+#include "msda_env.h"
 #include "msda_device.h"
 #include <cstdlib>
 
@@ -207,7 +208,7 @@ tokens_add(const T *__restrict__ tok, const T *__restrict__ res, T *__restrict__
 // per CU: the loops are latency-bound per workgroup; 32 pixels at 320 channels, 16 at 640, 8 at 1280); MMFS_QUERY_LDS_KB: tuning
 int query_tile_shift(int64_t C, int64_t HW)
 {
-    static const int env_kb = getenv("MMFS_QUERY_LDS_KB") ? atoi(getenv("MMFS_QUERY_LDS_KB")) : 0;
+    const int env_kb = mmfs::knob_int(mmfs::K_QUERY_LDS_KB, 0);
     const int64_t budget = (int64_t)(env_kb > 0 ? env_kb : 25) * 1024;
     const int64_t pitch = (C + 63) / 64 * 64 + kQueryPad;
     int sh = 3;

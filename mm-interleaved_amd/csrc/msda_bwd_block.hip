@@ -21,6 +21,7 @@
 // Reference semantics as in msda_bwd_value.hip (ms_deform_im2col_cuda.cuh:128-155, cast at the end:
 // ms_deform_attn_cuda.cu:122-165).
 #include "msda_device.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include "msda_bwd_block.h"
 #include "msda_plan.h"
@@ -970,7 +971,7 @@ TileParams make_params(const Dims &d)
     // are too few (b, h, level) slices to give half the CUs a workgroup (measured at the north-star shape,
     // 256 slices: 1 tile per level 65 us, 2: 71, 3: 77, 4: 91, 6: 140)
     int64_t nt = std::max<int64_t>(1, (128 + slices - 1) / slices);
-    if (const char *e = getenv("MMFS_NT_MIN")) nt = std::max(1, atoi(e));
+    if (const char *e = knob_str(K_NT_MIN)) nt = std::max(1, atoi(e));
     tp.nt_min = (int)std::min<int64_t>(nt, 256);
     // cells per level <= 2 * pixels + 2; tiles per level <= 2 * nt_l + 1
     const int64_t cells = 2LL * d.S + 2LL * d.L;
@@ -990,10 +991,10 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
     const uint32_t floor_bytes = kMaxTileCells * 4;
     int64_t want = (int64_t)d.Nq * d.P * (compact ? 8 : 16);
     if (tp.nt_min > 1) want = want / tp.nt_min + want / tp.nt_min / 4;
-    if (const char *e = getenv("MMFS_SORT_WINDOW_KB")) want = std::min<int64_t>(atoll(e) * 1024, kMaxSortWindow);
+    if (const char *e = knob_str(K_SORT_WINDOW_KB)) want = std::min<int64_t>(atoll(e) * 1024, kMaxSortWindow);
     // more records than the largest window: placed window by window while that takes few rounds (the SD block's
     // 32768 samples per level: two), else the direct path (MMFS_SORT_ROUNDS=0: always the direct path)
-    static const int max_rounds = getenv("MMFS_SORT_ROUNDS") ? atoi(getenv("MMFS_SORT_ROUNDS")) : 4;
+    const int max_rounds = knob_int(K_SORT_ROUNDS, 4);
     if (want > kMaxSortWindow) return (kWindowRounds && want <= (int64_t)max_rounds * kMaxSortWindow) ? kMaxSortWindow : floor_bytes;
     return (uint32_t)std::max<int64_t>(floor_bytes, (want + 15) / 16 * 16);
 }
@@ -1010,7 +1011,7 @@ uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
 constexpr int kSmallThreads = 256, kMidThreads = 512;
 int sort_lanes(const Dims &d, int vgroups, int nv)
 {
-    const char *e = getenv("MMFS_SORT_SMALL");                 // (read per call: the tests hold the variants to the oracle)
+    const char *e = knob_str(K_SORT_SMALL);                    // (the tests hold the variants to the oracle)
     if ((e && e[0] == '0') || nv <= 0 || vgroups != 1 || (int64_t)d.B * d.H * d.L < 512) return kThreads;
     const int64_t samples = (int64_t)d.Nq * d.P;
     if (samples <= 2048 && d.Nq <= kSmallThreads * kScanUnroll) return kSmallThreads;
@@ -1026,7 +1027,7 @@ KeptCfg kept_config(int es, const Dims &d, const TileParams &tp, bool compact)
     if (loc_bytes % 16 != 0) return c;
     const int vpq = loc_bytes / 16;
     if (vpq <= 2) { c.nv = vpq; return c; }
-    const char *e = getenv("MMFS_SORT_MANY_POINTS");
+    const char *e = knob_str(K_SORT_MANY_POINTS);
     if ((e && e[0] == '0') || sort_window_bytes(d, tp, compact) <= kMaxTileCells * 4u) return c;
     if ((int64_t)d.Nq * vpq <= kThreads * kScanUnroll) { c.nv = 1; c.g = vpq; }
     else if (vpq % 2 == 0 && (int64_t)d.Nq * (vpq / 2) <= kThreads * kScanUnroll) { c.nv = 2; c.g = vpq / 2; }
@@ -1179,7 +1180,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     // share lines in pairs): their workgroups on one XCD -- north star: the sort fetched 66 MB for 25 MB of loc + attn,
     // 37.9 -> 34.6 us (profiles/r03_experiments.md r03ay).  Pairs of heads (SD / LLM geometry, 64 bytes of attn per
     // head) measured slower than head h on XCD h % 8: 147 -> 154 us.  MMFS_SORT_HGROUP: tuning
-    static const int env_hg = getenv("MMFS_SORT_HGROUP") ? atoi(getenv("MMFS_SORT_HGROUP")) : -1;
+    const int env_hg = knob_int(K_SORT_HGROUP, -1);
     int hgroup = env_hg >= 0 ? std::min(env_hg, 4) : ((int64_t)d.L * d.P * (int64_t)sizeof(T) <= 32 ? 4 : 1);
     while (hgroup > 1 && d.H % hgroup) --hgroup;
     tp.hgroup = std::max(hgroup, 1);
@@ -1279,7 +1280,7 @@ bool bwd_value_block_supported(int dtype, const Dims &d)
     const int lps = d.D / vec;
     if (lps < 4 || lps > 32) return false;
     if (2LL * d.S + 2LL * d.L > 0x3fffffffLL) return false;
-    if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'p') return false;     // "pixel"
+    if (const char *e = knob_str(K_VALUE_ALGO)) if (e[0] == 'p') return false;       // "pixel"
     const TileParams tp = make_params(d);
     return (int64_t)d.B * d.H * tp.tiles_bound <= 0x7fffffffLL;
 }
@@ -1326,7 +1327,7 @@ hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *
         pa = plan_args(shapes, start, sc, d, tp);
         // the sort can read loc / attn where they are (the header tells it): no re-pack
         const bool aligned = (uintptr_t)loc % 16 == 0 && (uintptr_t)attn % 8 == 0;
-        const char *e = getenv("MMFS_SORT_REPACK");
+        const char *e = knob_str(K_SORT_REPACK);
         if (aligned && sort_keeps_samples(dtype, d, tp) && !(e && e[0] == '1')) {
             pa.loc_src = loc; pa.attn_src = attn;
             total_l = total_a = 0;
@@ -1343,7 +1344,7 @@ hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *
 bool value_prepare_job(int dtype, const void *loc, const void *attn, const int64_t *shapes, const int64_t *start,
                        void *workspace, const Dims &d, blk::PrepareJob *job)
 {
-    const char *off = getenv("MMFS_PREPARE_IN_TAPS");                // "0": always its own launch (read per call: tests)
+    const char *off = knob_str(K_PREPARE_IN_TAPS);                   // "0": always its own launch
     if (off && off[0] == '0') return false;
     if (!bwd_value_tiled_supported(dtype, d) || !bwd_value_block_supported(dtype, d) || !shapes || !start) return false;
     const TileParams tp = make_params(d);
@@ -1351,7 +1352,7 @@ bool value_prepare_job(int dtype, const void *loc, const void *attn, const int64
     job->pa = plan_args(shapes, start, sc, d, tp);
     job->cursor = sc.cursor; job->cursor_words = sc.cursor_bytes / 4;
     const bool aligned = (uintptr_t)loc % 16 == 0 && (uintptr_t)attn % 8 == 0;
-    const char *e = getenv("MMFS_SORT_REPACK");
+    const char *e = knob_str(K_SORT_REPACK);
     if (!aligned || !sort_keeps_samples(dtype, d, tp) || (e && e[0] == '1')) return false;
     job->pa.loc_src = loc; job->pa.attn_src = attn;
     return true;

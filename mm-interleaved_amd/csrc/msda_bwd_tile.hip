@@ -39,6 +39,7 @@
 // grad_out element reaches all 16 pixels of the blocks its sample touches (0 * Inf = NaN), not only
 // the sample's four corners.  Finite inputs: same products, fp32 sums in a different order.
 #include "msda_bwd_block.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include <cstdlib>
 #include <type_traits>
@@ -503,7 +504,7 @@ bool tile_reduce_supported(int dtype, const Dims &d)
     if (dtype != 1 && dtype != 2) return false;
     if (d.D != 32 && d.D != 64 && d.D != 128) return false;
     if (d.L > kMaxLevels) return false;
-    if (const char *e = getenv("MMFS_VALUE_ALGO")) if (e[0] == 'b' || e[0] == 'p') return false;     // "block", "pixel"
+    if (const char *e = knob_str(K_VALUE_ALGO)) if (e[0] == 'b' || e[0] == 'p') return false;       // "block", "pixel"
     // queue entries carry (b, h) and the block in 32 bits each; grid = B*H*blocks (+ queue) workgroups
     if ((int64_t)d.B * d.H * ((int64_t)d.S / 4 + d.L + 1 + 2 * ((int64_t)d.Nq * d.L * d.P * 25 / 16 / tile_chunk(d)) + 16) > 0x7fffffffLL) return false;
     // the rows are fetched through a buffer descriptor over one (b, h) slice: 31-bit byte offsets

@@ -37,6 +37,7 @@
 // reference API) by a one-thread kernel into a table; the host only supplies an upper bound on
 // the tile count.
 #include "msda_device.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include <type_traits>
 #include <cstdlib>
@@ -480,7 +481,7 @@ TileParams make_params(const Dims &d)
     // when there are few (b, h, level) slices: aim at ~2 workgroups per CU (256 CUs; measured best at the north-star shape).
     const int64_t slices = (int64_t)d.B * d.H * std::max(1, d.L);
     int64_t nt = std::max<int64_t>(1, (512 + slices - 1) / slices);
-    if (const char *e = getenv("MMFS_NT_MIN")) nt = std::max(1, atoi(e));      // tuning knob
+    if (const char *e = knob_str(K_NT_MIN)) nt = std::max(1, atoi(e));         // tuning knob
     tp.nt_min = (int)std::min<int64_t>(nt, 256);
     // tiles per level <= 2*nt_l + 1 with nt_l <= nt_min + px_l/kMaxTilePx + 1 (see plan_tile)
     const int64_t bound = 2LL * d.L * (tp.nt_min + 1) + 2LL * ((d.S + kMaxTilePx - 1) / kMaxTilePx) + d.L;

@@ -2,6 +2,7 @@
 // Validates arguments, narrows the dims to the kernels' 32-bit index range and
 // forwards to the kernel launchers.  No state, no allocation.
 #include "../../include/mmfs_msda.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include "msda_gv_mma.h"
 #include "msda_plan.h"
@@ -374,7 +375,7 @@ static mmfs::gv::Table value_blocks_plan(int dtype, const mmfs::Dims &d, const i
 {
     // opt-in (MMFS_BWD_VALUE_LDS_BLOCKS, or MMFS_GV_ALGO=on in the environment): measured slower than the sorted path on
     // every shipped geometry (profiles/r03_experiments.md, r03m-r03o)
-    static const char *algo = getenv("MMFS_GV_ALGO");
+    const char *algo = mmfs::knob_str(mmfs::K_GV_ALGO);
     const bool env_on = algo && algo[0] == 'o' && algo[1] == 'n';
     if ((flags & MMFS_BWD_VALUE_SORTED_ONLY) || !((flags & MMFS_BWD_VALUE_LDS_BLOCKS) || env_on)) {
         mmfs::gv::Table t;

@@ -22,6 +22,7 @@
 // times to place 1024 non-zeros -- and were removed in round 2, when grad_value moved to the
 // matrix cores by another route: csrc/msda_bwd_tile.hip.)
 #include "msda_device.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include "msda_plan.h"
 #include <cstring>
@@ -326,7 +327,7 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
     if (d.D != 32 && d.D != 64 && d.D != 128) return p;
     if (d.L <= 0 || d.L > kMaxSelLevels || d.P <= 0 || d.P > 16 || d.Nq < 32) return p;
     if ((int64_t)d.Nq * d.H * d.D * 2 > kMaxSlabBytes) return p;           // grad_out rows by 32-bit offsets
-    if (const char *e = getenv("MMFS_HYBRID")) if (atoi(e) == 0) return p;
+    if (const char *e = knob_str(K_HYBRID)) if (atoi(e) == 0) return p;
 
     // ---- grad_loc / grad_attn by dense dot products.  Per 64 queries a level costs px * D / 31.8
     // MFMA clocks (1017 FLOP/clk/SIMD) against 8 * P * D clocks of row reads (64 B/clk/CU): on
@@ -347,7 +348,7 @@ HybridPlan make_hybrid_plan(int dtype, const Dims &d, const int64_t *host_shapes
             // Measured (MI355X): a chunk step costs ~4k clocks per 64 queries, 4x its
             // MFMA time, so only single-chunk levels (<= 256 pixels) beat their row reads; 32x32 levels
             // in 5 chunks ran 1.6x slower than gathering them.  MMFS_DOT_CHUNKS=1 re-enables them.
-            static const bool multi = getenv("MMFS_DOT_CHUNKS") && atoi(getenv("MMFS_DOT_CHUNKS")) > 0;
+            const bool multi = knob_int(K_DOT_CHUNKS, 0) > 0;
             if (chunks > 1 && !multi) dense = false;
         }
         if (!dense) { p.fine_taps.idx[nft++] = (uint8_t)l; continue; }

@@ -39,6 +39,7 @@
 //
 // fp32 storage, other head widths, L > 64 and small query counts stay on msda_fwd_vec (msda_fwd.hip).
 #include "msda_mma_common.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include <cstdlib>
 
@@ -405,11 +406,11 @@ static hipError_t launch_mma(const void *value, const int64_t *shapes, const int
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_mma<T, D>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     if (once != hipSuccess) return once;
-    static const int env_kb = getenv("MMFS_FWD_MMA_LDS_KB") ? atoi(getenv("MMFS_FWD_MMA_LDS_KB")) : 0;      // tuning / debugging
+    const int env_kb = knob_int(K_FWD_MMA_LDS_KB, 0);      // tuning / debugging
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(G::IMG0 + 1024, env_kb * 1024)) : kLdsTotal;
     // queries per workgroup: the image fill (up to IMG_BUDGET bytes through the texture path) is paid per workgroup,
     // so runs are long; but the grid should still be a few workgroups per CU for the tail
-    static const int env_q = getenv("MMFS_FWD_MMA_QPW") ? atoi(getenv("MMFS_FWD_MMA_QPW")) : 0;
+    const int env_q = knob_int(K_FWD_MMA_QPW, 0);
     const int unit = kMmaWaves * G::QPW;
     const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
@@ -433,7 +434,7 @@ bool fwd_mma_supported(int dtype, const Dims &d)
 
 bool fwd_mma_applies(int dtype, const Dims &d)
 {
-    static const char *algo = getenv("MMFS_FWD_ALGO");                 // "vec": never; "mma": whenever the shape allows
+    const char *algo = knob_str(K_FWD_ALGO);                           // "vec": never; "mma": whenever the shape allows
     if (algo && algo[0] == 'v') return false;
     if (!fwd_mma_supported(dtype, d)) return false;
     if (algo && algo[0] == 'm') return true;

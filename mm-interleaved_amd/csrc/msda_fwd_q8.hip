@@ -41,6 +41,7 @@
 //
 // fp32 storage, head widths that are not multiples of 32, L > 64: msda_fwd_vec (msda_fwd.hip).
 #include "msda_mma_common.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include <cstdlib>
 #include <type_traits>
@@ -598,7 +599,7 @@ static hipError_t launch_q8(const void *value, const int64_t *shapes, const int6
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_q8<T>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     if (once != hipSuccess) return once;
-    static const int env_kb = getenv("MMFS_FWD_Q8_LDS_KB") ? atoi(getenv("MMFS_FWD_Q8_LDS_KB")) : 0;      // tuning / tests
+    const int env_kb = knob_int(K_FWD_Q8_LDS_KB, 0);      // tuning / tests
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(kImg0 + 1024, env_kb * 1024)) : kLdsTotal;
     // Queries per run: the image fill (one pass over the resident levels' slices + the barrier around it: 14-19 k clocks
     // per wave, a quarter of a 512-query run at the LLM geometry, r04f) is paid per run, so runs are as long as the shape
@@ -615,7 +616,7 @@ static hipError_t launch_q8(const void *value, const int64_t *shapes, const int6
     int q_per_run = q8_all_resident_likely(d) ? 1024 : 512;
     const int64_t units = (int64_t)d.B * d.H * n_slices;
     while (q_per_run > unit && units * ((d.Nq + q_per_run - 1) / q_per_run) < cus) q_per_run -= unit;
-    static const int env_q = getenv("MMFS_FWD_Q8_QPR") ? atoi(getenv("MMFS_FWD_Q8_QPR")) : 0;
+    const int env_q = knob_int(K_FWD_Q8_QPR, 0);
     if (env_q > 0) q_per_run = env_q;
     q_per_run = std::max(unit, (q_per_run + unit - 1) / unit * unit);
     d.q_tiles = (d.Nq + q_per_run - 1) / q_per_run;
@@ -639,7 +640,7 @@ bool fwd_q8_supported(int dtype, const Dims &d)
 
 bool fwd_q8_applies(int dtype, const Dims &d)
 {
-    static const char *algo = getenv("MMFS_FWD_ALGO");                 // "q8": whenever the shape allows
+    const char *algo = knob_str(K_FWD_ALGO);                           // "q8": whenever the shape allows
     if (!fwd_q8_supported(dtype, d)) return false;
     if (algo && algo[0] == 'q') return true;
     if (algo) return false;

@@ -41,6 +41,7 @@
 //
 // fp32 storage, other head widths, L > 64: the other formulations (msda_fwd.hip routes).
 #include "msda_mma_common.h"
+#include "msda_env.h"
 #include "msda_launch.h"
 #include <cstdlib>
 #include <type_traits>
@@ -537,9 +538,9 @@ static hipError_t launch_wq(const void *value, const int64_t *shapes, const int6
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     if (once1 != hipSuccess) return once1;
     if (once2 != hipSuccess) return once2;
-    static const int env_kb = getenv("MMFS_FWD_WQ_LDS_KB") ? atoi(getenv("MMFS_FWD_WQ_LDS_KB")) : 0;       // tuning / tests
+    const int env_kb = knob_int(K_FWD_WQ_LDS_KB, 0);       // tuning / tests
     const int lds_total = env_kb > 0 ? std::min(kLdsTotal, std::max(G::IMG0 + 1024, env_kb * 1024)) : kLdsTotal;
-    static const int env_q = getenv("MMFS_FWD_WQ_QPW") ? atoi(getenv("MMFS_FWD_WQ_QPW")) : 0;
+    const int env_q = knob_int(K_FWD_WQ_QPW, 0);
     const int unit = kMmaWaves * wq::kGroup;
     const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
@@ -568,7 +569,7 @@ bool fwd_wq_supported(int dtype, const Dims &d)
 
 bool fwd_wq_applies(int dtype, const Dims &d)
 {
-    static const char *algo = getenv("MMFS_FWD_ALGO");                 // "wq": whenever the shape allows
+    const char *algo = knob_str(K_FWD_ALGO);                           // "wq": whenever the shape allows
     if (algo && algo[0] != 'w') return false;
     if (!fwd_wq_supported(dtype, d)) return false;
     if (algo && algo[0] == 'w') return true;

@@ -25,6 +25,7 @@
 // Semantics inherited from the matrix-core formulation (as msda_bwd_tile.hip): a non-finite grad_out element
 // reaches all 16 pixels of the blocks its sample touches; samples of zero attention weight are not visited.
 #include "msda_gv_mma.h"
+#include "msda_env.h"
 #include "msda_mma_common.h"
 #include "msda_launch.h"
 #include <algorithm>
@@ -429,11 +430,6 @@ msda_gv_mma(const T *__restrict__ grad_out, const T *__restrict__ loc, const T *
     GPROF_FLUSH();
 }
 
-int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
 
 bool shape_supported(int dtype, const Dims &d)
 {
@@ -480,7 +476,7 @@ Table make_plan(int dtype, const Dims &d, const int64_t *hs, const int64_t *hst)
     Table t;
     memset(&t, 0, sizeof(t));
     if (!hs || !hst || !shape_supported(dtype, d)) return t;
-    if (d.Nq < env_int("MMFS_GV_MIN_NQ", 256)) return t;
+    if (d.Nq < knob_int(K_GV_MIN_NQ, 256)) return t;
     const int VB = d.D >= 128 ? Geom<128>::VB : Geom<64>::VB;
     const int RB = d.D * 2;
     struct Cand { int l, nb; };
@@ -499,10 +495,10 @@ Table make_plan(int dtype, const Dims &d, const int64_t *hs, const int64_t *hst)
     if ((int)cand.size() > kMaxLevels) cand.resize(kMaxLevels);
     if (cand.empty()) return t;
     const int64_t slabs = (int64_t)d.B * d.H;
-    const double unit = (double)cand.size() * (double)slabs / (double)env_int("MMFS_GV_TARGET_WGS", 512);   // levels per workgroup
+    const double unit = (double)cand.size() * (double)slabs / (double)knob_int(K_GV_TARGET_WGS, 512);   // levels per workgroup
     // groups of levels, smallest first: as many levels as the virtual blocks allow while a chunk still holds 64 queries
     // (the chunk's rows, barriers and prefix are shared by the levels of a group); MMFS_GV_MAX_SEGS=1: a level per group
-    const int max_segs = std::max(1, std::min(kMaxSegs, env_int("MMFS_GV_MAX_SEGS", kMaxSegs)));
+    const int max_segs = std::max(1, std::min(kMaxSegs, knob_int(K_GV_MAX_SEGS, kMaxSegs)));
     struct Tmp { std::vector<int> ci; int nb; };
     std::vector<Tmp> groups;
     for (int i = 0; i < (int)cand.size(); ++i) {

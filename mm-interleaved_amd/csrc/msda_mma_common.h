@@ -9,6 +9,7 @@
 //   * wave-level synchronisation for wave-private LDS records.
 #pragma once
 #include "msda_device.h"
+#include "msda_env.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -166,9 +167,8 @@ __device__ __forceinline__ void exact_lane8(const int *tab, __amdgpu_buffer_rsrc
 // MMFS_MMA_GRID=n: n workgroups whatever the shape (tuning); MMFS_MMA_PERSIST=0: always one workgroup per run.
 inline int64_t persistent_grid(int64_t runs, int H)
 {
-    // (read per call: the tests compare the deals inside one process)
-    const char *eg = getenv("MMFS_MMA_GRID"), *ep = getenv("MMFS_MMA_PERSIST");
-    const int env_grid = eg ? atoi(eg) : 0, env_persist = ep ? atoi(ep) : 1;
+    // (the tests compare the deals inside one process: mmfs_env_reload)
+    const int env_grid = knob_int(K_MMA_GRID, 0), env_persist = knob_int(K_MMA_PERSIST, 1);
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;

@@ -24,6 +24,7 @@
 // fp32 storage, other head widths, L > 64, small query counts: msda_bwd_vec (+ msda_taps_coarse when the caller
 // brings a host copy of the level table).
 #include "msda_dots.h"
+#include "msda_env.h"
 #include "msda_mma_common.h"
 #include "msda_plan.h"
 #include <cstring>
@@ -385,7 +386,7 @@ static hipError_t launch_taps_mma(const void *value, const int64_t *shapes, cons
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_taps_mma<T, D>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     if (once != hipSuccess) return once;
-    static const int env_q = getenv("MMFS_TAPS_MMA_QPW") ? atoi(getenv("MMFS_TAPS_MMA_QPW")) : 0;
+    const int env_q = knob_int(K_TAPS_MMA_QPW, 0);
     const int unit = kMmaWaves * G::QPW;
     const int q_per_wg = pick_queries_per_run(d, unit, env_q);       // (256, or shorter runs for few queries: msda_mma_common.h)
     d.q_tiles = (d.Nq + q_per_wg - 1) / q_per_wg;
@@ -409,7 +410,7 @@ bool taps_mma_supported(int dtype, const Dims &d)
 
 bool taps_mma_applies(int dtype, const Dims &d)
 {
-    static const char *algo = getenv("MMFS_TAPS_ALGO");                // "vec": never; "mma": whenever the shape allows
+    const char *algo = knob_str(K_TAPS_ALGO);                          // "vec": never; "mma": whenever the shape allows
     if (d.taps_algo == 1 || (d.taps_algo == 0 && algo && algo[0] == 'v')) return false;
     if (!taps_mma_supported(dtype, d)) return false;
     if (d.taps_algo == 2 || (algo && algo[0] == 'm')) return true;

@@ -36,6 +36,36 @@ def _ensure_library():
 _ensure_library()
 
 
+def _reload_library_env():
+    """The library reads its ``MMFS_*`` knobs once (csrc/msda_env.h): a test that changes one says so -- here, for all of
+    them: ``monkeypatch.setenv`` / ``delenv`` of such a name, and every ``undo``, are followed by a re-read."""
+    shim = sys.modules.get("MultiScaleDeformableAttention")
+    if shim is not None and hasattr(shim, "reload_env"):
+        shim.reload_env()
+
+
+def _follow(name):
+    orig = getattr(pytest.MonkeyPatch, name)
+
+    def method(self, *args, **kwargs):
+        res = orig(self, *args, **kwargs)
+        if name == "undo" or (args and str(args[0]).startswith("MMFS_")):
+            _reload_library_env()
+        return res
+    method.__name__ = name
+    setattr(pytest.MonkeyPatch, name, method)
+
+
+for _name in ("setenv", "delenv", "undo"):
+    _follow(_name)
+
+
+@pytest.fixture(autouse=True)
+def _library_env_as_the_environment_is():
+    _reload_library_env()
+    yield
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
 

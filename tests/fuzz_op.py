@@ -99,7 +99,7 @@ def one_case(rng, idx):
     MSDA._fwd_algo = rng.choice(["auto", "auto", "slices", "slices", "gather", "lds"])
     if WAVES:
         MSDA._fwd_algo = "waves"
-    MSDA._ws_cache.clear()
+    MSDA.reload_env()                        # (the library reads its knobs once: csrc/msda_env.h)
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
     desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
             f"value={algo} bwd={MSDA._bwd_algo} fwd={MSDA._fwd_algo}")

@@ -57,6 +57,8 @@ def one_case(rng, idx):
     # order: equal within the storage type's rounding); with MMFS_SAMPLE_DECODE=0 they stay on the in-order kernel
     from mmfs_amd.functions.mmfs_plan_func import sample_forward_groups
     os.environ["MMFS_SAMPLE_DECODE"] = rng.choice(["0", "1"])
+    import MultiScaleDeformableAttention as _msda
+    _msda.reload_env()                       # (the library reads its knobs once: csrc/msda_env.h)
     in_order = sample_forward_groups(dtype, Lq, D, n * L, P) <= 1
     desc += f" decode_kernel={not in_order}"
     outs = {}

@@ -183,3 +183,46 @@ def test_sample_forward_argument_errors_return_before_any_launch():
     assert f(2, *null, *(dims[:4] + [24] + dims[5:]), None) == -5       # D = 24: no 16-byte vector rows
     assert f(2, *null, *dims, None) == -3                               # NULL tensors
     assert f(2, *null, *([0] + dims[1:]), None) == 0                    # empty batch
+
+
+def test_environment_knobs_are_one_table():
+    """Every ``MMFS_*`` variable the library reads is an entry of csrc/msda_env.hip's table (read once; ``mmfs_env_reload``
+    reads it again) -- no kernel launcher calls getenv() -- and INTEGRATION.md names each of them."""
+    import glob
+    csrc = os.path.join(os.path.dirname(HEADER), "..", "mm-interleaved_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        if os.path.basename(path) == "msda_env.hip":
+            continue
+        text = open(path).read()
+        assert "getenv(" not in text, path
+    lib = ctypes.CDLL(LIB)
+    lib.mmfs_env_knob.restype = ctypes.c_int
+    lib.mmfs_env_knob.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_char_p)] * 3
+    lib.mmfs_env_reload.restype = None
+    names, i = [], 0
+    name, doc, val = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_char_p()
+    while lib.mmfs_env_knob(i, ctypes.byref(name), ctypes.byref(doc), ctypes.byref(val)) == 0:
+        assert name.value.startswith(b"MMFS_") and len(doc.value) > 10
+        names.append(name.value.decode())
+        i += 1
+    assert len(names) == len(set(names)) >= 30
+    integration = open(os.path.join(os.path.dirname(HEADER), "..", "INTEGRATION.md")).read()
+    for n in names:
+        assert n in integration, n
+    # the table follows the environment only when told to
+    probe = "MMFS_NORM_BWD_GRID"
+    k = names.index(probe)
+    old = os.environ.get(probe)
+    try:
+        os.environ[probe] = "77"
+        lib.mmfs_env_knob(k, None, None, ctypes.byref(val))
+        assert val.value != b"77"
+        lib.mmfs_env_reload()
+        lib.mmfs_env_knob(k, None, None, ctypes.byref(val))
+        assert val.value == b"77"
+    finally:
+        if old is None:
+            os.environ.pop(probe, None)
+        else:
+            os.environ[probe] = old
+        lib.mmfs_env_reload()

@@ -21,13 +21,13 @@ def _fuzz():
 @pytest.fixture
 def restore_knobs():
     import MultiScaleDeformableAttention as MSDA
-    keep = (MSDA._hybrid, MSDA._bwd_algo, os.environ.get("MMFS_VALUE_ALGO"), MSDA._fwd_algo)
+    keep = (MSDA._hybrid, MSDA._bwd_algo, {k: v for k, v in os.environ.items() if k.startswith("MMFS_")}, MSDA._fwd_algo)
     yield
     MSDA._hybrid, MSDA._bwd_algo, MSDA._fwd_algo = keep[0], keep[1], keep[3]
-    if keep[2] is None:
-        os.environ.pop("MMFS_VALUE_ALGO", None)
-    else:
-        os.environ["MMFS_VALUE_ALGO"] = keep[2]
+    for k in [k for k in os.environ if k.startswith("MMFS_")]:      # (every knob the fuzzer set)
+        del os.environ[k]
+    os.environ.update(keep[2])
+    MSDA.reload_env()
 
 
 @pytest.mark.gpu
