@@ -26,7 +26,8 @@ WHOLE step, which needs the caller to restructure its loop.  This module does it
     key) does not replay at all: it recomputes eagerly from the caller's tensors -- slower, never wrong.
   * a capture that fails (an op that synchronises, an allocation refused) marks the key as refused: eager from then on.
 
-Not used (the caller's plain path runs): CPU tensors, inside another capture, under autocast / inference mode / an active
+Not used (the caller's plain path runs): CPU tensors, inside another capture, under saved-tensor hooks (a non-reentrant
+checkpoint AROUND the caller, activation offloading), under autocast / inference mode / an active
 ``TorchDispatchMode`` or the shim's launch-event log (someone is counting ops: let them see the ops),
 ``mmfs_amd.graphed.enabled = False``.
 """
@@ -342,6 +343,11 @@ def _eligible(args):
     if first is None or torch.is_autocast_enabled() or torch.is_inference_mode_enabled():
         return None
     if MSDA._event_log is not None:                    # (someone brackets every launch with events: bench.py's kernel pass)
+        return None
+    # someone intercepts what autograd saves (a NON-reentrant checkpoint around the caller, activation offloading): the
+    # plain path, in the forward and in the recomputation alike -- they count and match the saved tensors of the two
+    hooks = getattr(torch._C._autograd, "_top_saved_tensors_default_hooks", None)
+    if hooks is not None and hooks(True) is not None:
         return None
     depth = getattr(torch._C, "_len_torch_dispatch_stack", None)
     if (depth is not None and depth() > 0) or torch.cuda.is_current_stream_capturing():

@@ -266,3 +266,51 @@ def test_a_changed_switch_is_another_key():
         assert graphed.stats["replays"] == r + 2
     finally:
         graphed.enabled = True
+
+
+@pytest.mark.parametrize("reentrant", [True, False])
+def test_llama_layer_inside_the_decoders_checkpoint(reentrant):
+    """What the reference's decoder does with every layer in training (modeling_llama_mmfs.py:700-717:
+    ``torch.utils.checkpoint.checkpoint(custom_forward, hidden, vision, mask, ...)``, the reentrant flavour by default): the
+    MMFS layer is first called WITHOUT autograd, then again with it from inside the backward pass -- where its graphs are
+    also recorded, on the autograd engine's thread.  Five steps against the same stack with the graphs off."""
+    import torch.utils.checkpoint as cp
+    from mmfs_amd import graphed
+    layer = llama_layer(torch.float32)
+    twin = copy.deepcopy(layer)
+    twin.graph_training_calls = False
+    B, Lq, n, hw = 2, 33, 2, 64 + 16 + 4
+    g = torch.Generator().manual_seed(2)
+    hidden = torch.randn(B, Lq, 512, generator=g).to(DEV)
+    feats = torch.randn(B, n, hw, 128, generator=g).to(DEV)
+    mask = torch.ones(B, Lq, n, device=DEV)
+    go = torch.randn(B, Lq, 512, generator=g).to(DEV)
+    dense = torch.nn.Linear(512, 512).to(DEV)              # (a stand-in for the decoder layer's own sub-layers)
+
+    def step(m, scale):
+        m.zero_grad(set_to_none=True)
+        dense.zero_grad(set_to_none=True)
+        x = (hidden * scale).requires_grad_(True)
+        f = feats.clone().requires_grad_(True)
+
+        def decoder_layer(h, v, c):
+            h = h + dense(h)
+            return m(h, v, c, residual=h)
+        y = cp.checkpoint(decoder_layer, x, f, mask, use_reentrant=reentrant)
+        y.backward(go)
+        return [y.detach(), x.grad, f.grad, dense.weight.grad.clone()] + [p.grad for p in m.parameters() if p.grad is not None]
+
+    before = dict(graphed.stats)
+    for i in range(5):
+        got = step(layer, 0.5 + 0.25 * i)
+    want = step(twin, 1.5)
+    if reentrant:
+        assert graphed.stats["captures"] > before["captures"] and graphed.stats["replays"] > before["replays"], graphed.stats
+    else:
+        # a non-reentrant checkpoint around the layer matches the tensors saved by its forward and by its recomputation
+        # one by one: the layer stays on the plain path in both
+        assert graphed.stats["replays"] == before["replays"]
+    assert graphed.stats["refused"] == before["refused"]
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
