@@ -32,6 +32,7 @@ checkpoint AROUND the caller, activation offloading), under autocast / inference
 ``mmfs_amd.graphed.enabled = False``.
 """
 import gc
+import threading
 import weakref
 
 import torch
@@ -52,6 +53,7 @@ trace = None                 # a callable(str): debugging aid
 _pools = {}                  # device index -> (graph memory pool shared by the recompute-mode graphs, the entries recorded into it)
 _stages = {}                 # (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument
 stats = {"captures": 0, "replays": 0, "eager_backward": 0, "refused": 0}
+_recording = threading.Lock()        # one capture at a time in the process (a caller's threads; the autograd engine's thread)
 
 
 class _Static:
@@ -114,6 +116,7 @@ def _hashable(a):
 
 class _Table(dict):
     """A module's recorded calls.  Lives in the module's ``__dict__``; a copy or a pickle of the module starts empty."""
+    epoch = None
 
     def __deepcopy__(self, memo):
         return _Table()
@@ -342,6 +345,8 @@ def _eligible(args):
                 first = a
     if first is None or torch.is_autocast_enabled() or torch.is_inference_mode_enabled():
         return None
+    if first.device.index != torch.cuda.current_device():       # (a capture records on the current device's stream)
+        return None
     if MSDA._event_log is not None:                    # (someone brackets every launch with events: bench.py's kernel pass)
         return None
     # someone intercepts what autograd saves (a NON-reentrant checkpoint around the caller, activation offloading): the
@@ -392,6 +397,11 @@ def graphed_call(owner, fn, args, recompute):
     table = owner.__dict__.get("_graphed")
     if table is None:
         table = owner.__dict__["_graphed"] = _Table()
+    if table.epoch != key[3]:
+        # the package's cache epoch moved (a mode change, a state-dict load): no key of before can come back -- drop
+        # what was recorded under it with its buffers
+        table.clear()
+        table.epoch = key[3]
     e = table.get(key)
     if e is None:
         e = table[key] = _Entry(key)
@@ -400,7 +410,7 @@ def graphed_call(owner, fn, args, recompute):
                 del table[k]
     e.seen += 1
     owner.__dict__["_graphed_tick"] = e.tick = owner.__dict__.get("_graphed_tick", 0) + 1
-    if e.state == 0 and e.seen > capture_after:
+    if e.state == 0 and e.seen > capture_after and _recording.acquire(blocking=False):
         need = grad and (any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
                          or any(p.requires_grad for p in owner.parameters()))
         # (no garbage collection while a stream records: a dead module's graphs destroyed in the middle of a capture
@@ -423,6 +433,7 @@ def graphed_call(owner, fn, args, recompute):
             _t("refused: " + e.error[:500])
             _reset_generator(args[e.dyn_pos[0]].device if getattr(e, "dyn_pos", None) else torch.device("cuda"))
         finally:
+            _recording.release()
             if collecting:
                 gc.enable()
     if e.state != 1:

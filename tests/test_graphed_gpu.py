@@ -266,6 +266,13 @@ def test_a_changed_switch_is_another_key():
         assert graphed.stats["replays"] == r + 2
     finally:
         graphed.enabled = True
+    # a mode change moves the package's cache epoch: what was recorded under the old one is dropped with its buffers,
+    # the calls count again and are recorded again
+    blk.eval(); blk.train()
+    call(s)
+    assert graphed.stats["replays"] == r + 2 and len(blk.__dict__["_graphed"]) == 1
+    call(s); call(s)
+    assert graphed.stats["captures"] - before["captures"] == 2 and graphed.stats["replays"] == r + 4
 
 
 @pytest.mark.parametrize("reentrant", [True, False])
