@@ -113,14 +113,12 @@ class LlamaMMFSAttention(CacheInvalidation, nn.Module):
         ``image_ranks`` (another): ``LlamaMMFSSchedule.image_ranks(cross_attention_mask, Lq)``, made once per step.
         ``residual`` (a third) [B, Lq, hidden]: the result is ``residual + layer(...)`` -- the decoder layer's own next
         statement (modeling_llama_mmfs.py:700-717), which without gradients rides in the output projection's kernel."""
+        args = (hidden_states, vision_hidden_states, cross_attention_mask, value, image_ranks, residual)
         if self.graph_training_calls and self.training:
             # a training step's call as HIP graphs once its shapes have been seen a few times (mmfs_amd/graphed.py) -- the
             # forward with its saved activations, the backward; and the no-grad forward of a checkpointing caller
-            res = graphed_call(self, self._forward, (hidden_states, vision_hidden_states, cross_attention_mask, value,
-                                                     image_ranks, residual), recompute=False)
-            if res is not NotImplemented:
-                return res
-        return self._forward(hidden_states, vision_hidden_states, cross_attention_mask, value, image_ranks, residual)
+            return graphed_call(self, self._forward, args, recompute=False, plain=lambda: self._forward(*args))
+        return self._forward(*args)
 
     def _forward(self, hidden_states, vision_hidden_states, cross_attention_mask, value, image_ranks, residual):
         hidden_states = self.norm1(hidden_states)

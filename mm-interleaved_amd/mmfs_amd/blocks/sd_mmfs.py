@@ -262,13 +262,13 @@ class MMFSBlock(CacheInvalidation, nn.Module):
             # (``residual`` is an input the caller holds anyway -- for ``MMFSNet`` the sample itself)
             # (no random numbers inside: nothing of the generator's state to save -- which would also be a host round
             # trip that a HIP-graph capture of the step refuses)
+            def plain():
+                return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
+                                     normed, use_reentrant=False, preserve_rng_state=False)
             if self.graph_checkpoints:
-                res = graphed_call(self, self._inner, (sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
-                                                       residual, normed), recompute=True)
-                if res is not NotImplemented:
-                    return res
-            return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
-                                 normed, use_reentrant=False, preserve_rng_state=False)
+                return graphed_call(self, self._inner, (sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
+                                                        residual, normed), recompute=True, plain=plain)
+            return plain()
         return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual, normed)
 
 

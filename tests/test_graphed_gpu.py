@@ -321,3 +321,27 @@ def test_llama_layer_inside_the_decoders_checkpoint(reentrant):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_a_device_bound_call_is_not_replayed():
+    """``graphed_call`` knows the host time of the plain path (it runs it) and times the recorded forward on an idle device:
+    a call whose kernels outlast their launches gives its graphs back and stays on the plain path (``device_bound_ratio``;
+    forced here -- at these sizes every call is bound by the host)."""
+    from mmfs_amd import graphed
+    layer = llama_layer(torch.float32)
+    hidden = torch.randn(2, 33, 512, device=DEV)
+    feats = torch.randn(2, 2, 84, 128, device=DEV)
+    mask = torch.ones(2, 33, 2, device=DEV)
+    before = dict(graphed.stats)
+    graphed.device_bound_ratio = 0.0
+    try:
+        for _ in range(5):
+            x = hidden.clone().requires_grad_(True)
+            layer(x, feats, mask, residual=x).sum().backward()
+    finally:
+        graphed.device_bound_ratio = 1.0
+    assert graphed.stats["device_bound"] - before["device_bound"] == 1
+    assert graphed.stats["captures"] == before["captures"] and graphed.stats["replays"] == before["replays"]
+    assert graphed.stats["refused"] == before["refused"]
+    entry, = layer.__dict__["_graphed"].values()
+    assert entry.state == -2 and not hasattr(entry, "fwd")
