@@ -23,6 +23,7 @@
 // reference's "accumulate in fp32, cast at the end" (ms_deform_attn_cuda.cu:122-165).
 // For the atomics the lanes of a query switch to an interleaved channel map
 // (channel = j*LPI + lane) so one atomic instruction covers LPI consecutive floats.
+#include <algorithm>
 #include "msda_device.h"
 #include "msda_dots.h"
 #include "msda_launch.h"
@@ -397,6 +398,29 @@ hipError_t backward_taps(int dtype, const void *value, const int64_t *shapes, co
                 return launch_scalar<double>(value, shapes, start, loc, attn, grad_out, gv, gl, ga, d, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+namespace {
+__global__ void __launch_bounds__(256) zero_fill_kernel(unsigned char *__restrict__ p, size_t head, size_t vecs, size_t tail)
+{
+    // [head bytes][vecs x 16 bytes][tail bytes]: the body starts on a 16-byte boundary
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+    if (i < head) p[i] = 0;
+    uint4 *body = reinterpret_cast<uint4 *>(p + head);
+    for (size_t k = i; k < vecs; k += n) body[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < tail) p[head + vecs * 16 + i] = 0;
+}
+}  // namespace
+
+hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    unsigned char *p = static_cast<unsigned char *>(ptr);
+    const size_t head = std::min<size_t>(bytes, (16 - ((uintptr_t)p & 15)) & 15);
+    const size_t vecs = (bytes - head) / 16, tail = bytes - head - vecs * 16;
+    const size_t blocks = std::min<size_t>(std::max<size_t>(1, (vecs + 255) / 256), 256 * 16);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, head, vecs, tail);
+    return hipGetLastError();
 }
 
 hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st)

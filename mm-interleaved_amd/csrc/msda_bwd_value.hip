@@ -605,7 +605,7 @@ hipError_t backward_value_prepare(int dtype, const void *loc, const void *attn, 
     }
     const int es = dtype == 0 ? 4 : 2;
     const Scratch sc = carve(workspace, dtype, d);
-    hipError_t e = hipMemsetAsync(sc.cursor, 0, (size_t)sc.cursor_bytes, st);
+    hipError_t e = mmfs::zero_fill(sc.cursor, (size_t)sc.cursor_bytes, st);
     if (e != hipSuccess) return e;
     e = repack(loc, sc.loc_t, d, d.P * 2 * es, st);
     if (e != hipSuccess) return e;

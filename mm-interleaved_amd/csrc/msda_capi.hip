@@ -96,7 +96,7 @@ int mmfs_msda_forward_flags(int dtype, const void *value, const int64_t *shapes,
     if (n_out == 0) return MMFS_OK;
     if (!out) return MMFS_E_NULLPTR;
     if (d.K == 0 || S == 0)                          // nothing to sample: the op's value is 0
-        return (int)hipMemsetAsync(out, 0, (size_t)n_out * es, st);
+        return (int)mmfs::zero_fill(out, (size_t)n_out * es, st);
     if (!value || !shapes || !start || !loc || !attn) return MMFS_E_NULLPTR;
     // the vector kernels move 16-byte channel vectors; rows are D*es apart, so the
     // bases must be 16-byte aligned whenever D*es is a multiple of 16
@@ -181,11 +181,11 @@ int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shap
     if (n_value && !grad_value) return MMFS_E_NULLPTR;
     if (n_samples == 0 || S == 0 || D == 0) {           // nothing flows: all gradients are zero
         hipError_t e = hipSuccess;
-        if (n_value) e = hipMemsetAsync(grad_value, 0, (size_t)n_value * es, st);
+        if (n_value) e = mmfs::zero_fill(grad_value, (size_t)n_value * es, st);
         if (e == hipSuccess && n_samples) {
             if (!grad_loc || !grad_attn) return MMFS_E_NULLPTR;
-            e = hipMemsetAsync(grad_loc, 0, (size_t)n_samples * 2 * es, st);
-            if (e == hipSuccess) e = hipMemsetAsync(grad_attn, 0, (size_t)n_samples * es, st);
+            e = mmfs::zero_fill(grad_loc, (size_t)n_samples * 2 * es, st);
+            if (e == hipSuccess) e = mmfs::zero_fill(grad_attn, (size_t)n_samples * es, st);
         }
         return (int)e;
     }
@@ -233,7 +233,7 @@ int mmfs_msda_backward_checked(int dtype, const void *value, const int64_t *shap
         acc = workspace;
         acc_bytes = (size_t)n_value * 4;
     }
-    hipError_t e = hipMemsetAsync(acc, 0, acc_bytes, st);              // reference: at::zeros, .cu:127
+    hipError_t e = mmfs::zero_fill(acc, acc_bytes, st);              // reference: at::zeros, .cu:127
     if (e != hipSuccess) return (int)e;
     e = mmfs::backward_taps(dtype, value, shapes, start, loc, attn, grad_out, acc, grad_loc, grad_attn,
                             d, true, st);
@@ -279,7 +279,7 @@ int mmfs_msda_backward_value(int dtype, const int64_t *shapes, const int64_t *st
     if (n_value == 0) return MMFS_OK;
     if (!grad_value) return MMFS_E_NULLPTR;
     if (B * Nq * H * L * P == 0)
-        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
+        return (int)mmfs::zero_fill(grad_value, (size_t)n_value * es, (hipStream_t)stream);
     if (!mmfs::bwd_value_tiled_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
     if (!shapes || !start || !loc || !attn || !grad_out) return MMFS_E_NULLPTR;
     if (misaligned(grad_out, 16) || misaligned(grad_value, 16) || misaligned(loc, es) || misaligned(attn, es))
@@ -346,7 +346,7 @@ int mmfs_msda_backward_value_reduce(int dtype, const void *grad_out, void *grad_
     const int64_t n_value = B * S * H * D;
     if (n_value > 0 && !grad_value) return MMFS_E_NULLPTR;
     if (n_value > 0 && B * Nq * H * L * P == 0)
-        return (int)hipMemsetAsync(grad_value, 0, (size_t)n_value * es, (hipStream_t)stream);
+        return (int)mmfs::zero_fill(grad_value, (size_t)n_value * es, (hipStream_t)stream);
     mmfs::Dims d;
     const int rc = value_stage_args(dtype, B, S, H, D, L, Nq, P, workspace, workspace_bytes, &d);
     if (rc <= 0) return rc;

@@ -458,7 +458,7 @@ hipError_t launch(const void *go, const void *loc, const void *attn, void *gv, f
     lds = std::max(lds, kCtrl + kWaves * 16 * D * 4);                          // the epilogue's tiles
     if (lds > kLds) return hipErrorInvalidValue;
     if (parts) {
-        const hipError_t e = hipMemsetAsync(arrive, 0, (size_t)d.B * d.H * kMaxGroups * sizeof(uint32_t), st);
+        const hipError_t e = mmfs::zero_fill(arrive, (size_t)d.B * d.H * kMaxGroups * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
     }
     const int64_t grid = (int64_t)d.B * d.H * t.wgs_per_slab;

@@ -107,6 +107,11 @@ hipError_t backward_taps_coarse(int dtype, const void *value, const void *loc, c
                                 const HybridPlan &p, hipStream_t st, const blk::PrepareJob *job = nullptr);   // job: as backward_taps_mma
 
 hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t st);
+// ``bytes`` zero bytes at ``p`` as a KERNEL in stream order.  Not hipMemsetAsync: recorded into a HIP graph that becomes
+// a memset node, and on replay the counters a memset node was to clear were seen uncleared by the kernel node behind
+// it (round 5, r05g36-37: msda_bwd_value_sort found 0xc4281000 in its level cursor and wrote its records 26 GB past
+// the workspace -- one replay in a few dozen, only the first run on a fresh device).  A kernel orders like a kernel.
+hipError_t zero_fill(void *p, size_t bytes, hipStream_t st);
 
 // grad_value for a level table the device-side check of the sorted backward refused (its plan's verdict is read on the
 // device from the workspace; nothing happens for a table it served): the reference's float-atomic scatter.
