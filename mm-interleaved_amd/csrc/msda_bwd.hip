@@ -292,6 +292,15 @@ msda_bwd_scalar(const T *__restrict__ value, const int64_t *__restrict__ shapes,
     }
 }
 
+// dst = src, one float per thread and trip (the fp32 "cast": a copy -- as a kernel, not hipMemcpyAsync: recorded into a HIP
+// graph that is a memcpy node, and nodes of that family do not order like kernels there, see zero_fill)
+__global__ void __launch_bounds__(kThreads)
+copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, const int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // dst = (T) src, 4 elements per thread
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
@@ -428,7 +437,8 @@ hipError_t cast_from_f32(int dtype, const float *src, void *dst, int64_t n, hipS
     if (n <= 0) return hipSuccess;
     const int64_t blocks = std::min<int64_t>((n / 4 + kThreads) / kThreads, 256 * 16);
     switch (dtype) {
-        case 0: return hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
+        case 0: hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)std::min<int64_t>((n + kThreads - 1) / kThreads, 256 * 16)), dim3(kThreads), 0, st,
+                                   src, (float *)dst, n); break;
         case 1: hipLaunchKernelGGL((cast_kernel<half_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, src, (half_t *)dst, n); break;
         case 2: hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, src, (bf16_t *)dst, n); break;
         default: return hipErrorInvalidValue;

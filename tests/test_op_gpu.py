@@ -1213,3 +1213,21 @@ def test_forward_formulations_take_locations_that_start_on_an_odd_element(algo):
     assert torch.equal(a, b)
     want = msda_oracle.forward(x["value"], x["shapes"], x["start"], x["loc"], x["attn"])
     assert max_abs(a.double().cpu().numpy(), want) <= TOL[torch.bfloat16]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,code", [(torch.float32, 0), (torch.float16, 1), (torch.bfloat16, 2)])
+def test_cast_from_f32_entry_point(dtype, code):
+    """``mmfs_msda_cast_from_f32`` (the float-atomic path's closing pass, ms_deform_attn_cuda.cu:156-165): fp32 -> storage type,
+    any length, bit for bit the framework's rounding; for fp32 storage a copy -- issued as a kernel, like every clear and copy
+    on a launch path since round 5 (a memset / memcpy NODE of a recorded graph does not order like a kernel: DESIGN 4.8c)."""
+    import ctypes
+    import MultiScaleDeformableAttention as MSDA
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 4096, 100003):
+        src = (torch.randn(n, generator=g) * 37.0).to("cuda")
+        dst = torch.full((n + 5,), 123.0, device="cuda", dtype=dtype)
+        rc = MSDA._lib.mmfs_msda_cast_from_f32(code, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), n,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        assert torch.equal(dst[:n], src.to(dtype)) and bool((dst[n:] == 123.0).all())
