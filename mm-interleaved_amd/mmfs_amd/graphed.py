@@ -372,6 +372,8 @@ def _eligible(args):
                 first = a
     if first is None or torch.is_autocast_enabled() or torch.is_inference_mode_enabled():
         return None
+    if torch.compiler.is_compiling():                  # (a tracing compiler wants the operations, not a replay)
+        return None
     if first.device.index != torch.cuda.current_device():       # (a capture records on the current device's stream)
         return None
     if MSDA._event_log is not None:                    # (someone brackets every launch with events: bench.py's kernel pass)
