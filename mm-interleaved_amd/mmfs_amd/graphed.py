@@ -139,7 +139,12 @@ class _Entry:
         self.host_s = float("inf")                                      # host time of the plain path's forward (least seen)
 
     def drop(self, state):
+        """Gives the graphs and their buffers back (refused, device-bound); the shared pool no longer counts this entry
+        among its holders."""
         self.state = state
+        holders = self.__dict__.pop("holders", None)
+        if holders is not None:
+            holders.discard(self)
         for name in ("fwd", "bwd", "out", "gout", "gin", "static"):
             self.__dict__.pop(name, None)
 
@@ -264,6 +269,7 @@ class _Entry:
             _t("backward recorded")
         if holders is not None:
             holders.add(self)
+            self.holders = holders
         self.state = 1
         stats["captures"] += 1
 
