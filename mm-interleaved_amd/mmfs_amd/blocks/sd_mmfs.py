@@ -19,7 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
-from ..graphed import graphed_call
+from ..graphed import graphed_call, memory_is_plentiful
 from ..functions.linear_func import _split_k, token_linear
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
 from ..levels import CacheInvalidation, cache_epoch, hook_free, make_level_tables, tensor_version
@@ -134,6 +134,12 @@ class MMFSBlock(CacheInvalidation, nn.Module):
     # seen a few times (mmfs_amd/graphed.py): the eager training step of the unchanged trainer is bound by the host
     # otherwise (4 075 launches per step at BASELINE config 4).  False: ``torch.utils.checkpoint`` always.
     graph_checkpoints = True
+    # ... and when the device has memory to spare, the recorded forward KEEPS its activations (in the graph's own pool) and
+    # the second graph is the backward alone: no recomputation.  Checkpointing exists to save memory -- the 13 blocks'
+    # activations at BASELINE config 4 are ~2 GB of a 288 GB device -- and costs a third of the step's kernels.  "auto":
+    # while at least half of the device's memory is free (``mmfs_amd.graphed.memory_is_plentiful``); False: the recorded
+    # call recomputes like the checkpoint it replaces; True: always keeps.  Same gradients bit for bit either way.
+    graph_keeps_activations = "auto"
     _behaviour_flags = ("layout_kernels_in_training", "fold_conv", "gradient_checkpointing")      # (part of a recorded call's key)
 
     def __init__(self, attn_dim=1024, query_dim=320, feat_dim=1024, num_heads=16, n_points=8,
@@ -266,8 +272,11 @@ class MMFSBlock(CacheInvalidation, nn.Module):
                 return cp.checkpoint(self._inner, sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual,
                                      normed, use_reentrant=False, preserve_rng_state=False)
             if self.graph_checkpoints:
+                keep = self.graph_keeps_activations
+                if keep == "auto":
+                    keep = sample.is_cuda and memory_is_plentiful(sample.device)
                 return graphed_call(self, self._inner, (sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
-                                                        residual, normed), recompute=True, plain=plain)
+                                                        residual, normed), recompute=not keep, plain=plain)
             return plain()
         return self._inner(sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks, residual, normed)
 

@@ -54,6 +54,7 @@ capture_after = 2            # eager calls with a key before it is recorded
 max_entries = 4              # recorded keys per module (least recently used goes first)
 stage_bytes = 4 << 20        # read-only tensor arguments at least this large share ONE static copy across modules
 device_bound_ratio = 1.0     # a recorded forward that runs longer on the device than this x its plain path's host time is dropped
+plentiful_fraction = 0.5     # "memory is plentiful" = this much of the device's memory is free (memory_is_plentiful)
 share_pool = True            # the recompute-mode graphs of all modules record into one memory pool (their transients overlap)
 capture_error_mode = "thread_local"
 trace = None                 # a callable(str): debugging aid
@@ -417,6 +418,20 @@ def _key(owner, args, recompute, grad):
         for f in getattr(type(m), "_behaviour_flags", ()):
             parts.append(_hashable(getattr(m, f, None)))
     return tuple(parts)
+
+
+_plenty = {}                 # device index -> (when asked, answer)
+
+
+def memory_is_plentiful(dev):
+    """Whether at least ``plentiful_fraction`` of the device's memory is free (asked of the driver at most once a second):
+    what a checkpointed block's ``graph_keeps_activations = "auto"`` goes by."""
+    now = time.monotonic()
+    hit = _plenty.get(dev.index)
+    if hit is None or now - hit[0] > 1.0:
+        free, total = torch.cuda.mem_get_info(dev)
+        hit = _plenty[dev.index] = (now, free >= plentiful_fraction * total)
+    return hit[1]
 
 
 def graphed_call(owner, fn, args, recompute, plain):

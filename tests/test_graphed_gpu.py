@@ -54,8 +54,9 @@ def net_step(net, z, dtype=torch.float32, scale=1.0):
     return new_mid, new_res, mid_t, res_t, feats_t
 
 
+@pytest.mark.parametrize("keep", [False, True], ids=["recompute", "keep"])
 @pytest.mark.parametrize("once", [True, False])
-def test_replayed_training_step_matches_the_reference(once):
+def test_replayed_training_step_matches_the_reference(once, keep):
     """The fixture's reference training step (checkpointing on) through ``MMFSNet`` five times: from the third step on every
     block's forward and its recompute + backward are graph replays -- and the fifth step still returns the reference's output
     and the reference's gradient for every input and each of the 119 parameters."""
@@ -63,6 +64,8 @@ def test_replayed_training_step_matches_the_reference(once):
     z = load_golden("block_sd_mmfs_net")
     net = small_net(z)
     net.project_once_in_training = once
+    for blk in net._blocks():                  # the recorded call recomputes like the checkpoint / keeps its activations
+        blk.graph_keeps_activations = keep
     before = dict(graphed.stats)
     for step in range(5):
         net.zero_grad(set_to_none=True)
@@ -118,9 +121,11 @@ def test_replays_follow_new_inputs_and_accumulate_gradients(dtype, tol):
         assert float((x.float() - y.float()).norm() / y.float().norm().clamp_min(1e-6)) <= tol, k
 
 
-def test_two_forwards_before_the_first_backward():
+@pytest.mark.parametrize("keep", [False, True], ids=["recompute", "keep"])
+def test_two_forwards_before_the_first_backward(keep):
     """A block called twice before either backward runs (two losses on one net): the second forward overwrites the first
-    call's static inputs; its backward copies the caller's tensors in again (checkpoint mode needs nothing else)."""
+    call's static inputs.  A recorded call that recomputes copies the caller's tensors in again and replays; one that keeps
+    its activations has lost the first call's and recomputes that backward eagerly."""
     from mmfs_amd import graphed
     from mmfs_amd.blocks import MMFSBlock
     z = load_golden("block_sd_mmfs_block")
@@ -130,6 +135,7 @@ def test_two_forwards_before_the_first_backward():
                                     base_spatial_shape=4, max_num_image_per_seq=5), z).to(DEV).train()
     with torch.no_grad():
         blk.conv.weight.normal_(0, 0.3)
+    blk.graph_keeps_activations = keep
     twin = copy.deepcopy(blk)
     twin.graph_checkpoints = False
     shapes, mask, go = [(8, 8), (4, 4), (2, 2)], T(z["ms_mask"], None), T(z["grad_out"], torch.float32)
@@ -150,7 +156,7 @@ def test_two_forwards_before_the_first_backward():
         got = pair(blk)
     want = pair(twin)
     assert graphed.stats["captures"] - before["captures"] == 1 and graphed.stats["replays"] > before["replays"]
-    assert graphed.stats["eager_backward"] == before["eager_backward"]
+    assert graphed.stats["eager_backward"] - before["eager_backward"] == (2 if keep else 0)      # (the first call of pairs 2 and 3)
     assert len(got) == len(want)
     for x, y in zip(got, want):
         assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))

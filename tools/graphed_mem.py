@@ -1,6 +1,7 @@
 """BASELINE config 4's training step (13 blocks at 512 px, B = 8, bf16, gradient checkpointing) through the per-block graphs:
 step time and device memory with the graphs' transients in ONE pool (default) or one pool per recorded call.
-usage: python tools/graphed_mem.py [shared|private|off]"""
+usage: python tools/graphed_mem.py [shared|private|off|recompute]   (recompute: the recorded calls recompute like the checkpoints
+they replace instead of keeping their activations)"""
 import contextlib, io, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd")]
@@ -9,7 +10,10 @@ from mmfs_amd import graphed
 from mmfs_amd.blocks import MMFSNet
 mode = sys.argv[1] if len(sys.argv) > 1 else "shared"
 graphed.enabled = mode != "off"
-graphed.share_pool = mode == "shared"
+graphed.share_pool = mode != "private"
+from mmfs_amd.blocks.sd_mmfs import MMFSBlock
+if mode in ("recompute", "private"):
+    MMFSBlock.graph_keeps_activations = False
 dev, dt, B, n = "cuda", torch.bfloat16, 8, 1
 with contextlib.redirect_stdout(io.StringIO()):
     net = MMFSNet(input_channel=1024, block_out_channels=[320, 640, 1280, 1280], layers_per_block=2,
