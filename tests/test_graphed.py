@@ -53,3 +53,20 @@ def test_a_copied_or_pickled_module_starts_without_recorded_calls():
         assert isinstance(twin.__dict__["_graphed"], graphed._Table) and len(twin.__dict__["_graphed"]) == 0
         assert twin.__dict__["_graphed"].epoch is None
     assert len(table) == 1
+
+
+def test_memory_is_plentiful_asks_the_driver_at_most_once_a_second(monkeypatch):
+    """``MMFSBlock.graph_keeps_activations = "auto"`` goes by ``memory_is_plentiful``: at least ``plentiful_fraction`` of the
+    device's memory free, asked of the driver once and remembered for a second."""
+    calls = []
+
+    def mem_get_info(dev):
+        calls.append(dev)
+        return (60 << 30, 100 << 30) if len(calls) == 1 else (10 << 30, 100 << 30)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", mem_get_info)
+    graphed._plenty.clear()
+    dev = torch.device("cuda", 0)
+    assert graphed.memory_is_plentiful(dev) and graphed.memory_is_plentiful(dev) and len(calls) == 1
+    graphed._plenty[0] = (graphed._plenty[0][0] - 2.0, True)          # (a second later)
+    assert not graphed.memory_is_plentiful(dev) and len(calls) == 2
+    graphed._plenty.clear()
