@@ -43,7 +43,11 @@ import time
 import weakref
 
 import torch
-from torch.nn.utils import stateless
+
+try:                                                   # (the mechanism of torch.func.functional_call; without it: no graphs)
+    from torch.nn.utils.stateless import _reparametrize_module as _reparametrize
+except Exception:                                      # pragma: no cover
+    _reparametrize = None
 
 import MultiScaleDeformableAttention as MSDA
 
@@ -289,7 +293,7 @@ class _Entry:
         with torch.enable_grad():
             lv = leaves if leaves is not None else [x.detach().requires_grad_(rq) for x, rq in zip(ins, self.req)]
             pal = [p.detach().requires_grad_(True) for p in self.params]
-            with stateless._reparametrize_module(self.owner, dict(zip(self.names, pal))):
+            with _reparametrize(self.owner, dict(zip(self.names, pal))):
                 outs = self._outs(self.fn(*self.call_args(lv)))
         return outs, lv, pal
 
@@ -368,7 +372,7 @@ class _GraphedFn(torch.autograd.Function):
 
 
 def _eligible(args):
-    if not enabled or not torch.cuda.is_available():
+    if not enabled or _reparametrize is None or not torch.cuda.is_available():
         return None
     first = None
     for a in args:
