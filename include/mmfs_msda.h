@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define MMFS_MSDA_ABI_VERSION 12  /* 12: + mmfs_env_reload / mmfs_env_knob (the environment knobs are one table, read once); 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
+#define MMFS_MSDA_ABI_VERSION 13  /* 13: + mmfs_msda_backward_sorted (+ _workspace_bytes): the whole backward on the cell-sorted records -- grad_loc / grad_attn
+                                   *     from the records the grad_value sort makes (csrc/msda_bwd_taps_sorted.hip), no per-sample value-row gather
+                                   * 12: + mmfs_env_reload / mmfs_env_knob (the environment knobs are one table, read once); 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
                                    *     heads of 128 channels with one chunk of samples per query -- the north-star shape); every
                                    *     matrix-core forward returns the reference's Inf / NaN element for element (a non-finite sum
                                    *     is recomputed channel by channel)
@@ -359,6 +361,38 @@ int mmfs_msda_backward_hybrid(int dtype,
                               void *workspace, int64_t workspace_bytes,
                               int64_t B, int64_t S, int64_t H, int64_t D,
                               int64_t L, int64_t Nq, int64_t P,
+                              unsigned flags, unsigned stages, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The whole backward on the CELL-SORTED records (round 6; replaces ms_deform_attn_backward, vision.cpp:15,
+ * ms_deform_attn_cuda.cu:84-166, ms_deform_im2col_cuda.cuh:90-162 + 304-923, like mmfs_msda_backward).
+ * The grad_value half sorts the samples by the cell of their top-left corner anyway; a sample's four corners are the four
+ * pixels around that cell.  Here grad_loc / grad_attn are computed from the same records (csrc/msda_bwd_taps_sorted.hip):
+ * a wave per 4x4 block of cells holds the block's 5x5 value rows as one matrix-core operand and multiplies them with the
+ * records' grad_out rows -- no value row is gathered per sample (the gather kernels: 4 rows per sample through the
+ * vector-memory path).  Same results within the storage type's rounding (same products, fp32 sums in another order).
+ * Applies to MMFS_F16 / MMFS_BF16, D in {32, 64, 128}, P a power of two with Nq * P <= 65536, a level table the HOST has
+ * verified (MMFS_BWD_CANONICAL_LEVELS in ``flags``) and shapes whose sort keeps its samples in registers (Nq <= 4096 per
+ * vector group); otherwise *_workspace_bytes returns 0 and the call MMFS_E_UNSUPPORTED: use mmfs_msda_backward[_hybrid].
+ * MMFS_BWD_LAZY_ZERO_ATTN as there.  ``stages``: OR of the bits, all of them = the whole pass, in this order (each stage
+ * needs the ones before it on the same workspace, and ``loc`` / ``attn`` unchanged until the sort has run).
+ */
+#define MMFS_SRT_BWD_PREPARE  1u   /* clear the cursors, plan (level rows, tiles) */
+#define MMFS_SRT_BWD_SORT     2u   /* cell sort; also writes the zero grad_loc / grad_attn of samples that get no record */
+#define MMFS_SRT_BWD_TAPS     4u   /* grad_loc / grad_attn from the records */
+#define MMFS_SRT_BWD_REDUCE   8u   /* grad_value from the records (the matrix-core tile reduce) */
+#define MMFS_SRT_BWD_ALL     15u
+int64_t mmfs_msda_backward_sorted_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                                  int64_t L, int64_t Nq, int64_t P, unsigned flags);
+/* blocks4: the number of 4x4 pixel blocks of all levels when the caller knows the level table on the host (exact grids),
+ * else 0 (a bound is launched). */
+int mmfs_msda_backward_sorted(int dtype,
+                              const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *loc, const void *attn, const void *grad_out,
+                              void *grad_value, void *grad_loc, void *grad_attn,
+                              void *workspace, int64_t workspace_bytes,
+                              int64_t B, int64_t S, int64_t H, int64_t D,
+                              int64_t L, int64_t Nq, int64_t P, int64_t blocks4,
                               unsigned flags, unsigned stages, void *stream);
 
 /*

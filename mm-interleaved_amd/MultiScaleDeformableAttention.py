@@ -40,7 +40,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = ctypes.CDLL(_LIB_PATH)
 
-_ABI_VERSION = 12
+_ABI_VERSION = 13
 _i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
 _lib.mmfs_msda_abi_version.restype = _int
@@ -81,6 +81,10 @@ _lib.mmfs_msda_backward_hybrid_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_hybrid_workspace_bytes.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_hybrid.restype = _int
 _lib.mmfs_msda_backward_hybrid.argtypes = [_int] + [_vp] * 12 + [_i64] * 8 + [ctypes.c_uint, ctypes.c_uint, _vp]
+_lib.mmfs_msda_backward_sorted_workspace_bytes.restype = _i64
+_lib.mmfs_msda_backward_sorted_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
+_lib.mmfs_msda_backward_sorted.restype = _int
+_lib.mmfs_msda_backward_sorted.argtypes = [_int] + [_vp] * 10 + [_i64] * 9 + [ctypes.c_uint, ctypes.c_uint, _vp]
 _lib.mmfs_msda_cast_from_f32.restype = _int
 _lib.mmfs_msda_cast_from_f32.argtypes = [_int, _vp, _vp, _i64, _vp]
 
@@ -319,9 +323,13 @@ _BWD_VALUE_LDS_BLOCKS = 512
 _E_UNSUPPORTED = -5
 
 # tests / measurements: which formulation computes grad_loc / grad_attn (include/mmfs_msda.h):
-# "auto" | "gather" (csrc/msda_bwd.hip + msda_dense.hip) | "lds" (csrc/msda_taps_mma.hip; unsupported shapes raise)
+# "auto" | "gather" (csrc/msda_bwd.hip + msda_dense.hip) | "lds" (csrc/msda_taps_mma.hip; unsupported shapes raise) |
+# "sorted" (csrc/msda_bwd_taps_sorted.hip: from the grad_value sort's records -- parity-green, measured slower than the gather
+# kernels on every shipped geometry, DESIGN.md 4.2c: opt-in; arguments mmfs_msda_backward_sorted does not take raise).
+# MMFS_TAPS_ROUTE=sorted in the environment takes it wherever it applies, for a whole process (measurements).
 _taps_algo = "auto"
-_TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS}
+_taps_prefer_sorted = os.environ.get("MMFS_TAPS_ROUTE") == "sorted"      # wherever it applies, silently not elsewhere
+_TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS, "sorted": 0}
 
 # tests / measurements: which formulation computes grad_value of the small levels (include/mmfs_msda.h; only the hybrid
 # entry point -- a registered level table -- has the choice): "auto" (= sorted, unless MMFS_GV_ALGO=on) | "sorted"
@@ -377,6 +385,10 @@ class _fork:
         if self.side is not None:
             self.main.wait_stream(self.side)
 
+
+# stage bits of mmfs_msda_backward_sorted (include/mmfs_msda.h)
+_SRT_BWD_STAGES = (("msda_bwd_value_prepare", 1), ("msda_bwd_value_sort", 2), ("msda_bwd_taps", 4), ("msda_bwd_value_reduce", 8))
+_SRT_BWD_ALL = 15
 
 # stage bits of mmfs_msda_backward_hybrid (include/mmfs_msda.h)
 _HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
@@ -503,6 +515,38 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         stream = _stream(value.device)
         status = _E_UNSUPPORTED
         hyb_bytes = 0
+        # opt-in: grad_loc / grad_attn from the grad_value sort's records (csrc/msda_bwd_taps_sorted.hip): a host-verified
+        # canonical table, 16-bit storage, shapes the sort's kept scan takes
+        srt_bytes = 0
+        if (_taps_algo == "sorted" or (_taps_prefer_sorted and _taps_algo == "auto")) and _bwd_algo != "atomic" and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
+            skey = ("sorted", code, dims, flags)
+            srt_bytes = _ws_cache.get(skey)
+            if srt_bytes is None:
+                if len(_ws_cache) > 4096:
+                    _ws_cache.clear()
+                srt_bytes = _ws_cache[skey] = _lib.mmfs_msda_backward_sorted_workspace_bytes(code, *dims, flags)
+        _require(srt_bytes > 0 or _taps_algo != "sorted", "taps algo 'sorted': mmfs_msda_backward_sorted does not apply to these arguments")
+        if srt_bytes > 0:
+            ws = torch.empty(srt_bytes, dtype=torch.uint8, device=value.device)
+            hs = info[1]
+            blocks4 = int((((hs[:, 0] + 3) // 4) * ((hs[:, 1] + 3) // 4))[(hs[:, 0] > 0) & (hs[:, 1] > 0)].sum())
+            sargs = (code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                     sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                     grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr(), srt_bytes,
+                     *dims, blocks4, flags)
+            if _event_log is None:
+                status = _lib.mmfs_msda_backward_sorted(*sargs, _SRT_BWD_ALL, stream)
+            else:
+                for name, bit in _SRT_BWD_STAGES:
+                    status = _launch(name, value.device, _lib.mmfs_msda_backward_sorted, *sargs, bit, _stream(value.device))
+                    if status != 0:
+                        break
+            _check(status, "ms_deform_attn_backward")
+            if loc_dtype != dt:
+                grad_loc = grad_loc.to(loc_dtype)
+            if attn_dtype != dt:
+                grad_attn = grad_attn.to(attn_dtype)
+            return [grad_value, grad_loc, grad_attn]
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
             flags |= _BWD_DENSE_TAPS | _VALUE_FLAGS[_value_algo]
             hs, hst = info[1].ctypes.data, info[2].ctypes.data

@@ -141,6 +141,16 @@ struct TileDesc {
 };
 static_assert(sizeof(TileDesc) == 64, "one 64-byte line per block");
 struct TileItem { uint32_t bh, blk, part, pidx; };          // one extra work item (part >= 1)
+// grad_loc / grad_attn from the same cell-sorted records (msda_bwd_taps_sorted.hip): every cell -- every sample -- has ONE
+// owner block there: the block whose pixels hold the cell's own pixel (cy, cx) -> block (cy / 4, cx / 4), the last block
+// row / column also taking the border cells cy = Hl / cx = Wl.  The owned cells of a run are its first ones (a run is
+// the cells 4 bx .. 4 bx + 4 of one cell row, in that order), so a block's owned records are five prefixes of its runs.
+struct TapsDesc {
+    int ocnt[5];                          // owned records of each run (run 4: only in the last block row)
+    int level;
+    int pad[2];
+};
+static_assert(sizeof(TapsDesc) == 32, "two per 64-byte line");
 
 struct TileReduceArgs {
     const uint4 *records;                 // cell-sorted {query, y, x, attention}
@@ -155,6 +165,10 @@ struct TileReduceArgs {
     uint32_t *n_extra;                    // [B, H] queued extra items of the slice (zeroed with the cursors)
     float *tpartials;                     // [cap_partials, kTB*kTB, D]
     int blocks_bound;
+    // grad_loc / grad_attn on the sorted records (Dims::taps_sorted; else null / 0)
+    TapsDesc *xdesc;                      // [B, H, blocks_bound]
+    void *g_loc, *g_attn;                 // the op's grad_loc / grad_attn: the sort writes the zeros of samples that get no record
+    int qshift;                           // a record's low 16 bits are query * P + point: query = bits >> qshift (P = 1 << qshift)
 };
 constexpr uint32_t kVoidPart = 0xffffffffu;
 
@@ -211,7 +225,7 @@ __device__ __host__ inline int tile_local_blocks(const CTile &tl, const LevelRow
     return (by_hi - *by_lo) * lr.nbx4;
 }
 __device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTile &tl, const LevelRow &lr, int by, int bx,
-                                                        const uint32_t *off, int64_t base)
+                                                        const uint32_t *off, int64_t base, TapsDesc *xd = nullptr)
 {
     const int tw = tl.Wl + 1;
     int64_t n = 0;
@@ -219,13 +233,19 @@ __device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTil
     for (int r = 0; r <= kTB; ++r) {
         const int cy = kTB * by + r;
         td.first[r] = 0; td.cnt[r] = 0;
+        if (xd) xd->ocnt[r] = 0;
         if (cy <= lr.Hl) {
             const int p0 = (cy - tl.ya) * tw + kTB * bx, p1 = (cy - tl.ya) * tw + min(kTB * bx + kTB + 1, tw);
             td.first[r] = (int)(uint32_t)(base + off[p0]);
             td.cnt[r] = (int)(off[p1] - off[p0]);
             n += td.cnt[r];
+            if (xd && (r < kTB || by == lr.nby4 - 1)) {
+                const int q1 = bx == lr.nbx4 - 1 ? p1 : (cy - tl.ya) * tw + kTB * bx + kTB;
+                xd->ocnt[r] = (int)(off[q1] - off[p0]);
+            }
         }
     }
+    if (xd) { xd->level = tl.level; xd->pad[0] = xd->pad[1] = 0; }
     td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
     td.lstart = lr.lstart;
     td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
@@ -244,14 +264,18 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
     for (int i = tid + nthreads; i < nloc; i += nthreads) {
         const int by = by_lo + i / lr.nbx4, bx = i % lr.nbx4;
         TileDesc td;
-        const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
+        TapsDesc xd;
+        const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base, a.xdesc ? &xd : nullptr);
+        if (a.xdesc) a.xdesc[bh * a.blocks_bound + lr.bbase4 + by * lr.nbx4 + bx] = xd;
         queue_block(a, d, bh, lr.bbase4 + by * lr.nbx4 + bx, td, n);
     }
     if (tid >= nloc) return pd;
     const int by = by_lo + tid / lr.nbx4, bx = tid % lr.nbx4;
     const int blk = lr.bbase4 + by * lr.nbx4 + bx;
     TileDesc td;
-    const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base);
+    TapsDesc xd;
+    const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base, a.xdesc ? &xd : nullptr);
+    if (a.xdesc) a.xdesc[bh * a.blocks_bound + blk] = xd;
     a.tdesc[bh * a.blocks_bound + blk] = td;
     const uint32_t parts = (uint32_t)((n + tile_chunk(d) - 1) / tile_chunk(d));
     if (parts > 1) {
@@ -295,9 +319,11 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
         while (level + 1 < d.L && blk >= lv[level + 1].bbase4) ++level;
         while (level < d.L && lv[level].nbx4 * lv[level].nby4 == 0) ++level;        // (empty levels own no block)
         TileDesc td;
+        TapsDesc xd;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { td.first[r] = 0; td.cnt[r] = 0; }
+        for (int r = 0; r < 5; ++r) { td.first[r] = 0; td.cnt[r] = 0; xd.ocnt[r] = 0; }
         td.hw = 0; td.lstart = 0; td.byx = 0; td.parts = 1; td.pbase = 0; td.arrived = 0;
+        xd.level = level < d.L ? level : 0; xd.pad[0] = xd.pad[1] = 0;
         int64_t n = 0;
         if (level < d.L) {
             const LevelRow lr = lv[level];
@@ -320,16 +346,21 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
 #pragma unroll
             for (int dy = 0; dy <= kTB; ++dy) {
                 td.first[dy] = (int)ent[dy][0].x;               // (the cells of a row are one contiguous run)
-                int c = 0;
+                int c = 0, oc = 0;
 #pragma unroll
-                for (int dx = 0; dx <= kTB; ++dx) c += (int)ent[dy][dx].y;
+                for (int dx = 0; dx <= kTB; ++dx) {
+                    c += (int)ent[dy][dx].y;
+                    if (dx < kTB || bx == lr.nbx4 - 1) oc += (int)ent[dy][dx].y;
+                }
                 td.cnt[dy] = c;
+                if (dy < kTB || by == lr.nby4 - 1) xd.ocnt[dy] = oc;
                 n += c;
             }
             td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
             td.lstart = lr.lstart;
             td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
         }
+        if (a.xdesc) a.xdesc[bh * a.blocks_bound + blk] = xd;
         queue_block(a, d, bh, blk, td, n);
     }
 }
@@ -337,6 +368,8 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
 
 // 16-bit storage, D in {32, 64, 128}; MMFS_VALUE_ALGO=block keeps the vector-ALU reduce
 bool tile_reduce_supported(int dtype, const Dims &d);
+// the planned workspace as msda_bwd_taps_sorted.hip reads it (descriptors, items, records), *cap_extra: queue places per slice
+TileReduceArgs taps_sorted_args(void *workspace, int dtype, const Dims &d, uint32_t *cap_extra);
 hipError_t tile_reduce(int dtype, const void *grad_out, void *grad_value, const TileReduceArgs &a, const Dims &d,
                        uint32_t cap_extra, hipStream_t st);      // cap_extra: TileHeader::cap_extra (the host's copy)
 

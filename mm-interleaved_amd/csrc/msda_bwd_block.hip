@@ -151,11 +151,15 @@ __device__ void block_exclusive_scan(uint32_t *a, int n, uint32_t *wave_tot)
 }
 
 // The sample's cell inside the tile, or -1: outside the level, zero weight, or another tile's.
-__device__ __forceinline__ int cell_in_tile(float lx, float ly, float a, const CTile &tl, int tw)
+// keep_zero: a zero weight is no reason to drop the sample (its grad_attn is not zero: Dims::taps_sorted without lazy_attn);
+// *dead: the sample gets no record in ANY tile of its level.
+__device__ __forceinline__ int cell_in_tile(float lx, float ly, float a, const CTile &tl, int tw, bool keep_zero = false, bool *dead = nullptr)
 {
     const float y = ly * (float)tl.Hl - 0.5f, x = lx * (float)tl.Wl - 0.5f;
     const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)tl.Hl) && (x < (float)tl.Wl);
-    if (!inside || a == 0.f) return -1;
+    const bool none = !inside || (a == 0.f && !keep_zero);
+    if (dead) *dead = none;
+    if (none) return -1;
     const int cy = (int)floorf(y) + 1, cx = (int)floorf(x) + 1;
     if (cy < tl.ya || cy >= tl.yb || cx < tl.xa || cx >= tl.xb) return -1;
     return (cy - tl.ya) * tw + (cx - tl.xa);
@@ -299,12 +303,19 @@ struct KeptScan {
         }
     }
 
-    __device__ __forceinline__ void count(const Dims &d, const CTile &tl, uint32_t *off)      // (after load())
+    // Dims::taps_sorted: zero weights keep their record unless the caller never reads their gradients (lazy_attn), and the
+    // level's first tile writes the zero gradients of the samples that get no record (g_loc / g_attn: the op's grad_loc /
+    // grad_attn, [B, Nq, H, L, P(, 2)])
+    __device__ __forceinline__ void count(const Dims &d, const CTile &tl, uint32_t *off, int b = 0, int h = 0,
+                                          T *__restrict__ g_loc = nullptr, T *__restrict__ g_attn = nullptr)      // (after load())
     {
         const int tw = tl.xb - tl.xa;
+        const bool ts = d.taps_sorted != 0, keep_zero = ts && !d.lazy_attn;
+        const bool zero_writer = ts && g_loc != nullptr && tl.ya == 0 && tl.xa == 0;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const int q = (int)threadIdx.x + u * THREADS;                // (virtual query)
+            const int qq = G == 1 ? q : q / G;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float l[VEC], a[VEC];
@@ -312,8 +323,14 @@ struct KeptScan {
                 V::unpack(make_uint4(araw[u][v].x, araw[u][v].y, 0u, 0u), a);
 #pragma unroll
                 for (int i = 0; i < SPV; ++i) {
-                    const int pl = q < d.Nq * G ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw) : -1;
+                    bool dead = false;
+                    const int pl = q < d.Nq * G ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw, keep_zero, &dead) : -1;
                     key[u][v][i] = pl < 0 ? kNoCell : ((uint32_t)pl | (atomicAdd(&off[pl], 1u) << kCellBits));
+                    if (zero_writer && dead && q < d.Nq * G) {
+                        const int64_t s = ((((int64_t)b * d.Nq + qq) * d.H + h) * d.L + tl.level) * d.P + ((q - qq * G) * NV + v) * SPV + i;
+                        g_attn[s] = (T)0.f;
+                        g_loc[2 * s] = (T)0.f; g_loc[2 * s + 1] = (T)0.f;
+                    }
                 }
             }
         }
@@ -327,10 +344,13 @@ struct KeptScan {
                                           uint32_t s0 = 0u, uint32_t cap = 0xffffffffu, bool reload = true)
     {
         if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
+        const bool ts = COMPACT && d.taps_sorted != 0;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const uint32_t qv = threadIdx.x + u * THREADS;
-            const uint32_t q = G == 1 ? qv : qv / (uint32_t)G;            // the record carries the query
+            const uint32_t qq = G == 1 ? qv : qv / (uint32_t)G;
+            // the record carries the query -- or (taps_sorted) query * P + point: the sample's place in grad_loc / grad_attn
+            const uint32_t q = ts ? qq * (uint32_t)d.P + (qv - qq * (uint32_t)G) * (uint32_t)(NV * SPV) : qq;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const uint32_t lw[4] = {lraw[u][v].x, lraw[u][v].y, lraw[u][v].z, lraw[u][v].w};
@@ -349,7 +369,7 @@ struct KeptScan {
                     slot -= s0;
                     if (COMPACT)
                         reinterpret_cast<uint2 *>(list)[slot] =
-                            make_uint2(q | (((aw[(i >> 1) & 1] >> (16 * (i & 1))) & 0xffffu) << 16), lw[i & 3]);
+                            make_uint2((ts ? q + (uint32_t)(v * SPV + i) : q) | (((aw[(i >> 1) & 1] >> (16 * (i & 1))) & 0xffffu) << 16), lw[i & 3]);
                     else
                         reinterpret_cast<uint4 *>(list)[slot] =
                             make_uint4(q, __float_as_uint(l[2 * i + 1] * (float)tl.Hl - 0.5f),
@@ -453,7 +473,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     for (int i = tid; i < ncell; i += THREADS) { off[i] = 0u; if (!kept) cur[i] = 0u; }
     __syncthreads();
     SPROF(0);
-    if (kept) ks.count(d, tl, off);
+    if (kept) ks.count(d, tl, off, b, h, reinterpret_cast<T *>(ta.g_loc), reinterpret_cast<T *>(ta.g_attn));
     else scan_samples<T, kCount, NV, COMPACT, THREADS>(loc, attn, d, tl, b, h, off, cur, nullptr);
     __syncthreads();
     SPROF(1);
@@ -988,7 +1008,9 @@ TileParams make_params(const Dims &d)
 constexpr uint32_t kMaxSortWindow = 128 * 1024;
 uint32_t sort_window_bytes(const Dims &d, const TileParams &tp, bool compact)
 {
-    const uint32_t floor_bytes = kMaxTileCells * 4;
+    // (Dims::taps_sorted needs the kept scan -- the only one that writes a sample's place into its record and the zeros of the
+    // samples that get none -- and the kernel reads "a window is expected" off the size: a little more than the floor then)
+    const uint32_t floor_bytes = kMaxTileCells * 4 + (d.taps_sorted ? 16u : 0u);
     int64_t want = (int64_t)d.Nq * d.P * (compact ? 8 : 16);
     if (tp.nt_min > 1) want = want / tp.nt_min + want / tp.nt_min / 4;
     if (const char *e = knob_str(K_SORT_WINDOW_KB)) want = std::min<int64_t>(atoll(e) * 1024, kMaxSortWindow);
@@ -1069,6 +1091,7 @@ struct Scratch {
     float *tpartials;
     uint32_t tile_cap_extra, tile_cap_partials;
     int tile_blocks_bound;     // >= 4x4 blocks of one (b, h)
+    TapsDesc *xdesc;           // [B, H, tile_blocks_bound] (msda_bwd_taps_sorted.hip)
     int64_t cursor_bytes, total;
 };
 
@@ -1104,7 +1127,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
     // ceil(n / tile_chunk(D)) items, so items and partial tiles are bounded by twice the visits / tile_chunk(D).  (The
     // bounds assume the AVERAGE 25/16 visits per sample; a block whose items or tiles do not fit is walked by one
     // wave alone -- slow, still correct.)
-    s.th = nullptr; s.tdesc = nullptr; s.titems = nullptr; s.slice_done = nullptr; s.n_extra = nullptr; s.tpartials = nullptr;
+    s.th = nullptr; s.tdesc = nullptr; s.titems = nullptr; s.slice_done = nullptr; s.n_extra = nullptr; s.tpartials = nullptr; s.xdesc = nullptr;
     s.tile_cap_extra = s.tile_cap_partials = 0; s.tile_blocks_bound = 0;
     if (tile_reduce_supported(dtype, d)) {
         const int64_t tvisits = pts * (kTB + 1) * (kTB + 1) / (kTB * kTB);
@@ -1118,6 +1141,7 @@ Scratch carve(void *workspace, int dtype, const Dims &d)
         s.slice_done = s.cursor + (int64_t)d.B * d.H * d.L;      // (zeroed with the cursors by backward_value_prepare)
         s.n_extra = s.slice_done + (int64_t)d.B * d.H;
         s.tpartials = (float *)p;    p += up((int64_t)s.tile_cap_partials * kTB * kTB * d.D * 4);
+        s.xdesc = (TapsDesc *)p;     p += up((int64_t)d.B * d.H * s.tile_blocks_bound * sizeof(TapsDesc));
     }
     s.total = p - (char *)workspace;
     return s;
@@ -1153,6 +1177,9 @@ TileReduceArgs tile_args(const Scratch &sc, const Dims &d)
     a.records = sc.records; a.celltab = sc.celltab; a.hdr = sc.hdr; a.cell_stride = cell_stride_of(d);
     a.th = sc.th; a.tdesc = sc.tdesc; a.titems = sc.titems; a.slice_done = sc.slice_done; a.n_extra = sc.n_extra; a.tpartials = sc.tpartials;
     a.blocks_bound = sc.tile_blocks_bound;
+    a.xdesc = d.taps_sorted ? sc.xdesc : nullptr; a.g_loc = a.g_attn = nullptr;
+    a.qshift = 0;
+    if (d.taps_sorted) while ((1 << a.qshift) < d.P) ++a.qshift;
     return a;
 }
 
@@ -1172,7 +1199,7 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
 
 template <typename T, int NV>
 hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
-                       hipStream_t st, int vgroups)
+                       hipStream_t st, int vgroups, void *g_loc, void *g_attn)
 {
     TileParams tp = make_params(d);
     tp.vgroups = vgroups;
@@ -1193,6 +1220,8 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     // the matrix-core reduce takes 8-byte records (its support test bounds Nq by 65536), the others 16-byte ones
     const bool compact = sizeof(T) == 2 && sc.th != nullptr;
     const uint32_t win = sort_window_bytes(d, tp, compact);
+    TileReduceArgs ta = tile_args(sc, d);
+    ta.g_loc = g_loc; ta.g_attn = g_attn;
     auto go = [&](auto tag_compact, auto tag_threads) {
         constexpr bool C = decltype(tag_compact)::value;
         constexpr int THREADS = decltype(tag_threads)::value;
@@ -1201,7 +1230,7 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
         (void)once;
         hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, C, THREADS>), dim3((unsigned)blocks), dim3(THREADS), win, st,
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
-                           cell_stride_of(d), win, tile_args(sc, d));
+                           cell_stride_of(d), win, ta);
     };
     const int lanes = sort_lanes(d, vgroups, NV);
     typedef std::integral_constant<bool, sizeof(T) == 2> Compact;
@@ -1216,13 +1245,13 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
 
 template <typename T>
 hipError_t dispatch_sort(const int64_t *shapes, const int64_t *start, const Scratch &sc, const Dims &d, bool planned,
-                         hipStream_t st)
+                         hipStream_t st, void *g_loc, void *g_attn)
 {
     const KeptCfg c = kept_config((int)sizeof(T), d, make_params(d), sizeof(T) == 2 && sc.th != nullptr);
     switch (c.nv) {
-        case 1: return launch_sort<T, 1>(shapes, start, sc, d, planned, st, c.g);
-        case 2: return launch_sort<T, 2>(shapes, start, sc, d, planned, st, c.g);
-        default: return launch_sort<T, 0>(shapes, start, sc, d, planned, st, 1);
+        case 1: return launch_sort<T, 1>(shapes, start, sc, d, planned, st, c.g, g_loc, g_attn);
+        case 2: return launch_sort<T, 2>(shapes, start, sc, d, planned, st, c.g, g_loc, g_attn);
+        default: return launch_sort<T, 0>(shapes, start, sc, d, planned, st, 1, g_loc, g_attn);
     }
 }
 
@@ -1359,16 +1388,38 @@ bool value_prepare_job(int dtype, const void *loc, const void *attn, const int64
 }
 
 hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                                     const Dims &d, bool planned, hipStream_t st)
+                                     const Dims &d, bool planned, hipStream_t st, void *g_loc, void *g_attn)
 {
     if (!bwd_value_block_supported(dtype, d)) return hipErrorInvalidValue;
+    if (d.taps_sorted && !(taps_sorted_supported(dtype, d) && g_loc && g_attn)) return hipErrorInvalidValue;
     const Scratch sc = carve(workspace, dtype, d);
     switch (dtype) {
-        case 0: return dispatch_sort<float>(shapes, start, sc, d, planned, st);
-        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, planned, st);
-        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, planned, st);
+        case 0: return dispatch_sort<float>(shapes, start, sc, d, planned, st, g_loc, g_attn);
+        case 1: return dispatch_sort<half_t>(shapes, start, sc, d, planned, st, g_loc, g_attn);
+        case 2: return dispatch_sort<bf16_t>(shapes, start, sc, d, planned, st, g_loc, g_attn);
         default: return hipErrorInvalidValue;
     }
+}
+
+// grad_loc / grad_attn from the cell-sorted records (msda_bwd_taps_sorted.hip) need: the matrix-core reduce's 8-byte records
+// (16-bit storage, D in {32, 64, 128}), the sample's place query * P + point in the record's 16 query bits (P a power of two),
+// the kept scan of the sort (the only one that writes that place and the zeros of samples without a record), no level
+// taken away from the sort.  MMFS_TAPS_ALGO = vec | mma: never.
+bool taps_sorted_supported(int dtype, const Dims &d)
+{
+    if (!bwd_value_block_supported(dtype, d) || !tile_reduce_supported(dtype, d)) return false;
+    if (d.P <= 0 || (d.P & (d.P - 1)) || (int64_t)d.Nq * d.P > 65536) return false;
+    if (d.gv_skip[0] | d.gv_skip[1]) return false;
+    if (const char *e = knob_str(K_TAPS_ALGO)) if (e[0] == 'v' || e[0] == 'm' || e[0] == 'g') return false;     // vec / mma / gather
+    return sort_keeps_samples(dtype, d, make_params(d));
+}
+
+// the pieces of the workspace msda_bwd_taps_sorted.hip reads
+blk::TileReduceArgs blk::taps_sorted_args(void *workspace, int dtype, const Dims &d, uint32_t *cap_extra)
+{
+    const Scratch sc = carve(workspace, dtype, d);
+    *cap_extra = sc.tile_cap_extra;
+    return tile_args(sc, d);
 }
 
 hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,

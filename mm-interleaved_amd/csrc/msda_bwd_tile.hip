@@ -98,7 +98,10 @@ template <int D> struct TileGeom {
     static constexpr int SLOT = kKS * RB;          // bytes of a row slot
     static constexpr int ROWS_BYTES = kStages * SLOT > 16 * (RB + 16) ? kStages * SLOT : 16 * (RB + 16);   // (the epilogue stages the block's rows here, pitch RB + 16)
     static constexpr int REC_BYTES = kRecSlots * kRecBatch * 8;       // per batch: 64 first words, then 64 second words
-    static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES + 1024;
+#ifndef MMFS_TILE_EXTRA_LDS
+#define MMFS_TILE_EXTRA_LDS 0          // (experiment: fewer waves per CU, profiles/r06_experiments.md)
+#endif
+    static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES + 1024 + MMFS_TILE_EXTRA_LDS;
     // chunk swizzle of row r (row index inside its slot): the 4 rows a 16-lane group of a transposing
     // read touches together must land in different banks
     static __device__ __forceinline__ int swz(int r) { return 4 * ((r / RP) % (4 / RP)); }
@@ -242,7 +245,7 @@ __device__ __forceinline__ void tile_item(const T *__restrict__ grad_out, T *__r
             const int rel0 = kKS * (4 * j + S);
             uint32_t q[G::NR];
 #pragma unroll
-            for (int u = 0; u < G::NR; ++u) q[u] = rq[u * G::RPI + rsel] & 0xffffu;
+            for (int u = 0; u < G::NR; ++u) q[u] = (rq[u * G::RPI + rsel] & 0xffffu) >> a.qshift;     // (taps_sorted: the record carries query * P + point)
 #pragma unroll
             for (int u = 0; u < G::NR; ++u) {
                 const int rr = u * G::RPI + rsel;

@@ -42,6 +42,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->table_status = nullptr;
     d->taps_algo = 0;
     d->gv_skip[0] = d->gv_skip[1] = 0;
+    d->taps_sorted = 0;
     return MMFS_OK;
 }
 
@@ -504,6 +505,60 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
         e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, true);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_BLOCKS) && gvt.n_groups > 0)
         e = mmfs::gv::backward_value(dtype, grad_out, loc, attn, grad_value, (char *)workspace + base, d, gvt, st);
+    return (int)e;
+}
+
+// ---------------------------------------------------------------- the backward on the cell-sorted records
+static bool sorted_route(int dtype, mmfs::Dims &d, unsigned flags)
+{
+    if (!(flags & MMFS_BWD_CANONICAL_LEVELS) || (flags & (MMFS_BWD_FORCE_ATOMIC | MMFS_BWD_TAPS_ROW_GATHER | MMFS_BWD_TAPS_LDS_LEVELS))) return false;
+    if (!use_tiled(dtype, d, flags)) return false;
+    d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
+    d.taps_sorted = 1;
+    return mmfs::taps_sorted_supported(dtype, d);
+}
+
+int64_t mmfs_msda_backward_sorted_workspace_bytes(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
+                                                  int64_t L, int64_t Nq, int64_t P, unsigned flags)
+{
+    mmfs::Dims d;
+    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
+    if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !sorted_route(dtype, d, flags)) return 0;
+    return mmfs::bwd_value_block_workspace_bytes(dtype, d);
+}
+
+int mmfs_msda_backward_sorted(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
+                              const void *loc, const void *attn, const void *grad_out,
+                              void *grad_value, void *grad_loc, void *grad_attn,
+                              void *workspace, int64_t workspace_bytes,
+                              int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P, int64_t blocks4,
+                              unsigned flags, unsigned stages, void *stream)
+{
+    const int es = elem_size(dtype);
+    if (!es) return MMFS_E_DTYPE;
+    mmfs::Dims d;
+    const int rc = make_dims(B, S, H, D, L, Nq, P, &d);
+    if (rc) return rc;
+    if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !sorted_route(dtype, d, flags)) return MMFS_E_UNSUPPORTED;
+    if (blocks4 < 0) return MMFS_E_DIMS;
+    d.blocks4 = (int)std::min<int64_t>(blocks4, 0x3fffffff);
+    if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
+        return MMFS_E_NULLPTR;
+    if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||
+        misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, 2 * es) || misaligned(grad_attn, es))
+        return MMFS_E_ALIGN;
+    if (!workspace || workspace_bytes < mmfs::bwd_value_block_workspace_bytes(dtype, d)) return MMFS_E_NULLPTR;
+    if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (stages & MMFS_SRT_BWD_PREPARE)
+        e = mmfs::backward_value_block_prepare(dtype, loc, attn, shapes, start, workspace, d, st);
+    if (e == hipSuccess && (stages & MMFS_SRT_BWD_SORT))
+        e = mmfs::backward_value_block_sort(dtype, shapes, start, workspace, d, true, st, grad_loc, grad_attn);
+    if (e == hipSuccess && (stages & MMFS_SRT_BWD_TAPS))
+        e = mmfs::backward_taps_sorted(dtype, value, grad_out, grad_loc, grad_attn, workspace, d, st);
+    if (e == hipSuccess && (stages & MMFS_SRT_BWD_REDUCE))
+        e = mmfs::backward_value_block_reduce(dtype, grad_out, grad_value, workspace, d, true, st);
     return (int)e;
 }
 

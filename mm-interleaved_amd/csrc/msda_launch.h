@@ -82,7 +82,13 @@ int64_t bwd_value_block_workspace_bytes(int dtype, const Dims &d);
 hipError_t backward_value_block_prepare(int dtype, const void *loc, const void *attn, const int64_t *shapes,
                                         const int64_t *start, void *workspace, const Dims &d, hipStream_t st);
 hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int64_t *start, void *workspace,
-                                     const Dims &d, bool planned, hipStream_t st);
+                                     const Dims &d, bool planned, hipStream_t st, void *g_loc = nullptr, void *g_attn = nullptr);
+// grad_loc / grad_attn from the cell-sorted records: a wave per 4x4 block of cells, the block's 5x5 pixel rows of value as one
+// matrix-core operand, the records' grad_out rows as the other (d.taps_sorted: the sort writes what this needs).
+// Order of a backward on this route: prepare (plan), sort, taps_sorted, reduce.                 [msda_bwd_taps_sorted.hip]
+bool taps_sorted_supported(int dtype, const Dims &d);
+hipError_t backward_taps_sorted(int dtype, const void *value, const void *grad_out, void *grad_loc, void *grad_attn,
+                                void *workspace, const Dims &d, hipStream_t st);
 hipError_t backward_value_block_reduce(int dtype, const void *grad_out, void *grad_value, void *workspace,
                                        const Dims &d, bool all_rows_owned, hipStream_t st);
 hipError_t backward_value_run(int dtype, const int64_t *shapes, const int64_t *start,
