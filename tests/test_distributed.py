@@ -94,6 +94,66 @@ def _worker_idle_rank(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def _worker_ragged(rank, world, port, tmp, n_img, nums):
+    """World sizes 4 and 8 with image counts that do not divide by the world size: the last rank(s) hold fewer images --
+    or NONE -- and pad their block with zeros in the forward gather (bank.py: all_gather_image_features); sequences are
+    sharded unevenly too; some ranks' shards show no image.  Same acceptance as the world-size-2 test."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "mm-interleaved_amd")]
+    from mmfs_amd import bank
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(2)
+        num = torch.tensor(nums)
+        assert int(num.sum()) == n_img
+        n_max = int(num.max())
+        packed = torch.randn(n_img, 20, 6, generator=g)          # the single-rank truth
+        packed[0, 0, 0] = float("inf")                          # a non-finite feature must not leak through keep_in_graph
+        want_bank = bank.llm_feature_bank(packed, num, n_max)
+        i0, i1 = bank.local_image_range(n_img, rank, world)
+        per = bank.images_per_rank(n_img, world)
+        assert 0 <= i1 - i0 <= per
+        mine = packed[i0:i1].clone().requires_grad_(True)       # (may be EMPTY: a rank past the last image)
+        gathered = bank.all_gather_image_features(mine, n_img)
+        assert gathered.shape[0] == n_img
+        assert torch.equal(gathered.detach(), packed), "gathered features differ from the single-rank tensor"
+        lo, hi = bank.shard_batch(num.numel(), rank, world)
+        first, cnt = int(num[:lo].sum()), int(num[lo:hi].sum())
+        local = bank.llm_feature_bank(gathered[first:first + cnt], num[lo:hi], n_max)
+        assert torch.equal(local.detach(), want_bank[lo:hi])
+        wts = torch.randn(want_bank.shape, generator=g)
+        wts[torch.isinf(want_bank)] = 0.0                        # (keep the truth's gradient finite where the feature is not)
+        loss = (torch.nan_to_num(local, posinf=0.0) * wts[lo:hi]).sum() + torch.zeros((), requires_grad=True).sum()
+        loss = bank.keep_in_graph(loss, gathered)
+        assert bool(torch.isfinite(loss)), "keep_in_graph must not read the gathered values"
+        loss.backward()
+        ref = packed.clone().requires_grad_(True)
+        (torch.nan_to_num(bank.llm_feature_bank(ref, num, n_max), posinf=0.0) * wts).sum().backward()
+        if i1 > i0:
+            assert torch.allclose(mine.grad, ref.grad[i0:i1], rtol=0, atol=1e-5), "gradient did not return to the owning rank"
+        else:
+            assert mine.grad is None or mine.grad.numel() == 0
+        open(os.path.join(tmp, f"ragged_ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+import pytest
+
+
+@pytest.mark.parametrize("world, n_img, nums", [
+    (4, 7, [3, 1, 0, 2, 0, 1]),                      # 7 images on 4 ranks: blocks of 2, the last rank holds ONE; 6 sequences on 4 ranks
+    (4, 5, [2, 0, 0, 3, 0]),                         # blocks of 2: rank 2 holds one image, rank 3 NONE (all padding)
+    (8, 11, [1, 2, 0, 3, 0, 0, 1, 2, 0, 2, 0]),      # blocks of 2: rank 5 holds one, ranks 6 and 7 none; 11 sequences on 8 ranks
+    (8, 3, [0, 1, 0, 0, 2, 0, 0, 0, 0]),             # fewer images than ranks
+])
+def test_ragged_image_blocks_and_idle_ranks_at_world_4_and_8(tmp_path, world, n_img, nums):
+    mp.spawn(_worker_ragged, args=(world, _free_port(), str(tmp_path), n_img, nums), nprocs=world, join=True)
+    assert all((tmp_path / f"ragged_ok{r}").exists() for r in range(world))
+
+
 def test_a_rank_without_images_still_joins_the_backward_collective(tmp_path):
     world = 2
     mp.spawn(_worker_idle_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
