@@ -37,6 +37,12 @@ Extra objects on the JSON line:
                every rank all-gathers the multiscale features of its block of context images (LLM
                geometry, 4 images per sequence: BASELINE config 5) and builds its sequences' bank
                from the gathered tensor -- us per all-gather, GB/s per xGMI link, us per bank build
+  step_roofline  the WHOLE step: SURVEY 8d's fwdbwd_bytes / the clean step time vs 8 TB/s ("frac") and vs the 6.29 TB/s a
+               plain copy reaches on this part ("frac_of_copy_ceiling"); forward and backward separately from the event pass
+  fp16         (default line only, N = 1) the same shape in fp16 -- the only 16-bit type the reference's op has: ms per step
+               and the largest error of a slab of ITS results against the CPU oracle (bar: north_star's 1e-3)
+  dropin_unchanged_ms  (default line only, N = 1) ms per step when spatial_shapes / level_start_index are rebuilt per call as
+               the reference's callers do (what an unchanged reference gets; "ms_per_step" uses tables built once)
   cpu_baseline the oracle's restatement of the reference's only CPU path
                (ms_deform_attn_core_pytorch) timed on this host at BASELINE config 1
                (B=2, Nq=1024, L=4, H=8, P=4, C=256, fp32), all cores and 1 thread, rank 0, N=1 only
@@ -52,9 +58,11 @@ for p in (ROOT, os.path.join(ROOT, "mm-interleaved_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_COPY_GBS = 6290.0          # what a float4 copy measures on this part (same guide: 79 % of the data sheet)
 
 WORKLOADS = {
     # name: (B, Nq, H, D, P, per-image level shapes, n_images, dtype)
@@ -83,7 +91,7 @@ WORKLOADS = {
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
-def algorithmic_bytes(w, e, lds_levels=()):
+def algorithmic_bytes(w, e):
     """compulsory traffic, every distinct tensor element touched once."""
     B, Nq, H, D, P = w["B"], w["Nq"], w["H"], w["D"], w["P"]
     Leff = len(w["shapes"]) * w["n"]
@@ -101,15 +109,11 @@ def algorithmic_bytes(w, e, lds_levels=()):
     pts_d = B * Nq * H * sum(dense) * P
     taps_dense = e * (B * Sd * C + 6 * pts_d + B * Nq * C)
     taps_fine = e * (B * (S - Sd) * C + 6 * (pts - pts_d) + B * Nq * C)
-    # grad_value: the levels in ``lds_levels`` are sorted and reduced inside a workgroup (csrc/msda_gv_mma.hip: loc,
-    # attn, grad_out -> their grad_value rows), the others by the cell sort (loc, attn -> scratch) + tile reduce
-    Sl = sum(h * ww for i, (h, ww) in enumerate(w["shapes"] * w["n"]) if i in lds_levels)
-    pts_l = B * Nq * H * len(lds_levels) * P
-    sort = e * 3 * (pts - pts_l)
-    red = e * (B * (S - Sl) * C + B * Nq * C)           # grad_out -> grad_value
-    blocks = e * (B * Sl * C + B * Nq * C + 3 * pts_l)
+    # grad_value: the cell sort (loc, attn -> scratch) + tile reduce
+    sort = e * 3 * pts
+    red = e * (B * S * C + B * Nq * C)                  # grad_out -> grad_value
     return dict(msda_fwd=fwd, msda_bwd_atomic=bwd, msda_bwd_taps=taps, msda_bwd_value_sort=sort,
-                msda_bwd_value_reduce=red, msda_bwd_value_blocks=blocks, fwdbwd=fwd + bwd,
+                msda_bwd_value_reduce=red, fwdbwd=fwd + bwd, bwd=bwd,
                 msda_bwd_taps_coarse=taps_dense, msda_bwd_taps_fine=taps_fine)
 
 
@@ -194,6 +198,64 @@ def cpu_baseline(budget_s=12.0):
             "sample": f"oracle/msda_torch.py (ms_deform_attn_core_pytorch restated), BASELINE config 1 "
                       f"(B={B} Nq={Nq} L={L} H={H} P={P} C={H * D}, fp32, fwd+bwd), {best[2]} timed iterations with "
                       f"{all_threads} threads and {runs[1][2]} with 1 thread after warm-up"}
+
+
+def timed_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def fp16_sibling(w, device, shapes, start, steps=20, warmup=10):
+    """The headline shape in fp16 -- the only 16-bit type the reference's op has (ms_deform_attn_cuda.cu:65 dispatches
+    fp64 / fp32 / fp16; training is fp16, configs/release/mm_pretrain.yaml:3) and so the only one in which BASELINE's
+    "within 1e-3 of the reference" can be checked at the headline shape: ms per step, and the largest error of a slab of
+    the results against the CPU oracle (the checker of tests/, here on the very tensors that were timed): a strided set of
+    48 queries of the first, a middle and the last sample (out, grad_loc, grad_attn: every head, every level) and
+    grad_value of one whole head of sample 0.  Errors are absolute for ``out`` (values in [0, 1)) and relative to the
+    largest reference entry for the gradients."""
+    from mmfs_amd.functions import MSDeformAttnFunction
+    from oracle import msda_oracle
+    w16 = dict(w, dtype="f16")
+    value, _, _, loc, attn, grad = make_inputs(w16, device, seed=0)
+    value.requires_grad_(True); loc.requires_grad_(True); attn.requires_grad_(True)
+
+    def step():
+        out = MSDeformAttnFunction.apply(value, shapes, start, loc, attn, 1)
+        return out, torch.autograd.grad(out, (value, loc, attn), grad)
+
+    ms = timed_steps(step, steps, warmup)
+    out, (gv, gl, ga) = step()
+    torch.cuda.synchronize()
+    B, Nq, H, D = w["B"], w["Nq"], w["H"], w["D"]
+    sh, st = shapes.cpu(), start.cpu()
+    err = {"out": 0.0, "grad_loc": 0.0, "grad_attn": 0.0, "grad_value": 0.0}
+    rel = lambda got, want: float(np.abs(got.double().cpu().numpy() - np.asarray(want, np.float64).reshape(got.shape)).max()
+                                  / max(1.0, float(np.abs(np.asarray(want)).max())))
+    for bi in sorted({0, B // 2, B - 1}):
+        qs = torch.arange(5, Nq, max(1, Nq // 48), device=device)[:48]
+        x = [t.detach().double().cpu() for t in (value[bi:bi + 1], loc[bi:bi + 1, qs], attn[bi:bi + 1, qs], grad[bi:bi + 1, qs])]
+        want = msda_oracle.forward(x[0], sh, st, x[1], x[2])
+        _, wgl, wga = msda_oracle.backward(x[0], sh, st, x[1], x[2], x[3])
+        err["out"] = max(err["out"], float(np.abs(out[bi:bi + 1, qs].detach().double().cpu().numpy() - np.asarray(want).reshape(1, len(qs), -1)).max()))
+        err["grad_loc"] = max(err["grad_loc"], rel(gl[bi:bi + 1, qs], wgl))
+        err["grad_attn"] = max(err["grad_attn"], rel(ga[bi:bi + 1, qs], wga))
+    h0 = 3 % H
+    x = [t.detach().double().cpu() for t in (value[:1, :, h0:h0 + 1], loc[:1, :, h0:h0 + 1], attn[:1, :, h0:h0 + 1],
+                                               grad[:1, :, h0 * D:(h0 + 1) * D])]
+    wgv, _, _ = msda_oracle.backward(x[0], sh, st, x[1], x[2], x[3])
+    err["grad_value"] = rel(gv[:1, :, h0:h0 + 1], wgv)
+    return {"dtype": "f16", "ms_per_step": round(ms, 4), "steps": steps,
+            "samples_per_s": round(w["B"] / (ms * 1e-3), 2),
+            "max_err_vs_oracle_slab": {k: float(f"{v:.3e}") for k, v in err.items()},
+            "bar": "1e-3 (north_star, fp16): absolute for out, relative to the largest reference entry for the gradients",
+            "within_bar": bool(max(err.values()) <= 1e-3),
+            "slab": "48 strided queries of samples 0, B/2, B-1 (out, grad_loc, grad_attn: all heads and levels); grad_value of head 3 of sample 0"}
 
 
 class ExchangeOverlap:
@@ -319,6 +381,9 @@ def main():
                          "registered pair -- what of the fresh line's distance to the default line is the CALLER's tensor construction")
     ap.add_argument("--grad", default="randn", choices=["randn", "ones"],
                     help="grad_output: N(0,1) or ones (the reference's speed test backpropagates .sum())")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two sibling measurements of the default line (N = 1): the fp16 run of the same shape with its "
+                         "error against the oracle slab, and the reference's call pattern (fresh level tensors per call)")
     ap.add_argument("--exchange-in-step", action="store_true",
                     help="N > 1: the feature all-gather of BASELINE config 5 is issued on a side stream inside every "
                          "timed step, overlapping the op (SURVEY 8e); default: timed after the main region")
@@ -364,10 +429,10 @@ def main():
     if args.exchange_in_step and dist is not None:
         overlap = ExchangeOverlap(device, rank, world)
 
-    def step():
+    def step(fresh=False):
         if overlap is not None:
             overlap.issue()                     # the all-gather rides a side stream under the op
-        if args.fresh_levels or args.fresh_levels_unused:
+        if args.fresh_levels or args.fresh_levels_unused or fresh:
             # what the reference's callers do per call: two new device tensors, nothing registered
             sh = host_shapes.to(device)
             st = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
@@ -443,10 +508,7 @@ def main():
         for name, a, b in log:
             per_kernel.setdefault(name, []).append(a.elapsed_time(b))     # ms
         mean_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
-        lds_levels = ()
-        if "msda_bwd_value_blocks" in mean_ms:
-            lds_levels = tuple(MSDA.value_lds_levels(DTYPES[w["dtype"]], w["shapes"] * w["n"], w["B"], w["H"], w["D"], w["Nq"], w["P"]))
-        ab = algorithmic_bytes(w, e, lds_levels)
+        ab = algorithmic_bytes(w, e)
         if "msda_bwd_taps_coarse" in mean_ms:          # the gather kernel then covers the other levels only
             ab["msda_bwd_taps"] = ab["msda_bwd_taps_fine"]
         dom = max((k for k in mean_ms if k in ab), key=lambda k: mean_ms[k])
@@ -493,6 +555,28 @@ def main():
             "fwdbwd_hbm_frac": round(ab["fwdbwd"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_hbm_frac": round(ab["fwdbwd"] / (sum(mean_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         }
+        # the WHOLE step against the roofline (SURVEY 8d's fwdbwd_bytes / the clean step time), against the 8 TB/s of the
+        # data sheet and against the 6.29 TB/s a plain copy reaches on this part (MI355X_MICROARCH.md); forward and
+        # backward separately from the per-kernel events
+        step_s = elapsed / args.steps
+        bwd_us = sum(v for k, v in mean_ms.items() if k != "msda_fwd") * 1e3
+        res["step_roofline"] = {
+            "bound": "hbm", "bytes": ab["fwdbwd"], "ms": round(step_s * 1e3, 4),
+            "achieved": round(ab["fwdbwd"] / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ab["fwdbwd"] / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            "copy_ceiling": HBM_COPY_GBS, "frac_of_copy_ceiling": round(ab["fwdbwd"] / step_s / 1e9 / HBM_COPY_GBS, 4),
+            "forward": {"bytes": ab["msda_fwd"], "us": round(mean_ms.get("msda_fwd", 0.0) * 1e3, 2),
+                        "frac": round(ab["msda_fwd"] / (mean_ms["msda_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mean_ms.get("msda_fwd") else None},
+            "backward": {"bytes": ab["bwd"], "us": round(bwd_us, 2),
+                         "frac": round(ab["bwd"] / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if bwd_us > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras and args.workload == "cfg2_northstar" \
+                and not (args.fresh_levels or args.fresh_levels_unused) and not experiment:
+            # the reference's call pattern on the same tensors: spatial_shapes / level_start_index rebuilt per call as its
+            # callers do (modeling_llama_mmfs.py:298-308) -- what an UNCHANGED reference gets from the drop-in
+            res["dropin_unchanged_ms"] = round(timed_steps(lambda: step(fresh=True), 20, 10), 4)
+            if w["dtype"] != "f16":
+                res["fp16"] = fp16_sibling(w, device, shapes, start)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
     ex = None

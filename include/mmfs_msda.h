@@ -37,7 +37,10 @@ extern "C" {
 #endif
 
 #define MMFS_MSDA_ABI_VERSION 13  /* 13: + mmfs_msda_backward_sorted (+ _workspace_bytes): the whole backward on the cell-sorted records -- grad_loc / grad_attn
-                                   *     from the records the grad_value sort makes (csrc/msda_bwd_taps_sorted.hip), no per-sample value-row gather
+                                   *     from the records the grad_value sort makes (csrc/msda_bwd_taps_sorted.hip), no per-sample value-row gather;
+                                   *     GONE: the workgroup-local grad_value of the small levels (csrc/msda_gv_mma.hip: parity-green, slower on every
+                                   *     shipped geometry for three rounds) with stage MMFS_HYB_BWD_VALUE_BLOCKS, MMFS_BWD_VALUE_SORTED_ONLY /
+                                   *     MMFS_BWD_VALUE_LDS_BLOCKS, mmfs_msda_backward_value_lds_levels, mmfs_msda_debug_value_plan
                                    * 12: + mmfs_env_reload / mmfs_env_knob (the environment knobs are one table, read once); 11: + MMFS_FWD_QUERY_WAVES (the forward's fourth formulation, csrc/msda_fwd_wq.hip: the default for 16-bit
                                    *     heads of 128 channels with one chunk of samples per query -- the north-star shape); every
                                    *     matrix-core forward returns the reference's Inf / NaN element for element (a non-finite sum
@@ -180,18 +183,6 @@ int mmfs_msda_forward_flags(int dtype,
  * MMFS_BWD_TAPS_LDS_LEVELS on a shape that does not allow it returns MMFS_E_UNSUPPORTED. */
 #define MMFS_BWD_TAPS_ROW_GATHER 64u
 #define MMFS_BWD_TAPS_LDS_LEVELS 128u
-/* grad_value has two formulations too (mmfs_msda_backward_hybrid only: the choice needs the host copy of the level table):
- *   sorted       csrc/msda_bwd_block.hip + msda_bwd_tile.hip: every sample sorted by cell through global memory, a wave
- *                per 4x4 pixel block;
- *   LDS blocks   csrc/msda_gv_mma.hip, 16-bit storage, D in {64, 128}, >= 256 queries: the levels of at most 32 (D = 128)
- *                / 64 (D = 64) blocks of 4x4 pixels are sorted by block INSIDE a workgroup, chunk of queries by chunk of
- *                queries, next to the chunk's grad_out rows in LDS; the other levels stay sorted.  OPT-IN: parity-green,
- *                but measured slower than the sorted path on every shipped geometry.
- * MMFS_BWD_VALUE_LDS_BLOCKS asks for it (on arguments for which no level qualifies: MMFS_E_UNSUPPORTED; environment
- * MMFS_GV_ALGO=on asks for it wherever it applies); MMFS_BWD_VALUE_SORTED_ONLY keeps every level on the sorted path
- * whatever the environment says. */
-#define MMFS_BWD_VALUE_SORTED_ONLY 256u
-#define MMFS_BWD_VALUE_LDS_BLOCKS 512u
 /* 1 when, for these arguments, grad_loc / grad_attn of ALL levels come from the one LDS-levels kernel (the staged
  * hybrid backward's MMFS_HYB_BWD_TAPS_COARSE stage then has nothing to launch), else 0.  Host-only. */
 int mmfs_msda_backward_taps_fused(int dtype, int64_t B, int64_t S, int64_t H, int64_t D,
@@ -335,24 +326,11 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
 #define MMFS_HYB_BWD_VALUE_PREPARE  4u
 #define MMFS_HYB_BWD_VALUE_SORT     8u
 #define MMFS_HYB_BWD_VALUE_REDUCE  16u
-#define MMFS_HYB_BWD_VALUE_BLOCKS  32u   /* the levels msda_gv_mma.hip serves (independent of PREPARE / SORT / REDUCE, which
-                                          * plan nothing for them; nothing to launch when no level qualifies) */
-#define MMFS_HYB_BWD_ALL           63u
+#define MMFS_HYB_BWD_ALL           31u
 int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype,
                                                   const int64_t *host_shapes, const int64_t *host_start,
                                                   int64_t B, int64_t S, int64_t H, int64_t D,
                                                   int64_t L, int64_t Nq, int64_t P, unsigned flags);
-/* How many levels' grad_value the MMFS_HYB_BWD_VALUE_BLOCKS stage computes for these arguments (0: the stage has nothing
- * to launch; L: the PREPARE / SORT / REDUCE stages have nothing to launch).  Host-only. */
-int mmfs_msda_backward_value_lds_levels(int dtype, const int64_t *host_shapes, const int64_t *host_start,
-                                        int64_t B, int64_t S, int64_t H, int64_t D,
-                                        int64_t L, int64_t Nq, int64_t P, unsigned flags);
-/* Test hook, host-only: the plan behind the MMFS_HYB_BWD_VALUE_BLOCKS stage (struct mmfs::gv::Table of
- * csrc/msda_gv_mma.h, copied to ``out`` when ``out_bytes`` suffices); returns the struct's size.
- * tests/test_gv_mma_model.py checks its invariants and runs a lane-level model of the kernel on it. */
-int64_t mmfs_msda_debug_value_plan(int dtype, const int64_t *host_shapes, const int64_t *host_start,
-                                   int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
-                                   unsigned flags, void *out, int64_t out_bytes);
 int mmfs_msda_backward_hybrid(int dtype,
                               const void *value, const int64_t *shapes, const int64_t *start,
                               const int64_t *host_shapes, const int64_t *host_start,

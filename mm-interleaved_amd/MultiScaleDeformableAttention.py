@@ -59,10 +59,6 @@ _lib.mmfs_msda_backward_checked.restype = _int
 _lib.mmfs_msda_backward_checked.argtypes = [_int] + [_vp] * 10 + [_i64] * 8 + [ctypes.c_uint, _vp, _vp]
 _lib.mmfs_msda_backward_taps_fused.restype = _int
 _lib.mmfs_msda_backward_taps_fused.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
-_lib.mmfs_msda_backward_value_lds_levels.restype = _int
-_lib.mmfs_msda_backward_value_lds_levels.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint]
-_lib.mmfs_msda_debug_value_plan.restype = _i64
-_lib.mmfs_msda_debug_value_plan.argtypes = [_int, _vp, _vp] + [_i64] * 7 + [ctypes.c_uint, _vp, _i64]
 _lib.mmfs_msda_backward_workspace_bytes.restype = _i64
 _lib.mmfs_msda_backward_workspace_bytes.argtypes = [_int] + [_i64] * 7 + [ctypes.c_uint]
 _lib.mmfs_msda_backward_taps.restype = _int
@@ -318,8 +314,6 @@ _BWD_LAZY_ZERO_ATTN = 16
 _BWD_DEVICE_CHECKED_LEVELS = 32
 _BWD_TAPS_ROW_GATHER = 64
 _BWD_TAPS_LDS_LEVELS = 128
-_BWD_VALUE_SORTED_ONLY = 256
-_BWD_VALUE_LDS_BLOCKS = 512
 _E_UNSUPPORTED = -5
 
 # tests / measurements: which formulation computes grad_loc / grad_attn (include/mmfs_msda.h):
@@ -330,13 +324,6 @@ _E_UNSUPPORTED = -5
 _taps_algo = "auto"
 _taps_prefer_sorted = os.environ.get("MMFS_TAPS_ROUTE") == "sorted"      # wherever it applies, silently not elsewhere
 _TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS, "sorted": 0}
-
-# tests / measurements: which formulation computes grad_value of the small levels (include/mmfs_msda.h; only the hybrid
-# entry point -- a registered level table -- has the choice): "auto" (= sorted, unless MMFS_GV_ALGO=on) | "sorted"
-# (csrc/msda_bwd_block.hip + msda_bwd_tile.hip for every level) | "lds" (csrc/msda_gv_mma.hip where a level qualifies;
-# arguments without one raise).  The LDS formulation is parity-green and measured slower: opt-in
-_value_algo = "auto"
-_VALUE_FLAGS = {"auto": 0, "sorted": _BWD_VALUE_SORTED_ONLY, "lds": _BWD_VALUE_LDS_BLOCKS}
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
 _bwd_algo = "auto"
@@ -392,24 +379,8 @@ _SRT_BWD_ALL = 15
 
 # stage bits of mmfs_msda_backward_hybrid (include/mmfs_msda.h)
 _HYB_BWD_STAGES = (("msda_bwd_taps", 1), ("msda_bwd_taps_coarse", 2), ("msda_bwd_value_prepare", 4),
-                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16), ("msda_bwd_value_blocks", 32))
-_HYB_BWD_ALL = 63
-
-
-def value_lds_levels(dtype, shapes, B, H, D, Nq, P, flags=0):
-    """Measurement / test helper: the levels (indices into ``shapes``, a list of (H_l, W_l) packed canonically)
-    whose grad_value the workgroup-local kernel (csrc/msda_gv_mma.hip) computes for these arguments on a
-    registered level table; the others stay with the cell sort + tile reduce."""
-    hs = np.ascontiguousarray(np.asarray(shapes, dtype=np.int64).reshape(-1, 2))
-    px = hs[:, 0] * hs[:, 1]
-    hst = np.ascontiguousarray(np.cumsum(px) - px)
-    size = _lib.mmfs_msda_debug_value_plan(_DTYPE_CODE[dtype], None, None, 0, 0, 0, 0, 0, 0, 0, 0, None, 0)
-    buf = (ctypes.c_uint8 * max(int(size), 32))()
-    _lib.mmfs_msda_debug_value_plan(_DTYPE_CODE[dtype], hs.ctypes.data, hst.ctypes.data, B, int(px.sum()), H, D, len(hs),
-                                    Nq, P, flags | _BWD_CANONICAL_LEVELS, ctypes.addressof(buf), len(buf))
-    head = np.frombuffer(buf, dtype=np.uint64, count=4)            # {n_levels, n_groups | wgs, ptiles}, skip[2]
-    mask = int(head[2]) | (int(head[3]) << 64)
-    return [l for l in range(len(hs)) if (mask >> l) & 1]
+                   ("msda_bwd_value_sort", 8), ("msda_bwd_value_reduce", 16))
+_HYB_BWD_ALL = 31
 
 
 def levels_are_canonical(spatial_shapes, level_start_index, S):
@@ -548,7 +519,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 grad_attn = grad_attn.to(attn_dtype)
             return [grad_value, grad_loc, grad_attn]
         if _hybrid and info is not None and (flags & _BWD_CANONICAL_LEVELS) and code in (1, 2):
-            flags |= _BWD_DENSE_TAPS | _VALUE_FLAGS[_value_algo]
+            flags |= _BWD_DENSE_TAPS
             hs, hst = info[1].ctypes.data, info[2].ctypes.data
             # (keyed by the table's CONTENT: a freed host copy's address can come back with another table)
             key = (code, dims, flags, info[1].tobytes(), info[2].tobytes())
@@ -568,18 +539,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             fused = _ws_cache.get(fkey)
             if fused is None:
                 fused = _ws_cache[fkey] = _lib.mmfs_msda_backward_taps_fused(code, *dims, flags)
-            lkey = ("lds_levels", key)
-            lds_levels = _ws_cache.get(lkey)
-            if lds_levels is None:
-                lds_levels = _ws_cache[lkey] = _lib.mmfs_msda_backward_value_lds_levels(code, hs, hst, *dims, flags)
-            sorted_levels = int(((info[1][:, 0] > 0) & (info[1][:, 1] > 0)).sum()) - lds_levels
+            sorted_levels = int(((info[1][:, 0] > 0) & (info[1][:, 1] > 0)).sum())
 
             def run_stages(stages):
                 st = 0
                 if fused:               # one kernel does every level: the dense stage has nothing to launch
                     stages = tuple(sb for sb in stages if sb[0] != "msda_bwd_taps_coarse")
-                if lds_levels == 0:     # grad_value: no level for the workgroup-local kernel / none left for the sort
-                    stages = tuple(sb for sb in stages if sb[0] != "msda_bwd_value_blocks")
                 if sorted_levels == 0:
                     stages = tuple(sb for sb in stages if sb[0] not in ("msda_bwd_value_prepare", "msda_bwd_value_sort",
                                                                         "msda_bwd_value_reduce"))

@@ -1193,7 +1193,6 @@ static PlanArgs plan_args(const int64_t *shapes, const int64_t *start, const Scr
     pa.loc_src = pa.attn_src = nullptr;
     pa.status = d.table_status;
     pa.stamp = header_stamp(d);
-    pa.skip[0] = d.gv_skip[0]; pa.skip[1] = d.gv_skip[1];
     return pa;
 }
 
@@ -1409,7 +1408,6 @@ bool taps_sorted_supported(int dtype, const Dims &d)
 {
     if (!bwd_value_block_supported(dtype, d) || !tile_reduce_supported(dtype, d)) return false;
     if (d.P <= 0 || (d.P & (d.P - 1)) || (int64_t)d.Nq * d.P > 65536) return false;
-    if (d.gv_skip[0] | d.gv_skip[1]) return false;
     if (const char *e = knob_str(K_TAPS_ALGO)) if (e[0] == 'v' || e[0] == 'm' || e[0] == 'g') return false;     // vec / mma / gather
     return sort_keeps_samples(dtype, d, make_params(d));
 }

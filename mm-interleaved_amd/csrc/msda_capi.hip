@@ -4,7 +4,6 @@
 #include "../../include/mmfs_msda.h"
 #include "msda_env.h"
 #include "msda_launch.h"
-#include "msda_gv_mma.h"
 #include "msda_plan.h"
 #include <cstring>
 #include <cstdlib>
@@ -41,7 +40,6 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->blocks4 = 0;
     d->table_status = nullptr;
     d->taps_algo = 0;
-    d->gv_skip[0] = d->gv_skip[1] = 0;
     d->taps_sorted = 0;
     return MMFS_OK;
 }
@@ -370,22 +368,6 @@ int mmfs_msda_backward_value_run(int dtype, const int64_t *shapes, const int64_t
 }
 
 // ---------------------------------------------------------------- hybrid entry points
-// the levels whose grad_value is sorted and reduced inside a workgroup (msda_gv_mma.hip): none when the caller says so
-static mmfs::gv::Table value_blocks_plan(int dtype, const mmfs::Dims &d, const int64_t *host_shapes,
-                                         const int64_t *host_start, unsigned flags)
-{
-    // opt-in (MMFS_BWD_VALUE_LDS_BLOCKS, or MMFS_GV_ALGO=on in the environment): measured slower than the sorted path on
-    // every shipped geometry (profiles/r03_experiments.md, r03m-r03o)
-    const char *algo = mmfs::knob_str(mmfs::K_GV_ALGO);
-    const bool env_on = algo && algo[0] == 'o' && algo[1] == 'n';
-    if ((flags & MMFS_BWD_VALUE_SORTED_ONLY) || !((flags & MMFS_BWD_VALUE_LDS_BLOCKS) || env_on)) {
-        mmfs::gv::Table t;
-        memset(&t, 0, sizeof(t));
-        return t;
-    }
-    return mmfs::gv::make_plan(dtype, d, host_shapes, host_start);
-}
-
 static mmfs::HybridPlan hybrid_plan(int dtype, const mmfs::Dims &d, const int64_t *host_shapes,
                                     const int64_t *host_start)
 {
@@ -400,31 +382,9 @@ int64_t mmfs_msda_backward_hybrid_workspace_bytes(int dtype, const int64_t *host
     if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
     if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
-    const mmfs::gv::Table gvt = value_blocks_plan(dtype, d, host_shapes, host_start, flags);
-    // (something for this entry point to do: a level for the dense taps product, or one for the workgroup-local grad_value)
-    if (!((flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active) && gvt.n_groups == 0) return 0;
-    return (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256 + mmfs::gv::workspace_bytes(gvt, d);
-}
-
-int64_t mmfs_msda_debug_value_plan(int dtype, const int64_t *host_shapes, const int64_t *host_start,
-                                   int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq, int64_t P,
-                                   unsigned flags, void *out, int64_t out_bytes)
-{
-    mmfs::Dims d;
-    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return MMFS_E_DIMS;
-    const mmfs::gv::Table t = value_blocks_plan(dtype, d, host_shapes, host_start, flags);
-    if (out && out_bytes >= (int64_t)sizeof(t)) memcpy(out, &t, sizeof(t));
-    return (int64_t)sizeof(t);
-}
-
-int mmfs_msda_backward_value_lds_levels(int dtype, const int64_t *host_shapes, const int64_t *host_start,
-                                        int64_t B, int64_t S, int64_t H, int64_t D,
-                                        int64_t L, int64_t Nq, int64_t P, unsigned flags)
-{
-    mmfs::Dims d;
-    if (!elem_size(dtype) || make_dims(B, S, H, D, L, Nq, P, &d)) return 0;
-    if (B * Nq * H * L * P == 0 || S == 0 || D == 0 || !use_tiled(dtype, d, flags)) return 0;
-    return value_blocks_plan(dtype, d, host_shapes, host_start, flags).n_levels;
+    // (something for this entry point to do: a level for the dense taps product)
+    if (!((flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active)) return 0;
+    return (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
 }
 
 int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shapes, const int64_t *start,
@@ -444,15 +404,11 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     d.lazy_attn = (flags & MMFS_BWD_LAZY_ZERO_ATTN) ? 1 : 0;
     d.taps_algo = (flags & MMFS_BWD_TAPS_LDS_LEVELS) ? 2 : (flags & MMFS_BWD_TAPS_ROW_GATHER) ? 1 : 0;
     if (d.taps_algo == 2 && !mmfs::taps_mma_supported(dtype, d)) return MMFS_E_UNSUPPORTED;
-    // small levels' grad_value: sorted and reduced inside a workgroup; the sorted backward leaves them alone
-    const mmfs::gv::Table gvt = value_blocks_plan(dtype, d, host_shapes, host_start, flags);
-    if ((flags & MMFS_BWD_VALUE_LDS_BLOCKS) && gvt.n_groups == 0) return MMFS_E_UNSUPPORTED;
-    d.gv_skip[0] = gvt.skip[0]; d.gv_skip[1] = gvt.skip[1];
-    bool sorted_levels = !host_shapes;          // some level is left to the sort + tile reduce
+    bool sorted_levels = !host_shapes;          // some level owns pixels: the sort + tile reduce have something to do
     if (host_shapes) {          // exact grid for the matrix-core grad_value reduce (else a bound is launched)
         int64_t nb4 = 0;
         for (int64_t l = 0; l < L; ++l)
-            if (host_shapes[2 * l] > 0 && host_shapes[2 * l + 1] > 0 && !((gvt.skip[(l >> 6) & 1] >> (l & 63)) & 1ull)) {
+            if (host_shapes[2 * l] > 0 && host_shapes[2 * l + 1] > 0) {
                 nb4 += ((host_shapes[2 * l] + 3) / 4) * ((host_shapes[2 * l + 1] + 3) / 4);
                 sorted_levels = true;
             }
@@ -460,14 +416,14 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     }
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;
-    if (!dense_taps && gvt.n_groups == 0) return MMFS_E_UNSUPPORTED;
+    if (!dense_taps) return MMFS_E_UNSUPPORTED;
     if (!value || !shapes || !start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
         return MMFS_E_NULLPTR;
     if (misaligned(value, 16) || misaligned(grad_out, 16) || misaligned(grad_value, 16) ||
         misaligned(loc, es) || misaligned(attn, es) || misaligned(grad_loc, es) || misaligned(grad_attn, es))
         return MMFS_E_ALIGN;
     const int64_t base = (mmfs::bwd_value_tiled_workspace_bytes(dtype, d) + 255) / 256 * 256;
-    if (!workspace || workspace_bytes < base + mmfs::gv::workspace_bytes(gvt, d)) return MMFS_E_NULLPTR;
+    if (!workspace || workspace_bytes < base) return MMFS_E_NULLPTR;
     if (misaligned(workspace, 16)) return MMFS_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
@@ -495,7 +451,6 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
     // (the plan rides in the prepare launch only when this very call also sorts; the hybrid path needs
     // MMFS_BWD_CANONICAL_LEVELS, so every grad_value row has an owner and no zero-fill pass is due)
     // (the prepare stage always plans: a staged pass then runs the very kernels of the one-call pass)
-    // (when the workgroup-local kernel serves every level, the sort and the tile reduce have nothing to do: not launched)
     bool planned = false;
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_PREPARE) && sorted_levels && !folded)
         e = mmfs::backward_value_prepare(dtype, loc, attn, workspace, d, st, shapes, start, &planned);
@@ -503,8 +458,6 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
         e = mmfs::backward_value_sort(dtype, shapes, start, workspace, d, st, true);
     if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_REDUCE) && sorted_levels)
         e = mmfs::backward_value_reduce(dtype, grad_out, grad_value, workspace, d, st, true);
-    if (e == hipSuccess && (stages & MMFS_HYB_BWD_VALUE_BLOCKS) && gvt.n_groups > 0)
-        e = mmfs::gv::backward_value(dtype, grad_out, loc, attn, grad_value, (char *)workspace + base, d, gvt, st);
     return (int)e;
 }
 

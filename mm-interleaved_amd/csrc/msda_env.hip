@@ -16,17 +16,13 @@ const KnobInfo kKnobs[K_COUNT] = {
     {"MMFS_FWD_Q8_QPR", "msda_fwd_q8: queries per run"},
     {"MMFS_FWD_WQ_LDS_KB", "msda_fwd_wq: LDS budget of a workgroup"},
     {"MMFS_FWD_WQ_QPW", "msda_fwd_wq: queries per run"},
-    {"MMFS_TAPS_ALGO", "grad_loc / grad_attn: vec (row gather) | mma (LDS levels on the matrix cores)"},
+    {"MMFS_TAPS_ALGO", "grad_loc / grad_attn: vec (row gather) | mma (LDS levels on the matrix cores); either one also refuses mmfs_msda_backward_sorted"},
     {"MMFS_TAPS_MMA_QPW", "msda_taps_mma: queries per run"},
     {"MMFS_MMA_GRID", "persistent kernels: this many workgroups whatever the shape"},
     {"MMFS_MMA_PERSIST", "0: one workgroup per run of queries instead of one per CU"},
     {"MMFS_HYBRID", "0: no dense small-level product for grad_loc / grad_attn (row gather for every level)"},
     {"MMFS_DOT_CHUNKS", "1: dense grad_loc / grad_attn also for levels of several 256-pixel chunks"},
     {"MMFS_VALUE_ALGO", "grad_value generation: block (2x2-block reduce) | pixel (first generation); default: matrix-core tile reduce"},
-    {"MMFS_GV_ALGO", "on: small levels' grad_value sorted inside a workgroup (msda_gv_mma: parity-green, measured slower)"},
-    {"MMFS_GV_MIN_NQ", "msda_gv_mma: fewest queries it is used for"},
-    {"MMFS_GV_TARGET_WGS", "msda_gv_mma: workgroups a launch aims at"},
-    {"MMFS_GV_MAX_SEGS", "msda_gv_mma: most segments per workgroup"},
     {"MMFS_PREPARE_IN_TAPS", "0: the grad_value half's opening job is a launch of its own, not hosted by msda_taps_mma"},
     {"MMFS_NT_MIN", "cell sort: tiles per level at least"},
     {"MMFS_SORT_WINDOW_KB", "cell sort: LDS window"},

@@ -49,7 +49,6 @@ struct PlanArgs {
     const void *loc_src, *attn_src;    // handed to the sort through the header (null: it reads the re-packed copies)
     int32_t *status;                   // where a table the sorted backward cannot serve is reported (device-accessible; may be null)
     uint32_t stamp;                    // header_stamp of the call's dimensions
-    uint64_t skip[2];                  // bit l: another kernel writes level l's grad_value rows (msda_gv_mma.hip): no tiles, no blocks
 };
 
 // The plan: one workgroup's job.  A lane per level for everything that divides (the 64-bit divisions of one
@@ -91,7 +90,6 @@ __device__ inline void plan_cells_body(const PlanArgs &pa, unsigned char *lds)
         r.nbx4 = (Wl + kTB - 1) / kTB; r.nby4 = (Hl + kTB - 1) / kTB;
         r.band = 0;
         LevelTiling lt = level_tiling(Hl64, Wl64, nt_min);
-        if ((pa.skip[(l >> 6) & 1] >> (l & 63)) & 1ull) lt.n = 0;       // served elsewhere: the level keeps its rows, owns no tile
         const int R = lt.R, C = lt.C, n = lt.n;
         if (n == 0) {
             r.nbx = r.nby = r.nbx4 = r.nby4 = 0;                   // (empty; or refused below: no tiles)
@@ -110,8 +108,7 @@ __device__ inline void plan_cells_body(const PlanArgs &pa, unsigned char *lds)
             LevelRow &r = rows[l];
             r.cbase = cbase; r.bbase = bbase; r.bbase4 = bbase4;
             tile_base[l] = (int)min(n, (int64_t)cap);
-            if ((pa.skip[(l >> 6) & 1] >> (l & 63)) & 1ull) covered += (int64_t)r.Hl * r.Wl;    // (its rows have an owner)
-            if (tile_n[l] == 0) continue;                                // (empty, served elsewhere, or refused below)
+            if (tile_n[l] == 0) continue;                                // (empty, or refused below)
             bbase4 += r.nbx4 * r.nby4;
             n += tile_n[l];
             if (tile_n[l] > 1) ++seamed;

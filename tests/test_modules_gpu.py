@@ -64,6 +64,30 @@ def test_mmfs_on_gpu_matches_reference(name, dtype, tol):
                 assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
 
 
+@pytest.mark.parametrize("name", ["mmfs_p8_llm_boxes", "mmfs_p8_sd_padded", "mmfs_p8_llm_boxes_padded_f32"])
+def test_mmfs_box_reference_points_and_padding_mask_on_gpu(name):
+    """MMFS.forward's box reference points (ops/modules/mmfs.py:251-258) and ``input_padding_mask`` (mmfs.py:165-172)
+    through the HIP op, fp32, against the reference's goldens: output and every gradient."""
+    from mmfs_amd.modules import MMFS
+    dtype, tol = torch.float32, 2e-5
+    z = load_golden(name)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = load_params(MMFS(**cfg), z).to(DEV, dtype)
+    q = T(z["query"], dtype).requires_grad_(True)
+    f = T(z["feat"], dtype).requires_grad_(True)
+    pad = torch.from_numpy(z["input_padding_mask"]).to(DEV) if "input_padding_mask" in z else None
+    out = m(q, T(z["reference_points"], dtype), f, T(z["spatial_shapes"], None), T(z["level_start_index"], None), pad,
+            T(z["attention_mask"], torch.float32))
+    assert rel_err(out, z["out"]) <= tol
+    out.backward(T(z["grad_out"], dtype))
+    assert rel_err(q.grad, z["grad_query"]) <= tol * 4
+    assert rel_err(f.grad, z["grad_feat"]) <= tol * 4
+    for k, p in m.named_parameters():
+        if "grad." + k in z:
+            assert rel_err(p.grad, z["grad." + k]) <= 1e-4, k
+
+
 # The fused sampling-plan kernel (csrc/mmfs_plan.hip) only takes P in {4, 8, 16}: these are the goldens that
 # reach it -- the decoders' real point count (P = 8: modeling_llama_mmfs.py:326-339, sd_mmfs.py:50-53) and the
 # north star's (P = 4), LLM flavour (centre reference point, 3-D mask with an all-masked row, decode slice)

@@ -57,6 +57,15 @@ def check(got, want, dtype, what=""):
         scale = max(1.0, float(np.abs(w).max())) if w.size else 1.0
         err = max_abs(g, w)
         assert err <= tol * scale, f"{what} {n}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+        if n in ("grad_loc", "grad_attn") and w.size:
+            # per element too (a bar relative to the LARGEST entry leaves the small entries of grad_loc
+            # -- range up to ~50 -- unconstrained): |err| <= tol * (|ref| + 0.05 * max|ref|)
+            g64 = np.asarray(g, dtype=np.float64)
+            w64 = np.asarray(w, dtype=np.float64).reshape(g64.shape)
+            fin = np.isfinite(w64)
+            excess = np.abs(g64 - w64)[fin] - tol * (np.abs(w64)[fin] + 0.05 * scale)
+            assert excess.size == 0 or float(excess.max()) <= 0.0, \
+                f"{what} {n}: an element is off by {float(excess.max()):.3e} more than {tol:.1e} * (|ref| + 0.05 * {scale:.3g})"
 
 
 def golden_inputs(z, dtype):
@@ -1010,96 +1019,6 @@ def test_staged_sort_and_reduce_on_a_foreign_workspace_do_nothing():
         torch.cuda.synchronize()
         assert bool((gv == 7.0).all())                          # nothing was written
     check(run_hip(x, torch.bfloat16, register=True), run_oracle(x), torch.bfloat16, "after staged calls on foreign workspaces")
-
-
-# grad_value of the small levels, sorted and reduced INSIDE a workgroup (csrc/msda_gv_mma.hip): the levels of at most
-# 32 (D = 128) / 64 (D = 64) blocks of 4x4 pixels leave the global cell sort; default on a registered level table from
-# 256 queries on, forced here (MMFS_BWD_VALUE_LDS_BLOCKS) on shapes of every kind.  ``target`` steers the host plan
-# (MMFS_GV_TARGET_WGS, read per call): many workgroups = one level per group and several query ranges per group (fp32
-# partial tiles, the last range adds them up); few = several levels per group, one range.
-GV_LDS_CASES = [
-    # B, H, D, Nq, P, shapes, target, min_nq
-    (1, 8, 128, 600, 4, [(64, 64), (32, 32), (16, 16), (8, 8)], 512, None),   # the north-star pyramid: 16^2, 8^2 served, three ranges each
-    (2, 3, 128, 333, 4, [(16, 16), (8, 8), (20, 20), (5, 7)], 4, None),       # every level served; blocks at ragged edges; two levels per group
-    (1, 2, 64, 300, 8, [(32, 32), (16, 16), (8, 8)] * 2, 1, None),            # the LLM path's tables, D = 64: four slots per wave, four levels per group
-    (1, 4, 64, 257, 3, [(9, 5), (40, 40), (3, 3), (1, 1), (2, 9)], 64, None), # degenerate levels, one left to the sort, a ragged last chunk of one query
-    (2, 8, 128, 128, 64, [(16, 16), (8, 8)], 512, 16),                        # the reference's speed-test shape: 64 points, chunks of 32 queries
-    (1, 2, 64, 260, 4, [(8, 8), (4, 4)], 2, None),                            # nothing left for the sort: its three stages are not launched
-    (3, 2, 128, 17, 4, [(12, 12), (6, 6)], 512, 16),                          # fewer queries than a chunk
-]
-
-
-@pytest.mark.parametrize("case", GV_LDS_CASES, ids=[f"B{c[0]}H{c[1]}D{c[2]}Nq{c[3]}P{c[4]}L{len(c[5])}" for c in GV_LDS_CASES])
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_lds_blocks_grad_value_matches_oracle(case, dtype, monkeypatch):
-    import MultiScaleDeformableAttention as MSDA
-    B, H, D, Nq, P, shapes, target, min_nq = case
-    monkeypatch.setenv("MMFS_GV_TARGET_WGS", str(target))
-    if min_nq is not None:
-        monkeypatch.setenv("MMFS_GV_MIN_NQ", str(min_nq))
-    monkeypatch.setattr(MSDA, "_value_algo", "lds")
-    x = make_inputs(B, H, D, Nq, P, shapes, seed=23, loc_range=(-0.15, 1.15), dtype=dtype)
-    x["loc"][0, 0, 0, 0, 0, 0] = float("nan")            # non-finite locations: no contribution
-    x["loc"][0, Nq // 2, 1 % H, -1, 0, 1] = float("inf")
-    x["attn"][0, Nq - 1, 0, -1] = 0.0                     # zero weights: not visited
-    x["loc"][B - 1, :, H - 1, -1, :, :] = 0.5              # a hot spot: every sample of one slab's last level in one cell
-    log = []
-    monkeypatch.setattr(MSDA, "_event_log", log)
-    got = run_hip(x, dtype, use_autograd=False, register=True)
-    monkeypatch.setattr(MSDA, "_event_log", None)
-    names = [n for n, _, _ in log]
-    assert "msda_bwd_value_blocks" in names, names
-    small = [h * w for h, w in shapes if ((h + 3) // 4) * ((w + 3) // 4) <= (32 if D == 128 else 64)]
-    assert ("msda_bwd_value_sort" in names) == (len(small) < len(shapes)), names
-    check(got, run_oracle(x), dtype, f"gv lds {case[:5]}")
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_lds_blocks_are_opt_in_and_agree_with_the_sorted_path(dtype, monkeypatch):
-    import MultiScaleDeformableAttention as MSDA
-    x = make_inputs(2, 4, 128, 300, 4, [(24, 24), (16, 16), (8, 8)], seed=29, loc_range=(-0.1, 1.1), dtype=dtype)
-    res = {}
-    for algo in ("auto", "lds", "sorted"):
-        monkeypatch.setattr(MSDA, "_value_algo", algo)
-        log = []
-        monkeypatch.setattr(MSDA, "_event_log", log)
-        res[algo] = run_hip(x, dtype, use_autograd=False, register=True)
-        monkeypatch.setattr(MSDA, "_event_log", None)
-        assert ("msda_bwd_value_blocks" in [n for n, _, _ in log]) == (algo == "lds")       # (measured slower: not the default)
-    want = run_oracle(x)
-    for algo in ("auto", "lds", "sorted"):
-        check(res[algo], want, dtype, algo)
-    # same products, fp32 sums in another order, one rounding to the storage type: a unit in the last place apart at most
-    a, b = res["lds"][1], res["sorted"][1]
-    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
-    assert np.all(np.abs(a - b) <= ulp * np.maximum(np.abs(a), np.abs(b)) + 1e-5 * np.abs(b).max())      # (+ cancellation)
-    # a table the shim has not seen on the host keeps the sorted path whatever is asked (the plan needs the host copy)
-    monkeypatch.setattr(MSDA, "_value_algo", "lds")
-    log = []
-    monkeypatch.setattr(MSDA, "_event_log", log)
-    fresh = run_hip(x, dtype, use_autograd=False, register=False)
-    monkeypatch.setattr(MSDA, "_event_log", None)
-    assert "msda_bwd_value_blocks" not in [n for n, _, _ in log]
-    check(fresh, want, dtype, "fresh")
-
-
-def test_lds_blocks_full_size_slab_against_the_sorted_path():
-    """The north-star shape, one batch item: every row of grad_value from the two paths within a unit in the last
-    place (the sorted path is pinned against the oracle at full size by its own test)."""
-    import MultiScaleDeformableAttention as MSDA
-    dtype = torch.bfloat16
-    x = make_inputs(1, 8, 128, 4096, 4, [(64, 64), (32, 32), (16, 16), (8, 8)], seed=31, dtype=dtype)
-    res = {}
-    for algo in ("lds", "sorted"):
-        MSDA._value_algo = algo
-        try:
-            res[algo] = run_hip(x, dtype, use_autograd=False, register=True)
-        finally:
-            MSDA._value_algo = "auto"
-    a, b = res["lds"][1], res["sorted"][1]
-    assert np.isfinite(a).all()
-    assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), np.abs(b)) + 1e-5 * np.abs(b).max())     # (+ cancellation)
-    assert np.abs(a).max() > 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

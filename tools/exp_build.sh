@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../mm-interleaved_amd/csrc"
 name=$1; flags=$2
 mkdir -p build/exp/$name
-for f in msda_env msda_fwd msda_fwd_mma msda_fwd_q8 msda_fwd_wq msda_taps_mma msda_gv_mma msda_bwd msda_bwd_value msda_bwd_block msda_bwd_tile msda_bwd_refused msda_dense mmfs_plan mmfs_bank mmfs_norm mmfs_query mmfs_linear msda_capi; do
+for f in msda_env msda_fwd msda_fwd_mma msda_fwd_q8 msda_fwd_wq msda_taps_mma msda_bwd msda_bwd_value msda_bwd_block msda_bwd_tile msda_bwd_refused msda_dense mmfs_plan mmfs_bank mmfs_norm mmfs_query mmfs_linear msda_capi; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function $flags -c $f.hip -o build/exp/$name/$f.o &
 done
 wait
