@@ -2,6 +2,7 @@
 #include "msda_env.h"
 #include "../../include/mmfs_msda.h"
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -43,16 +44,34 @@ struct Values {
     std::string text[K_COUNT];
     bool set[K_COUNT];
 };
-Values g_values;
-std::once_flag g_once;
+// The table the launch paths read is reached through one atomic pointer; a reload publishes a NEW table and never frees the
+// old one (a launch on another thread may still hold a pointer into its strings: ADVICE r5 -- reassigning the strings in
+// place was a data race).  Reloads are a test / measurement affair: a few hundred bytes each.
+std::atomic<const Values *> g_values{nullptr};
+std::mutex g_reload;
 
-void read_all()
+const Values *read_all()
 {
+    Values *v = new Values;
     for (int k = 0; k < K_COUNT; ++k) {
         const char *e = std::getenv(kKnobs[k].name);
-        g_values.set[k] = e != nullptr;
-        g_values.text[k] = e ? e : "";
+        v->set[k] = e != nullptr;
+        v->text[k] = e ? e : "";
     }
+    return v;
+}
+
+const Values *current()
+{
+    const Values *v = g_values.load(std::memory_order_acquire);
+    if (v) return v;
+    std::lock_guard<std::mutex> lock(g_reload);
+    v = g_values.load(std::memory_order_acquire);
+    if (!v) {
+        v = read_all();
+        g_values.store(v, std::memory_order_release);
+    }
+    return v;
 }
 
 }  // namespace
@@ -61,8 +80,8 @@ const KnobInfo &knob_info(int k) { return kKnobs[k]; }
 
 const char *knob_str(Knob k)
 {
-    std::call_once(g_once, read_all);
-    return g_values.set[k] ? g_values.text[k].c_str() : nullptr;
+    const Values *v = current();
+    return v->set[k] ? v->text[k].c_str() : nullptr;
 }
 
 int knob_int(Knob k, int dflt)
@@ -81,8 +100,8 @@ long long knob_ll(Knob k, long long dflt)
 
 extern "C" void mmfs_env_reload(void)
 {
-    std::call_once(mmfs::g_once, mmfs::read_all);
-    mmfs::read_all();
+    std::lock_guard<std::mutex> lock(mmfs::g_reload);
+    mmfs::g_values.store(mmfs::read_all(), std::memory_order_release);
 }
 
 extern "C" int mmfs_env_knob(int index, const char **name, const char **doc, const char **value)

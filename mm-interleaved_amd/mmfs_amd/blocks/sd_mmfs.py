@@ -19,6 +19,7 @@ import torch.utils.checkpoint as cp
 from torch import nn
 
 from ..bank import gather_bank
+from .. import graphed as _graphed
 from ..graphed import graphed_call, memory_is_plentiful
 from ..functions.linear_func import _split_k, token_linear
 from ..functions.query_func import QueryPrepFunction, TokensAddFunction, layout_supported, query_prep, tokens_add
@@ -274,7 +275,15 @@ class MMFSBlock(CacheInvalidation, nn.Module):
             if self.graph_checkpoints:
                 keep = self.graph_keeps_activations
                 if keep == "auto":
-                    keep = sample.is_cuda and memory_is_plentiful(sample.device)
+                    # decided ONCE per block and latched (asked on every forward, the answer is part of the key --
+                    # free memory crossing the mark mid-run recorded a second set of graphs next to the first, just as
+                    # memory became scarce); not asked at all where the call takes the plain path anyway
+                    keep = self.__dict__.get("_keeps_latched")
+                    if keep is None:
+                        if not (sample.is_cuda and _graphed.enabled) or torch.cuda.is_current_stream_capturing():
+                            keep = False
+                        else:
+                            keep = self.__dict__["_keeps_latched"] = bool(memory_is_plentiful(sample.device))
                 return graphed_call(self, self._inner, (sample, ms_feat, ms_feat_mask, spatial_shapes, value, image_ranks,
                                                         residual, normed), recompute=not keep, plain=plain)
             return plain()

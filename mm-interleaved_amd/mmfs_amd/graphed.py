@@ -51,7 +51,7 @@ except Exception:                                      # pragma: no cover
 
 import MultiScaleDeformableAttention as MSDA
 
-from .levels import cache_epoch, tensor_version
+from .levels import cache_epoch, hook_free, tensor_version
 
 enabled = True
 capture_after = 2            # eager calls with a key before it is recorded
@@ -64,14 +64,18 @@ capture_error_mode = "thread_local"
 trace = None                 # a callable(str): debugging aid
 
 _pools = {}                  # device index -> (graph memory pool shared by the recompute-mode graphs, the entries recorded into it)
-_stages = {}                 # (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument
+# (argument place, shape, stride, dtype, device) -> _Static shared by every entry that reads such an argument.  Held WEAKLY: the
+# entries that read a stage keep it alive (``_Entry.static``); when the last of them goes -- LRU eviction, a moved cache epoch,
+# a refused capture, the module itself -- so does the bank-sized buffer (a plain dict kept one device buffer per
+# distinct bank shape ever captured, for the life of the process)
+_stages = weakref.WeakValueDictionary()
 stats = {"captures": 0, "replays": 0, "eager_backward": 0, "refused": 0, "device_bound": 0}
 _recording = threading.Lock()        # one capture at a time in the process (a caller's threads; the autograd engine's thread)
 
 
 class _Static:
     """A buffer recorded graphs read.  ``gen`` counts its writes."""
-    __slots__ = ("t", "gen", "src", "ver")
+    __slots__ = ("t", "gen", "src", "ver", "__weakref__")
 
     def __init__(self, like, requires_grad=False):
         self.t = torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=like.device)
@@ -338,7 +342,10 @@ class _Entry:
         # copies: the graphs of all modules share one pool, and what is an OUTPUT here may be a transient of a graph that
         # was recorded earlier -- whose next replay (the previous block's backward) comes before autograd has consumed
         # this gradient (a projected bank's: at the very end of the backward pass)
-        return [None if g is None else g.clone() for g in self.gin] if self.pooled else self.gin
+        # (and in keep mode too: the static gradient buffers are overwritten by this entry's next backward replay -- a
+        # gradient someone keeps past that point, torch.autograd.grad's result or a hook's, must not change under them:
+        # ADVICE r5)
+        return [None if g is None else g.clone() for g in self.gin]
 
     def eager_backward(self, dyn, gouts):
         """The way back without the graphs (their buffers moved on since this call's forward): recompute from the
@@ -412,10 +419,12 @@ def _key(owner, args, recompute, grad):
         if isinstance(a, torch.Tensor):
             parts.append(ident.setdefault(id(a), i))
     for p in owner.parameters():
-        # a trainable parameter is read at its address every replay; a frozen one (and any, without gradients) may have
-        # been baked into something the recorded kernels read: its version counts too
-        parts.append((p.data_ptr(), p.dtype, p.requires_grad,
-                      tensor_version(p) if (not grad or not p.requires_grad) else -2))
+        # a trainable parameter is read at its address every replay, with or without gradients (graphed_call only runs in
+        # training mode, where no module keeps anything derived from a parameter: nothing is baked in) -- its VERSION must
+        # not be in the key: every optimizer.step() bumps it, and the no-grad forward of a reentrant-checkpointed decoder
+        # layer would re-record every step.  A frozen one may have been baked into something the recorded
+        # kernels read: its version counts.
+        parts.append((p.data_ptr(), p.dtype, p.requires_grad, -2 if p.requires_grad else tensor_version(p)))
     for b in owner.buffers():
         parts.append((b.data_ptr(), b.dtype, tensor_version(b)))
     for m in owner.modules():                          # the switches that choose a module's path (``_behaviour_flags``)
@@ -438,11 +447,23 @@ def memory_is_plentiful(dev):
     return hit[1]
 
 
+def _hooks_free(owner):
+    """No hook on the owner or on anything inside it (a replay runs no Python: hooks would fire at recording time only --
+    activation capture, profilers, parameter-gathering pre-hooks).  Asked once per (module, hook state): the
+    hook dictionaries' sizes are the state."""
+    sizes = tuple(len(m._forward_hooks) + len(m._forward_pre_hooks) + len(m._backward_hooks)
+                  + len(getattr(m, "_backward_pre_hooks", ())) for m in owner.modules())
+    hit = owner.__dict__.get("_graphed_hooks")
+    if hit is None or hit[0] != sizes:
+        hit = owner.__dict__["_graphed_hooks"] = (sizes, all(hook_free(m) for m in owner.modules()))
+    return hit[1] and hook_free(owner)             # (the process-wide hook lists are looked at every time)
+
+
 def graphed_call(owner, fn, args, recompute, plain):
     """``fn(*args)`` through recorded HIP graphs when this call's key has them, else ``plain()`` -- the caller's own
     statement of the same call (``fn(*args)``, or it under ``torch.utils.checkpoint``).  ``owner``: the module whose
     parameters ``fn`` reads."""
-    if _eligible(args) is None:
+    if _eligible(args) is None or not _hooks_free(owner):
         return plain()
     grad = torch.is_grad_enabled()
     try:

@@ -70,3 +70,35 @@ def test_memory_is_plentiful_asks_the_driver_at_most_once_a_second(monkeypatch):
     graphed._plenty[0] = (graphed._plenty[0][0] - 2.0, True)          # (a second later)
     assert not graphed.memory_is_plentiful(dev) and len(calls) == 2
     graphed._plenty.clear()
+
+
+def test_a_trainable_parameters_version_is_not_in_the_key():
+    """``optimizer.step()`` bumps a trainable parameter's version; the recorded kernels read it at its address,
+    so neither the with-gradients nor the no-grad key of a call may change with it (a frozen parameter's version may have
+    been baked in: it stays in the key)."""
+    from mmfs_amd import graphed
+    m = torch.nn.Linear(4, 4)
+    m.bias.requires_grad_(False)
+    x = torch.zeros(2, 4)
+    keys = {g: graphed._key(m, (x,), False, g) for g in (True, False)}
+    with torch.no_grad():
+        m.weight.add_(1.0)                                  # what an optimizer step does
+    assert all(graphed._key(m, (x,), False, g) == keys[g] for g in (True, False))
+    with torch.no_grad():
+        m.bias.add_(1.0)                                    # a frozen parameter moved: another key
+    assert all(graphed._key(m, (x,), False, g) != keys[g] for g in (True, False))
+
+
+def test_shared_stages_are_held_weakly():
+    """the bank-sized static copies shared between recorded calls live as long as an entry that reads them."""
+    import weakref
+    from mmfs_amd import graphed
+    assert isinstance(graphed._stages, weakref.WeakValueDictionary)
+    s = graphed._Static(torch.zeros(3))
+    graphed._stages[("probe",)] = s
+    assert ("probe",) in graphed._stages
+    del s
+    import gc
+    gc.collect()
+    assert ("probe",) not in graphed._stages
+

@@ -351,3 +351,42 @@ def test_a_device_bound_call_is_not_replayed():
     assert graphed.stats["refused"] == before["refused"]
     entry, = layer.__dict__["_graphed"].values()
     assert entry.state == -2 and not hasattr(entry, "fwd")
+
+
+def test_optimizer_steps_between_calls_do_not_re_record(monkeypatch):
+    """the key of a recorded call held the VERSION of trainable parameters whenever gradients were disabled -- the
+    no-grad forward of a reentrant-checkpointed decoder layer -- and every ``optimizer.step()`` bumps it: each layer re-recorded
+    every step.  Trainable parameters are in the key by address only: with an optimizer step between the steps the captures
+    stay flat and the replays continue (and the results follow the moved weights: the graphs read them where they are)."""
+    import torch.utils.checkpoint as cp
+    from mmfs_amd import graphed
+    layer = llama_layer(torch.float32)
+    twin = copy.deepcopy(layer)
+    twin.graph_training_calls = False
+    B, Lq, n, hw = 2, 33, 2, 64 + 16 + 4
+    g = torch.Generator().manual_seed(4)
+    hidden = torch.randn(B, Lq, 512, generator=g).to(DEV)
+    feats = torch.randn(B, n, hw, 128, generator=g).to(DEV)
+    mask = torch.ones(B, Lq, n, device=DEV)
+    go = torch.randn(B, Lq, 512, generator=g).to(DEV)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-3) for m in (layer, twin)]
+
+    def step(m, opt):
+        opt.zero_grad(set_to_none=True)
+        x = hidden.clone().requires_grad_(True)
+        f = feats.clone().requires_grad_(True)
+        y = cp.checkpoint(lambda h, v, c: m(h, v, c, residual=h), x, f, mask, use_reentrant=True)
+        y.backward(go)
+        opt.step()
+        return y.detach()
+
+    for _ in range(4):                                     # warm-up + recording
+        step(layer, opts[0]); step(twin, opts[1])
+    before = dict(graphed.stats)
+    for _ in range(6):
+        got = step(layer, opts[0]); want = step(twin, opts[1])
+    assert graphed.stats["captures"] == before["captures"], (before, graphed.stats)
+    assert graphed.stats["replays"] >= before["replays"] + 6, (before, graphed.stats)
+    assert graphed.stats["refused"] == before["refused"]
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
