@@ -224,8 +224,11 @@ __device__ __host__ inline int tile_local_blocks(const CTile &tl, const LevelRow
     while (by_hi < lr.nby4 && (kTB * by_hi + kTB < lr.Hl ? kTB * by_hi + kTB : lr.Hl) < tl.yb) ++by_hi;
     return (by_hi - *by_lo) * lr.nbx4;
 }
+// TS (Dims::taps_sorted, a compile-time property of the sort kernel that plans: the sort's two-vector variants have no
+// register to spare for a run-time flag): also the owned prefix of each run, for msda_bwd_taps_sorted.hip
+template <bool TS>
 __device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTile &tl, const LevelRow &lr, int by, int bx,
-                                                        const uint32_t *off, int64_t base, TapsDesc *xd = nullptr)
+                                                        const uint32_t *off, int64_t base, TapsDesc &xd)
 {
     const int tw = tl.Wl + 1;
     int64_t n = 0;
@@ -233,25 +236,26 @@ __device__ __forceinline__ int64_t describe_local_block(TileDesc &td, const CTil
     for (int r = 0; r <= kTB; ++r) {
         const int cy = kTB * by + r;
         td.first[r] = 0; td.cnt[r] = 0;
-        if (xd) xd->ocnt[r] = 0;
+        if (TS) xd.ocnt[r] = 0;
         if (cy <= lr.Hl) {
             const int p0 = (cy - tl.ya) * tw + kTB * bx, p1 = (cy - tl.ya) * tw + min(kTB * bx + kTB + 1, tw);
             td.first[r] = (int)(uint32_t)(base + off[p0]);
             td.cnt[r] = (int)(off[p1] - off[p0]);
             n += td.cnt[r];
-            if (xd && (r < kTB || by == lr.nby4 - 1)) {
+            if (TS && (r < kTB || by == lr.nby4 - 1)) {
                 const int q1 = bx == lr.nbx4 - 1 ? p1 : (cy - tl.ya) * tw + kTB * bx + kTB;
-                xd->ocnt[r] = (int)(off[q1] - off[p0]);
+                xd.ocnt[r] = (int)(off[q1] - off[p0]);
             }
         }
     }
-    if (xd) { xd->level = tl.level; xd->pad[0] = xd->pad[1] = 0; }
+    if (TS) { xd.level = tl.level; xd.pad[0] = xd.pad[1] = 0; }
     td.hw = ((uint32_t)lr.Hl << 16) | (uint32_t)lr.Wl;
     td.lstart = lr.lstart;
     td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
     td.parts = 1; td.pbase = 0; td.arrived = 0;
     return n;
 }
+template <bool TS>
 __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Dims &d, int64_t bh, const CTile &tl, const LevelRow &lr,
                                                const uint32_t *off, int64_t base, int tid, int nthreads)
 {
@@ -265,8 +269,8 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
         const int by = by_lo + i / lr.nbx4, bx = i % lr.nbx4;
         TileDesc td;
         TapsDesc xd;
-        const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base, a.xdesc ? &xd : nullptr);
-        if (a.xdesc) a.xdesc[bh * a.blocks_bound + lr.bbase4 + by * lr.nbx4 + bx] = xd;
+        const int64_t n = describe_local_block<TS>(td, tl, lr, by, bx, off, base, xd);
+        if (TS) a.xdesc[bh * a.blocks_bound + lr.bbase4 + by * lr.nbx4 + bx] = xd;
         queue_block(a, d, bh, lr.bbase4 + by * lr.nbx4 + bx, td, n);
     }
     if (tid >= nloc) return pd;
@@ -274,8 +278,8 @@ __device__ inline PendingBlock plan_tile_begin(const TileReduceArgs &a, const Di
     const int blk = lr.bbase4 + by * lr.nbx4 + bx;
     TileDesc td;
     TapsDesc xd;
-    const int64_t n = describe_local_block(td, tl, lr, by, bx, off, base, a.xdesc ? &xd : nullptr);
-    if (a.xdesc) a.xdesc[bh * a.blocks_bound + blk] = xd;
+    const int64_t n = describe_local_block<TS>(td, tl, lr, by, bx, off, base, xd);
+    if (TS) a.xdesc[bh * a.blocks_bound + blk] = xd;
     a.tdesc[bh * a.blocks_bound + blk] = td;
     const uint32_t parts = (uint32_t)((n + tile_chunk(d) - 1) / tile_chunk(d));
     if (parts > 1) {
@@ -310,6 +314,7 @@ __device__ inline void plan_tile_finish(const TileReduceArgs &a, const Dims &d, 
 // The blocks of one (b, h) slice that no tile could plan by itself.  Run by the LAST sort workgroup of the
 // slice (the cell table it reads was written by the slice's sort workgroups, which share an XCD and so an
 // L2): thread `tid` of `nthreads` takes blocks tid, tid + nthreads, ...
+template <bool TS>
 __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d, int64_t bh, int tid, int nthreads)
 {
     const LevelRow *lv = level_rows(a.hdr);
@@ -350,7 +355,7 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
 #pragma unroll
                 for (int dx = 0; dx <= kTB; ++dx) {
                     c += (int)ent[dy][dx].y;
-                    if (dx < kTB || bx == lr.nbx4 - 1) oc += (int)ent[dy][dx].y;
+                    if (TS && (dx < kTB || bx == lr.nbx4 - 1)) oc += (int)ent[dy][dx].y;
                 }
                 td.cnt[dy] = c;
                 if (dy < kTB || by == lr.nby4 - 1) xd.ocnt[dy] = oc;
@@ -360,7 +365,7 @@ __device__ inline void plan_slice_blocks(const TileReduceArgs &a, const Dims &d,
             td.lstart = lr.lstart;
             td.byx = ((uint32_t)by << 16) | (uint32_t)bx;
         }
-        if (a.xdesc) a.xdesc[bh * a.blocks_bound + blk] = xd;
+        if (TS) a.xdesc[bh * a.blocks_bound + blk] = xd;
         queue_block(a, d, bh, blk, td, n);
     }
 }

@@ -266,7 +266,7 @@ constexpr bool kWindowRounds = MMFS_SORT_WINDOW_ROUNDS != 0;       // a kept sca
 constexpr uint32_t kNoCell = 0xffffffffu;
 constexpr int kCellBits = 13;
 static_assert(kMaxTileCells <= (1 << kCellBits), "a cell index and a rank share one word");
-template <typename T, int NV, bool COMPACT, int THREADS>
+template <typename T, int NV, bool COMPACT, int THREADS, bool TS>
 struct KeptScan {
     typedef Vec16<T> V;
     static constexpr int VEC = V::N, SPV = V::N / 2;
@@ -310,8 +310,8 @@ struct KeptScan {
                                           T *__restrict__ g_loc = nullptr, T *__restrict__ g_attn = nullptr)      // (after load())
     {
         const int tw = tl.xb - tl.xa;
-        const bool ts = d.taps_sorted != 0, keep_zero = ts && !d.lazy_attn;
-        const bool zero_writer = ts && g_loc != nullptr && tl.ya == 0 && tl.xa == 0;
+        const bool keep_zero = TS && !d.lazy_attn;
+        const bool zero_writer = TS && g_loc != nullptr && tl.ya == 0 && tl.xa == 0;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const int q = (int)threadIdx.x + u * THREADS;                // (virtual query)
@@ -326,7 +326,7 @@ struct KeptScan {
                     bool dead = false;
                     const int pl = q < d.Nq * G ? cell_in_tile(l[2 * i], l[2 * i + 1], a[i], tl, tw, keep_zero, &dead) : -1;
                     key[u][v][i] = pl < 0 ? kNoCell : ((uint32_t)pl | (atomicAdd(&off[pl], 1u) << kCellBits));
-                    if (zero_writer && dead && q < d.Nq * G) {
+                    if (TS && zero_writer && dead && q < d.Nq * G) {
                         const int64_t s = ((((int64_t)b * d.Nq + qq) * d.H + h) * d.L + tl.level) * d.P + ((q - qq * G) * NV + v) * SPV + i;
                         g_attn[s] = (T)0.f;
                         g_loc[2 * s] = (T)0.f; g_loc[2 * s + 1] = (T)0.f;
@@ -344,7 +344,7 @@ struct KeptScan {
                                           uint32_t s0 = 0u, uint32_t cap = 0xffffffffu, bool reload = true)
     {
         if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
-        const bool ts = COMPACT && d.taps_sorted != 0;
+        constexpr bool ts = COMPACT && TS;
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             const uint32_t qv = threadIdx.x + u * THREADS;
@@ -409,7 +409,7 @@ namespace {
 // the chain of dependent round trips a tile is (header, samples, counters, the level's cursor, records) overlaps with
 // three other tiles' -- at the ViT-Adapter injector's shape (512 slices x 3 levels of ~1000 samples) a 1024-lane
 // workgroup spends 7 us on a tile whatever its size, six rounds of them (tools/sort_prof.py injector, r04zw)
-template <typename T, int NV, bool COMPACT, int THREADS>
+template <typename T, int NV, bool COMPACT, int THREADS, bool TS>
 __global__ void __launch_bounds__(THREADS)
 msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
@@ -458,7 +458,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     // (only where the launch expects windows: into memory, the two-scan path's stores are the faster -- SD 512 px
     // geometry, 32768 samples per level: 151 us against 196)
     const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= THREADS * kScanUnroll && win_bytes > kMaxTileCells * 4u;
-    KeptScan<T, KNV, COMPACT, THREADS> ks;
+    KeptScan<T, KNV, COMPACT, THREADS, TS> ks;
     ks.G = tp.vgroups;
 
     // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
@@ -499,7 +499,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     }
     PendingBlock pending;
     pending.blk = -1;
-    if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, THREADS);
+    if (ta.th != nullptr && lr.band > 0) pending = plan_tile_begin<TS>(ta, d, (int64_t)b * d.H + h, tl, lr, off, base, tid, THREADS);
     SPROF(3);
     // (a kept scan whose records exceed the window places them window by window: the records of a window are
     // consecutive slots, so each window leaves as one coalesced copy)
@@ -563,7 +563,7 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
         __syncthreads();
         SPROF(5);
         if (arrived == (uint32_t)hdr->n_tiles - 1u)
-            plan_slice_blocks(ta, d, (int64_t)b * d.H + h, tid, THREADS);
+            plan_slice_blocks<TS>(ta, d, (int64_t)b * d.H + h, tid, THREADS);
         SPROF(6);
     }
     SPROF_WG(2);
@@ -1210,6 +1210,10 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     int hgroup = env_hg >= 0 ? std::min(env_hg, 4) : ((int64_t)d.L * d.P * (int64_t)sizeof(T) <= 32 ? 4 : 1);
     while (hgroup > 1 && d.H % hgroup) --hgroup;
     tp.hgroup = std::max(hgroup, 1);
+    // (the grid's stride: the exact tile count when the caller knows the level table on the host -- the workgroups of a
+    // bound-sized grid past the plan's tile count return at once, but 1024-lane workgroups are not free to start: north
+    // star, 26 places per slice for 4 tiles: sort 35.7 -> 31.1 us, r06j)
+    if (d.tiles_hint > 0 && d.tiles_hint <= tp.tiles_bound) tp.tiles_bound = d.tiles_hint;
     int64_t blocks = (int64_t)d.B * d.H * tp.tiles_bound;
     if (tp.hgroup > 1) blocks = ((int64_t)d.B * (d.H / tp.hgroup) + 7) / 8 * 8 * tp.hgroup * tp.tiles_bound;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -1221,15 +1225,20 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
     const uint32_t win = sort_window_bytes(d, tp, compact);
     TileReduceArgs ta = tile_args(sc, d);
     ta.g_loc = g_loc; ta.g_attn = g_attn;
-    auto go = [&](auto tag_compact, auto tag_threads) {
+    auto go_ts = [&](auto tag_compact, auto tag_threads, auto tag_ts) {
         constexpr bool C = decltype(tag_compact)::value;
         constexpr int THREADS = decltype(tag_threads)::value;
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, C, THREADS>),
+        constexpr bool TS = decltype(tag_ts)::value && C && NV > 0;       // (only the kept scan of the compact records serves it)
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, C, THREADS, TS>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
         (void)once;
-        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, C, THREADS>), dim3((unsigned)blocks), dim3(THREADS), win, st,
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, C, THREADS, TS>), dim3((unsigned)blocks), dim3(THREADS), win, st,
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                            cell_stride_of(d), win, ta);
+    };
+    auto go = [&](auto tag_compact, auto tag_threads) {
+        if (d.taps_sorted) go_ts(tag_compact, tag_threads, std::true_type());
+        else go_ts(tag_compact, tag_threads, std::false_type());
     };
     const int lanes = sort_lanes(d, vgroups, NV);
     typedef std::integral_constant<bool, sizeof(T) == 2> Compact;
@@ -1410,6 +1419,16 @@ bool taps_sorted_supported(int dtype, const Dims &d)
     if (d.P <= 0 || (d.P & (d.P - 1)) || (int64_t)d.Nq * d.P > 65536) return false;
     if (const char *e = knob_str(K_TAPS_ALGO)) if (e[0] == 'v' || e[0] == 'm' || e[0] == 'g') return false;     // vec / mma / gather
     return sort_keeps_samples(dtype, d, make_params(d));
+}
+
+// Tiles the plan will make for a level table the HOST knows (Dims::tiles_hint): the plan's own rule per level.
+int sort_tiles_exact(int dtype, const Dims &d, const int64_t *host_shapes)
+{
+    if (!host_shapes || !bwd_value_block_supported(dtype, d)) return 0;
+    const TileParams tp = make_params(d);
+    int64_t n = 0;
+    for (int l = 0; l < d.L; ++l) n += level_tiling(host_shapes[2 * l], host_shapes[2 * l + 1], tp.nt_min).n;
+    return n > 0 && n <= tp.tiles_bound ? (int)n : 0;
 }
 
 // the pieces of the workspace msda_bwd_taps_sorted.hip reads

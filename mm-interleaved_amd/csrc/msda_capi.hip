@@ -41,6 +41,7 @@ int make_dims(int64_t B, int64_t S, int64_t H, int64_t D, int64_t L, int64_t Nq,
     d->table_status = nullptr;
     d->taps_algo = 0;
     d->taps_sorted = 0;
+    d->tiles_hint = 0;
     return MMFS_OK;
 }
 
@@ -413,6 +414,7 @@ int mmfs_msda_backward_hybrid(int dtype, const void *value, const int64_t *shape
                 sorted_levels = true;
             }
         d.blocks4 = (int)std::min<int64_t>(nb4, 0x3fffffff);
+        d.tiles_hint = mmfs::sort_tiles_exact(dtype, d, host_shapes);
     }
     const mmfs::HybridPlan plan = hybrid_plan(dtype, d, host_shapes, host_start);
     const bool dense_taps = (flags & MMFS_BWD_DENSE_TAPS) && plan.dots_active;

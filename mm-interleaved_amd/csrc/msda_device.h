@@ -20,6 +20,7 @@ struct Dims {
     int blocks4;    // backward: 4x4 pixel blocks of all levels when the caller knows the level table on the host (else 0)
     int32_t *table_status;   // backward, level table checked on the device: where the plan reports a table it cannot serve (or null)
     int taps_algo;  // backward, grad_loc / grad_attn: 0 the library chooses, 1 row gather (+ dense small levels), 2 LDS-resident levels
+    int tiles_hint;          // backward: sort tiles of all levels when the caller knows the level table on the host (else 0: a bound is launched)
     int taps_sorted;         // backward: grad_loc / grad_attn come from the cell-sorted records too (msda_bwd_taps_sorted.hip): the sort keeps
                              // zero-weight samples (unless lazy_attn), its records carry query * P + point, it zeroes the gradients of samples without a record
 };

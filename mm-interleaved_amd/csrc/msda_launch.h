@@ -86,6 +86,7 @@ hipError_t backward_value_block_sort(int dtype, const int64_t *shapes, const int
 // grad_loc / grad_attn from the cell-sorted records: a wave per 4x4 block of cells, the block's 5x5 pixel rows of value as one
 // matrix-core operand, the records' grad_out rows as the other (d.taps_sorted: the sort writes what this needs).
 // Order of a backward on this route: prepare (plan), sort, taps_sorted, reduce.                 [msda_bwd_taps_sorted.hip]
+int sort_tiles_exact(int dtype, const Dims &d, const int64_t *host_shapes);      // 0: unknown (no host table / not the block generation)
 bool taps_sorted_supported(int dtype, const Dims &d);
 hipError_t backward_taps_sorted(int dtype, const void *value, const void *grad_out, void *grad_loc, void *grad_attn,
                                 void *workspace, const Dims &d, hipStream_t st);
