@@ -323,6 +323,7 @@ _E_UNSUPPORTED = -5
 # MMFS_TAPS_ROUTE=sorted in the environment takes it wherever it applies, for a whole process (measurements).
 _taps_algo = "auto"
 _taps_prefer_sorted = os.environ.get("MMFS_TAPS_ROUTE") == "sorted"      # wherever it applies, silently not elsewhere
+route_counts = {"sorted": 0}                  # backward calls that took mmfs_msda_backward_sorted (tests: "the route ran")
 _TAPS_FLAGS = {"auto": 0, "gather": _BWD_TAPS_ROW_GATHER, "lds": _BWD_TAPS_LDS_LEVELS, "sorted": 0}
 
 # tests / measurements: "auto" | "atomic" (force the float-atomic path)
@@ -498,6 +499,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 srt_bytes = _ws_cache[skey] = _lib.mmfs_msda_backward_sorted_workspace_bytes(code, *dims, flags)
         _require(srt_bytes > 0 or _taps_algo != "sorted", "taps algo 'sorted': mmfs_msda_backward_sorted does not apply to these arguments")
         if srt_bytes > 0:
+            route_counts["sorted"] += 1
             ws = torch.empty(srt_bytes, dtype=torch.uint8, device=value.device)
             hs = info[1]
             blocks4 = int((((hs[:, 0] + 3) // 4) * ((hs[:, 1] + 3) // 4))[(hs[:, 0] > 0) & (hs[:, 1] > 0)].sum())

@@ -20,6 +20,7 @@ TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 1e-3, torch.bfl
 
 
 BIG = False
+SORTED = False     # round 6: every case prefers the backward on the cell-sorted records where it applies (mmfs_msda_backward_sorted)
 WAVES = False      # round 5: every case a 16-bit head of 128 channels through the forward's fourth kernel (csrc/msda_fwd_wq.hip)
 
 
@@ -85,6 +86,9 @@ def one_case(rng, idx):
         os.environ["MMFS_VALUE_ALGO"] = algo
     MSDA._hybrid = hybrid
     MSDA._bwd_algo = "atomic" if rng.random() < 0.08 else "auto"
+    # round 6: the backward on the cell-sorted records (mmfs_msda_backward_sorted) wherever it applies -- a registered table,
+    # 16-bit storage, P a power of two, the sort's kept scan -- silently the other routes elsewhere
+    MSDA._taps_prefer_sorted = SORTED or rng.random() < 0.3
     # round 3's routes: the grad_value plan hosted by the taps kernels or launched on its own; a small sort window (records
     # placed window by window); the scalar scan for queries of many points
     os.environ["MMFS_PREPARE_IN_TAPS"] = rng.choice(["0", "1", "1"])
@@ -102,7 +106,7 @@ def one_case(rng, idx):
     MSDA.reload_env()                        # (the library reads its knobs once: csrc/msda_env.h)
     dev = lambda t: t.to("cuda", dtype) if t.is_floating_point() else t.to("cuda")
     desc = (f"#{idx} {str(dtype)[6:]} B{B} H{H} D{D} P{P} Nq{Nq} {shapes} {dist} hybrid={hybrid} registered={registered} "
-            f"value={algo} bwd={MSDA._bwd_algo} fwd={MSDA._fwd_algo}")
+            f"value={algo} bwd={MSDA._bwd_algo} fwd={MSDA._fwd_algo} sorted={MSDA._taps_prefer_sorted}")
     dsh, dst = dev(sh), dev(st)
     if registered:
         MSDA.register_level_tables(dsh, dst, S, sh.numpy(), st.numpy())
@@ -144,7 +148,8 @@ def one_case(rng, idx):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+    BIG = len(sys.argv) > 3 and "big" in sys.argv[3:]
+    SORTED = "sorted" in sys.argv[3:]
     rng = random.Random(seed)
     fails = 0
     for i in range(n):

@@ -24,6 +24,7 @@ def restore_knobs():
     keep = (MSDA._hybrid, MSDA._bwd_algo, {k: v for k, v in os.environ.items() if k.startswith("MMFS_")}, MSDA._fwd_algo)
     yield
     MSDA._hybrid, MSDA._bwd_algo, MSDA._fwd_algo = keep[0], keep[1], keep[3]
+    MSDA._taps_prefer_sorted = False
     for k in [k for k in os.environ if k.startswith("MMFS_")]:      # (every knob the fuzzer set)
         del os.environ[k]
     os.environ.update(keep[2])
@@ -31,13 +32,19 @@ def restore_knobs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("big,n,seed", [(False, 120, 7), (True, 16, 8), ("waves", 80, 9), ("waves-big", 12, 10)],
-                         ids=["small", "big", "waves", "waves-big"])
+@pytest.mark.parametrize("big,n,seed", [(False, 120, 7), (True, 16, 8), ("waves", 80, 9), ("waves-big", 12, 10),
+                                        ("sorted", 100, 11), ("sorted-big", 16, 12)],
+                         ids=["small", "big", "waves", "waves-big", "sorted", "sorted-big"])
 def test_random_cases_match_oracle(big, n, seed, restore_knobs):
     fz = _fuzz()
-    fz.WAVES = isinstance(big, str)                  # (round 5: 16-bit heads of 128 channels, the forward's fourth kernel forced)
-    big = big is True or big == "waves-big"
+    fz.WAVES = isinstance(big, str) and big.startswith("waves")    # (round 5: 16-bit heads of 128 channels, the forward's fourth kernel forced)
+    fz.SORTED = isinstance(big, str) and big.startswith("sorted")  # (round 6: the backward on the cell-sorted records wherever it applies)
+    big = big is True or (isinstance(big, str) and big.endswith("-big"))
     fz.BIG = big
     rng = random.Random(seed)
+    import MultiScaleDeformableAttention as MSDA
+    took = MSDA.route_counts["sorted"]
     bad = [r for r in (fz.one_case(rng, seed * 100000 + i) for i in range(n)) if r.startswith("FAIL")]
     assert not bad, "\n".join(bad)
+    if fz.SORTED:               # (a registered table, 16-bit storage, P a power of two >= 4: a fifth of the cases or more)
+        assert MSDA.route_counts["sorted"] - took >= n // 8, (MSDA.route_counts["sorted"] - took, n)
