@@ -47,4 +47,5 @@ def test_random_cases_match_oracle(big, n, seed, restore_knobs):
     bad = [r for r in (fz.one_case(rng, seed * 100000 + i) for i in range(n)) if r.startswith("FAIL")]
     assert not bad, "\n".join(bad)
     if fz.SORTED:               # (a registered table, 16-bit storage, P a power of two >= 4: a fifth of the cases or more)
-        assert MSDA.route_counts["sorted"] - took >= n // 8, (MSDA.route_counts["sorted"] - took, n)
+        # (the big cases mostly fall outside it: 4097 queries, fp32 / fp64 storage, the older grad_value generations forced)
+        assert MSDA.route_counts["sorted"] - took >= (1 if big else n // 8), (MSDA.route_counts["sorted"] - took, n)
