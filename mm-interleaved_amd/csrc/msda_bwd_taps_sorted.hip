@@ -68,7 +68,12 @@ template <int D> struct TsGeom {
     static constexpr int SLOT = kKS * RB;          // bytes of a row slot
     static constexpr int ROWS_BYTES = 2 * SLOT;    // one slot being multiplied, one in flight
     static constexpr int REC_BYTES = 2 * kRecBatch * 8;       // per batch: 64 first words, then 64 second words
-    static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES;
+    // the step's dots D[record][pixel] (fp32) on their way from the accumulator layout (a lane = a record x a pixel ROW) to
+    // the lane that needs them (a lane = a record x a CORNER): 16 records at a pitch of 36 words (the two 16-byte stores of
+    // the 8 lanes of a store phase fall into 8 x 4 different banks)
+    static constexpr int DOT_PITCH = 36 * 4;
+    static constexpr int DOT_BYTES = kKS * DOT_PITCH;
+    static constexpr int LDS_BYTES = ROWS_BYTES + REC_BYTES + DOT_BYTES;
     // Channel chunk of lane group g in product t of the chain: 4 t + g (both operands).  Row r of a slot stores its logical
     // chunk c at position c ^ swz(r) (applied to the DMA's SOURCE address: the LDS image of a DMA is lane-linear), which
     // makes the ds_read_b128 of the B operand -- 16 lanes = 8 + 8 rows at two neighbouring chunks per LDS cycle -- free
@@ -126,6 +131,7 @@ __device__ __forceinline__ float add_rows32(float x)
 // c ? a : b on values that are already there: a v_cndmask, never a branch (a conditional expression whose arms are
 // expressions becomes control flow under exec masks -- the first build of this kernel spent its time there)
 __device__ __forceinline__ float sel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ int sel_i(bool c, int a, int b) { return c ? a : b; }
 
 struct TsItem { int b, h, part; };
 
@@ -143,7 +149,7 @@ __device__ __forceinline__ void taps_item(const T *__restrict__ value, const T *
 {
     typedef TsGeom<D> G;
     typedef DotMma<T> M;
-    unsigned char *rows = lds, *recs = lds + G::ROWS_BYTES;
+    unsigned char *rows = lds, *recs = lds + G::ROWS_BYTES, *dots = recs + G::REC_BYTES;
     const int lane = threadIdx.x;
     TSPROF_DECL;
     const int Hl = (int)(td.hw >> 16), Wl = (int)(td.hw & 0xffffu);
@@ -166,34 +172,34 @@ __device__ __forceinline__ void taps_item(const T *__restrict__ value, const T *
     const int y00 = kTB * by - 1, x00 = kTB * bx - 1;              // the 5x5's first pixel
 
     // ---- the block's 25 value rows as A operands: group 0 = rows 0..3 x columns 0..3 (m = 4 py + px), group 1 holds, for
-    // m = 4 jj + s: s = 0 pixel (jj, 4), s = 1 pixel (4, jj), s = 2 pixel (4, 4) (jj = 0 only), else nothing
-    s16x8 va[2][G::KT];
+    // m = 4 jj + s: s = 0 pixel (jj, 4), s = 1 pixel (4, jj), s = 2 pixel (4, 4) (jj = 0 only), else nothing.
+    // They travel like the grad_out rows: global -> LDS by DMA, whole rows per 16 / 8 / 4 lanes (loaded straight into the
+    // operand layout -- a lane = 16 bytes of "its" row -- four consecutive lanes ask for four different rows and the texture
+    // path serves 16 bytes per clock instead of 64: 512 clocks per work item, as much as eight steps' row requests), into the
+    // row slots (free until the first step's rows are asked for), operand row r = 16 g + m at row r, chunks swizzled as the
+    // slots' rows are; a pixel that is not there (outside the map, an unused operand row) moves nothing and is masked at the read.
+    auto pixel_of_row = [&](int r, int &y, int &x) -> bool {
+        const int g = r >> 4, jj = (r >> 2) & 3, sx = r & 3;
+        const int py = g == 0 ? jj : (sx == 0 ? jj : 4), px = g == 0 ? sx : (sx == 0 ? 4 : sx == 1 ? jj : 4);
+        y = y00 + py; x = x00 + px;
+        return (g == 0 || sx <= 1 || (sx == 2 && jj == 0)) && y >= 0 && y < Hl && x >= 0 && x < Wl;
+    };
     {
         const T *vslice = value + (((int64_t)it.b * d.S + td.lstart) * d.H + it.h) * d.D;
-        const int jj = n16 >> 2, s = n16 & 3;
-        int py[2], px[2];
-        py[0] = jj; px[0] = s;
-        py[1] = s == 0 ? jj : 4; px[1] = s == 0 ? 4 : s == 1 ? jj : 4;
-        const bool exists1 = s <= 1 || (s == 2 && jj == 0);
+        const __amdgpu_buffer_rsrc_t vrsrc =
+            make_slab_rsrc(vslice, ((int64_t)Hl * Wl * d.H * d.D - (int64_t)it.h * d.D) * (int64_t)sizeof(T));
+        const uint32_t PXB = (uint32_t)(d.H * d.D) * (uint32_t)sizeof(T);        // bytes between consecutive pixels
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int y = y00 + py[g], x = x00 + px[g];
-            const bool ok = (g == 0 || exists1) && y >= 0 && y < Hl && x >= 0 && x < Wl;
-            const T *row = vslice + (int64_t)(ok ? y * Wl + x : 0) * d.H * d.D;     // (a pixel that is not there: any row, masked)
-            const uint32_t keep = ok ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int t = 0; t < G::KT; ++t) {
-                uint4 v = *reinterpret_cast<const uint4 *>(row + (4 * t + j) * 8);
-                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
-                va[g][t] = __builtin_bit_cast(s16x8, v);
-            }
+        for (int u = 0; u < 32 / G::RPI; ++u) {
+            const int r = u * G::RPI + lane / G::LPR;
+            int y, x;
+            const bool ok = pixel_of_row(r, y, x);
+            const uint32_t chunk = (uint32_t)((lane % G::LPR) ^ G::swz(r & 15));
+            const uint32_t off = ok ? (uint32_t)(y * Wl + x) * PXB + chunk * 16u : kOobOffset;
+            ts_dma16_buf(vrsrc, off, rows + u * 1024);
         }
     }
-    // lane constants of the selection: is pixel row j / the pixel (4, j) / the pixel (4, 4) inside the map?
-    const bool row_in = y00 + j >= 0 && y00 + j < Hl;
-    const bool row4_in = y00 + 4 < Hl;
-    const bool p4j_in = row4_in && x00 + j >= 0 && x00 + j < Wl;
-    const bool p44_in = row4_in && x00 + 4 < Wl && j == 0;
+    s16x8 va[2][G::KT];                                                 // (filled in the prologue, once the rows have landed)
 
     const uint32_t HDB = (uint32_t)(d.H * d.D) * (uint32_t)sizeof(T);            // bytes between consecutive queries
     const T *gslice = grad_out + ((int64_t)it.b * d.Nq * d.H + it.h) * d.D;
@@ -256,6 +262,13 @@ __device__ __forceinline__ void taps_item(const T *__restrict__ value, const T *
         }
         pend_ok = false;
     };
+    // The step's dots leave the accumulators through LDS: lane (n, j) holds pixel row j's five dots and the fifth row's
+    // pixel (4, j) (+ (4, 4) in lane row 0) of record n -- as 8 consecutive words [8 j .. 8 j + 7] of the record's 36-word
+    // line: pixel (py < 4, px < 4) at 8 py + px, (py < 4, 4) at 8 py + 4, (4, px < 4) at 8 px + 5, (4, 4) at 6 -- and reads
+    // back ONE: the dot of corner c = j of its record's sample, wherever in the 5x5 that is.  (The first build selected in
+    // registers: 190 vector instructions per step, the kernel's bound -- profiles/r06_experiments.md.)
+    const int dot_wr = n16 * G::DOT_PITCH + j * 32;
+    const int cy = j >> 1, cx = j & 1;                              // this lane's corner of its record's sample
     auto multiply = [&](int jb, auto stage) {
         constexpr int S = decltype(stage)::value;
         const unsigned char *slot = rows + (S % 2) * G::SLOT;
@@ -270,58 +283,34 @@ __device__ __forceinline__ void taps_item(const T *__restrict__ value, const T *
             d0 = M::run(va[0][t], bf, d0);
             d1 = M::run(va[1][t], bf, d1);
         }
+        *reinterpret_cast<f32x4 *>(dots + dot_wr) = d0;
+        *reinterpret_cast<f32x4 *>(dots + dot_wr + 16) = d1;
         const float av = to_f32(__builtin_bit_cast(T, (uint16_t)(w0 >> 16)));
         const float lx = to_f32(__builtin_bit_cast(T, (uint16_t)(w1 & 0xffffu))), ly = to_f32(__builtin_bit_cast(T, (uint16_t)(w1 >> 16)));
         const float y = ly * fH - 0.5f, x = lx * fW - 0.5f;              // (the sort's expression, bit for bit)
         const float yf = floorf(y), xf = floorf(x);
         const float fy = y - yf, fx = x - xf;
-        const int iy = (int)yf - y00, ix = (int)xf - x00;                // the sample's top-left pixel inside the 5x5: 0..4
-        const float hy = 1.f - fy, hx = 1.f - fx;
-        const float r0 = d0[0], r1 = d0[1], r2 = d0[2], r3 = d0[3], r4 = d1[0], bj = d1[1], b4 = d1[2];
-#ifdef TS_EXP_NOALG
-        {
-            const uint32_t qp = w0 & 0xffffu;
-            pend_s = out_base + (int64_t)(qp >> a.qshift) * q_stride + (qp & pmask);
-            pend_ga = r0 + r1 + r2 + r3 + r4 + bj + b4 + av + lx + ly;
-            pend_gl = __float_as_uint(pend_ga);
-            pend_ok = kKS * (4 * jb + S) + n16 < cnt;
-            return;
-        }
-#endif
-        // ---- the two columns the sample straddles, of pixel row j (a corner outside the map reads 0: cuh:58-81)
-        const bool x0 = ix == 0, x1 = ix == 1, x2 = ix == 2, x3 = ix == 3, x4 = ix == 4;
-        float e0v = sel(x0, r0, sel(x1, r1, sel(x2, r2, sel(x3, r3, r4))));
-        float e1v = sel(x0, r1, sel(x1, r2, sel(x2, r3, r4)));
-        e0v = sel(xf >= 0.f, e0v, 0.f);
-        e1v = sel((xf + 1.f < fW) & !x4, e1v, 0.f);
-        const float hrow = hx * e0v + fx * e1v, drow = e1v - e0v;
-        const bool top = row_in & (iy == j), bot = row_in & (iy + 1 == j);
-        const float wrow = sel(top, hy, sel(bot, fy, 0.f));               // this pixel row's weight along y, or none
-        float ga = sel(top | bot, wrow * hrow, 0.f);
-        float gx = sel(top | bot, wrow * drow, 0.f);
-        float gy = sel(top, -hrow, sel(bot, hrow, 0.f));
-        // ---- the 5x5's fifth row: pixel (4, j) in every lane row, pixel (4, 4) in lane row 0
-        {
-            const bool cl = p4j_in & (ix == j), cr = p4j_in & (ix + 1 == j);
-            const bool dl = p44_in & x4, dr = p44_in & x3;
-            const float t = sel(cl, hx * bj, sel(cr, fx * bj, 0.f)) + sel(dl, hx * b4, sel(dr, fx * b4, 0.f));
-            const float u = sel(cl, -bj, sel(cr, bj, 0.f)) + sel(dl, -b4, sel(dr, b4, 0.f));
-            const bool t4 = iy == 4, b3 = iy == 3;
-            const float w4 = sel(t4, hy, sel(b3, fy, 0.f));
-            ga += sel(t4 | b3, w4 * t, 0.f);
-            gx += sel(t4 | b3, w4 * u, 0.f);
-            gy += sel(t4, -t, sel(b3, t, 0.f));
-        }
+        const int y0 = (int)yf + cy, x0 = (int)xf + cx;                  // this corner's pixel in the map ...
+        const int py = y0 - y00, px = x0 - x00;                          // ... and in the 5x5: 0 .. 5 (5: past the map's last row / column)
+        // a corner outside the map reads 0 (cuh:58-81); inside the map it is inside the 5x5 (the block owns the sample)
+        const bool in_map = (y0 >= 0) & (y0 < Hl) & (x0 >= 0) & (x0 < Wl);
+        const int w_in = py * 8 + px, w_row4 = px * 8 + 5;
+        int word = sel_i(py < 4, sel_i(px < 4, w_in, py * 8 + 4), sel_i(px < 4, w_row4, 6));
+        word = sel_i(in_map, word, 0);
+        const float dot_raw = *reinterpret_cast<const float *>(dots + n16 * G::DOT_PITCH + word * 4);
+        const float dot = sel(in_map, dot_raw, 0.f);
+        // ---- this corner's share (cuh:119-161): w = wy wx;  d/dx: wy (+-1);  d/dy: (+-1) wx
+        const float wy = sel(cy != 0, fy, 1.f - fy), wx = sel(cx != 0, fx, 1.f - fx);
+        const float wyd = wy * dot, wxd = wx * dot;
+        float ga = wx * wyd;
+        float gx = sel(cx != 0, wyd, -wyd);
+        float gy = sel(cy != 0, wxd, -wxd);
         ga = add_rows32(add_rows16(ga));
         gx = add_rows32(add_rows16(gx));
         gy = add_rows32(add_rows16(gy));
         // ---- out by sample index (stored by the next step)
         const uint32_t qp = w0 & 0xffffu;
-#ifdef TS_EXP_LINSTORE
-        pend_s = (int64_t)(td.first[0] + e0 + kKS * (4 * jb + S) + n16) + 0 * (int64_t)(qp + pmask);
-#else
         pend_s = out_base + (int64_t)(qp >> a.qshift) * q_stride + (qp & pmask);
-#endif
         pend_ga = ga;
         pend_gl = M::pack2(fW * av * gx, fH * av * gy);
         pend_ok = kKS * (4 * jb + S) + n16 < cnt;
@@ -331,9 +320,23 @@ __device__ __forceinline__ void taps_item(const T *__restrict__ value, const T *
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
 
-    // prologue: recs(0) | rows(0)
+    // prologue: value rows + recs(0) | operands out of LDS | rows(0)
     issue_records(0);
     MMFS_TS_WAIT_VM(0);
+    {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            int y, x;
+            const uint32_t keep = pixel_of_row(16 * g + n16, y, x) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int t = 0; t < G::KT; ++t) {
+                uint4 v = *reinterpret_cast<const uint4 *>(rows + g * 16 * G::RB + b_rd[t]);
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                va[g][t] = __builtin_bit_cast(s16x8, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the operands are in registers before the slots are written again)
+    }
     issue_rows(0, S0{});
     // (vmcnt counts the stores too, in issue order: a wait that lets the n newest requests stand assumes the stores of the
     // step before are among them -- when a step had none, the wait is merely stricter than needed)
