@@ -77,7 +77,10 @@ def test_forward_formulations_repeat_bit_for_bit_at_full_size(algo, cfg, dtype):
     assert _rel(first, ref) <= 0.5 * BAR[dtype], f"{algo}: whole tensor vs the row gather {_rel(first, ref):.3e}"
 
 
-BWD_CASES = [("lds", NORTH_STAR), ("auto", NORTH_STAR), ("auto", SD_BLOCK), ("auto", LLM_N1)]
+# ("sorted": round 6, csrc/msda_bwd_taps_sorted.hip -- grad_loc / grad_attn from the grad_value sort's records; the route needs
+# a level table the host has verified: the case registers its tables.  A sample's sums do not depend on where the sort put its
+# record: bit-equal run to run although the record order is not)
+BWD_CASES = [("lds", NORTH_STAR), ("auto", NORTH_STAR), ("auto", SD_BLOCK), ("auto", LLM_N1), ("sorted", NORTH_STAR), ("sorted", LLM_N4)]
 
 
 @pytest.mark.parametrize("algo,cfg", BWD_CASES, ids=[f"{a}-B{c[0]}Nq{c[1]}H{c[2]}D{c[3]}P{c[4]}n{c[6]}" for a, c in BWD_CASES])
@@ -88,6 +91,8 @@ def test_backward_formulations_repeat_bit_for_bit_at_full_size(algo, cfg, dtype)
     against the row-gather taps kernel and the float-atomic scatter (fp32 sums in another order)."""
     import MultiScaleDeformableAttention as MSDA
     value, sh, st, loc, attn, grad = _inputs(cfg, dtype, seed=1)
+    if algo == "sorted":
+        assert MSDA.register_level_tables(sh, st, value.shape[1])[0]
     runs = RUNS // 2
     old, old_b = MSDA._taps_algo, MSDA._bwd_algo
     try:
