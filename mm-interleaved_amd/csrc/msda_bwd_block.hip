@@ -266,16 +266,17 @@ constexpr bool kWindowRounds = MMFS_SORT_WINDOW_ROUNDS != 0;       // a kept sca
 constexpr uint32_t kNoCell = 0xffffffffu;
 constexpr int kCellBits = 13;
 static_assert(kMaxTileCells <= (1 << kCellBits), "a cell index and a rank share one word");
-template <typename T, int NV, bool COMPACT, int THREADS, bool TS>
+template <typename T, int NV, bool COMPACT, int THREADS, bool TS, int UNROLL = kScanUnroll>
 struct KeptScan {
     typedef Vec16<T> V;
     static constexpr int VEC = V::N, SPV = V::N / 2;
-    uint4 lraw[kScanUnroll][NV];
-    uint2 araw[kScanUnroll][NV];
-    uint32_t key[kScanUnroll][NV][SPV];
+    uint4 lraw[UNROLL][NV];
+    uint2 araw[UNROLL][NV];
+    uint32_t key[UNROLL][NV][SPV];
     // Two vectors per query (P = 8 of 16-bit storage): the samples' words AND their keys do not fit the 128
-    // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits).
-    static constexpr bool kKeepRaw = NV == 1;
+    // registers a 1024-thread workgroup leaves a thread; the placing pass then reads the words again (L2 hits) -- unless
+    // the workgroup is 512 threads with twice the samples each (UNROLL = 8: 256 registers a thread; round 6, r06v)
+    static constexpr bool kKeepRaw = NV == 1 || THREADS <= 512;
     // G > 1: a query's samples span G * NV vectors (many points per query: the reference's own speed test has 64);
     // "virtual query" tid + u * THREADS then stands for vectors (qv % G) * NV .. + NV of query qv / G
     int G = 1;
@@ -289,7 +290,7 @@ struct KeptScan {
     {
         const int64_t s_first = ((((int64_t)b * d.H + h) * d.L + tl.level) * d.Nq) * d.P;
 #pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             const int qv = min((int)threadIdx.x + u * THREADS, d.Nq * G - 1);
             const int qq = G == 1 ? qv : qv / G;
             const int v0 = (qv - qq * G) * NV;
@@ -313,7 +314,7 @@ struct KeptScan {
         const bool keep_zero = TS && !d.lazy_attn;
         const bool zero_writer = TS && g_loc != nullptr && tl.ya == 0 && tl.xa == 0;
 #pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             const int q = (int)threadIdx.x + u * THREADS;                // (virtual query)
             const int qq = G == 1 ? q : q / G;
 #pragma unroll
@@ -346,7 +347,7 @@ struct KeptScan {
         if (!kKeepRaw && reload) load(loc, attn, d, tl, b, h, in_place);
         constexpr bool ts = COMPACT && TS;
 #pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             const uint32_t qv = threadIdx.x + u * THREADS;
             const uint32_t qq = G == 1 ? qv : qv / (uint32_t)G;
             // the record carries the query -- or (taps_sorted) query * P + point: the sample's place in grad_loc / grad_attn
@@ -409,7 +410,7 @@ namespace {
 // the chain of dependent round trips a tile is (header, samples, counters, the level's cursor, records) overlaps with
 // three other tiles' -- at the ViT-Adapter injector's shape (512 slices x 3 levels of ~1000 samples) a 1024-lane
 // workgroup spends 7 us on a tile whatever its size, six rounds of them (tools/sort_prof.py injector, r04zw)
-template <typename T, int NV, bool COMPACT, int THREADS, bool TS>
+template <typename T, int NV, bool COMPACT, int THREADS, bool TS, int UNROLL = kScanUnroll>
 __global__ void __launch_bounds__(THREADS)
 msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
                    uint32_t *__restrict__ level_cursor, uint2 *__restrict__ celltab,
@@ -457,8 +458,8 @@ msda_bwd_cell_sort(const T *loc, const T *attn, uint4 *__restrict__ records,
     constexpr int KNV = NV > 0 ? NV : 1;
     // (only where the launch expects windows: into memory, the two-scan path's stores are the faster -- SD 512 px
     // geometry, 32768 samples per level: 151 us against 196)
-    const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= THREADS * kScanUnroll && win_bytes > kMaxTileCells * 4u;
-    KeptScan<T, KNV, COMPACT, THREADS, TS> ks;
+    const bool kept = NV > 0 && (int64_t)d.Nq * tp.vgroups <= THREADS * UNROLL && win_bytes > kMaxTileCells * 4u;
+    KeptScan<T, KNV, COMPACT, THREADS, TS, UNROLL> ks;
     ks.G = tp.vgroups;
 
     // (the sort reads the op's own loc / attn when the opening launch said so: nothing was re-packed then)
@@ -1236,11 +1237,33 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
                            (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
                            cell_stride_of(d), win, ta);
     };
+    // Two vectors of locations per query (P = 8 of 16-bit storage: the decoders' geometry) in a 1024-lane workgroup: the
+    // samples' words do not fit next to their keys, so every placing pass reads loc / attn AGAIN -- and a tile of more
+    // records than the window holds (the SD block: 32 768 samples per level) places in two passes: three reads of the
+    // level's words in all (641 MB of traffic for 101 MB of input).  512 lanes with eight samples each keep the
+    // words in registers (256 a lane): one read.  MMFS_SORT_WIDE=0: the 1024-lane kernel
+    auto go_wide = [&](auto tag_ts) {
+        constexpr bool TS = decltype(tag_ts)::value && NV > 0;
+        constexpr int THREADS = kMidThreads, UNROLL = 2 * kScanUnroll;
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_cell_sort<T, NV, true, THREADS, TS, UNROLL>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSortWindow);
+        (void)once;
+        hipLaunchKernelGGL((msda_bwd_cell_sort<T, NV, true, THREADS, TS, UNROLL>), dim3((unsigned)blocks), dim3(THREADS), win, st,
+                           (const T *)sc.loc_t, (const T *)sc.attn_t, sc.records, sc.cursor, sc.celltab, sc.hdr, d, tp,
+                           cell_stride_of(d), win, ta);
+    };
     auto go = [&](auto tag_compact, auto tag_threads) {
         if (d.taps_sorted) go_ts(tag_compact, tag_threads, std::true_type());
         else go_ts(tag_compact, tag_threads, std::false_type());
     };
     const int lanes = sort_lanes(d, vgroups, NV);
+    if constexpr (NV == 2 && sizeof(T) == 2) {
+        const char *e = knob_str(K_SORT_WIDE);
+        if (compact && lanes == kThreads && !(e && e[0] == '0')) {
+            if (d.taps_sorted) go_wide(std::true_type()); else go_wide(std::false_type());
+            return hipGetLastError();
+        }
+    }
     typedef std::integral_constant<bool, sizeof(T) == 2> Compact;
     typedef std::integral_constant<bool, false> Wide;
     typedef std::integral_constant<int, kThreads> Big;

@@ -11,7 +11,7 @@ enum Knob {
     K_FWD_ALGO, K_FWD_MMA_LDS_KB, K_FWD_MMA_QPW, K_FWD_Q8_LDS_KB, K_FWD_Q8_QPR, K_FWD_WQ_LDS_KB, K_FWD_WQ_QPW,
     K_TAPS_ALGO, K_TAPS_MMA_QPW, K_MMA_GRID, K_MMA_PERSIST, K_HYBRID, K_DOT_CHUNKS,
     K_VALUE_ALGO, K_PREPARE_IN_TAPS,
-    K_NT_MIN, K_SORT_WINDOW_KB, K_SORT_ROUNDS, K_SORT_SMALL, K_SORT_MANY_POINTS, K_SORT_HGROUP, K_SORT_REPACK,
+    K_NT_MIN, K_SORT_WINDOW_KB, K_SORT_ROUNDS, K_SORT_SMALL, K_SORT_MANY_POINTS, K_SORT_HGROUP, K_SORT_REPACK, K_SORT_WIDE,
     K_SAMPLE_DECODE, K_LIN_ROWS, K_LIN_UNROLL, K_LIN_EARLY, K_QUERY_LDS_KB, K_NORM_BWD_GRID,
     K_COUNT
 };
