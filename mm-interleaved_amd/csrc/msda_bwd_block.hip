@@ -1257,9 +1257,10 @@ hipError_t launch_sort(const int64_t *shapes, const int64_t *start, const Scratc
         else go_ts(tag_compact, tag_threads, std::false_type());
     };
     const int lanes = sort_lanes(d, vgroups, NV);
-    if constexpr (NV == 2 && sizeof(T) == 2) {
+    if constexpr ((NV == 2 || NV == 1) && sizeof(T) == 2) {
         const char *e = knob_str(K_SORT_WIDE);
-        if (compact && lanes == kThreads && !(e && e[0] == '0')) {
+        // (one-vector queries -- P = 4: the north star -- only when asked, "2": measured in r06x)
+        if (compact && lanes == kThreads && !(e && e[0] == '0') && (NV == 2 || (e && e[0] == '2'))) {
             if (d.taps_sorted) go_wide(std::true_type()); else go_wide(std::false_type());
             return hipGetLastError();
         }

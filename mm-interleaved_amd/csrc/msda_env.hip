@@ -32,7 +32,7 @@ const KnobInfo kKnobs[K_COUNT] = {
     {"MMFS_SORT_MANY_POINTS", "0: no grouped scan for more than two 16-byte vectors of locations per query"},
     {"MMFS_SORT_HGROUP", "cell sort: heads that share a workgroup's sector reads"},
     {"MMFS_SORT_REPACK", "1: re-pack loc / attn level-major before the sort even where it could read them in place"},
-    {"MMFS_SORT_WIDE", "0: two-vector queries (P = 8, 16-bit) on the 1024-lane sort instead of 512 lanes with eight samples each"},
+    {"MMFS_SORT_WIDE", "0: two-vector queries (P = 8, 16-bit) on the 1024-lane sort instead of 512 lanes with eight samples each; 2: one-vector queries on 512 lanes too (measured slower, r06x)"},
     {"MMFS_SAMPLE_DECODE", "0: decode-sized fused-sampler calls on the in-order kernel"},
     {"MMFS_LIN_ROWS", "mmfs_linear_small: token rows per wave (1 | 2)"},
     {"MMFS_LIN_UNROLL", "mmfs_linear_small: weight pieces in flight (4 | 8)"},
