@@ -463,8 +463,14 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
 #ifndef Q8_BUILTIN_MFMA
                 Q8Mma<T>::run2(A, Bv[u][0], Bv[u][1], acc[0], acc[1]);
 #else
+#ifdef Q8_EXP_PRE                                                        // (experiment r06: wait states between whatever wrote the operands and the product)
+                asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+#endif
 #pragma unroll
                 for (int g = 0; g < 2; ++g) acc[g] = M::run(A, Bv[u][g], acc[g]);
+#ifdef Q8_EXP_POST                                                       // (experiment r06: ... and between the products and whatever reads their results)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+#endif
 #endif
             }
         };
