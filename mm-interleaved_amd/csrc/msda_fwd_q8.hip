@@ -67,6 +67,13 @@ __device__ unsigned long long g_q8_prof[kQProfSlots * 8];
 #endif
 
 
+// Development aid (tools/debug/q8_probe.py; -DQ8_PROBE): at the end of a pass's staging every lane reads back what it stored for
+// corner 2 of its sample and compares it with the weight recomputed from copies of its factors; mismatches are logged.
+#ifdef Q8_PROBE
+__device__ unsigned int g_q8_probe_n;
+__device__ unsigned int g_q8_probe[4096 * 8];
+#endif
+
 // The tile's products as inline assembly, accumulating IN PLACE, fenced by wait states on both sides.
 // With the builtin, and >= 5 busy waves per CU, the accumulator rows of lanes 48 .. 63 (queries 6 and 7 of a tile) came out
 // wrong now and then -- never with one or two waves, never with one K-block per sequence (profiles/r04_experiments.md
@@ -339,6 +346,9 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         for (int i = 0; i < 8; ++i) accv[i] = 0.f;
         bool any_gather = false;
         for (int pass = 0; pass < n_pass; ++pass) {
+#ifdef Q8_PROBE
+        float pr_fy = 0.f, pr_gx = 0.f, pr_aa = 0.f, pr_w2 = 0.f, pr_t0 = 0.f, pr_t1 = 0.f, pr_u1 = 0.f;
+#endif
         uint4 st_a, st_b;
         // ---- stage: one sample per lane (its words arrived during the previous pass); what the sample's level is
         // comes out of a per-sample-index table (made once per workgroup: no division, one 16-byte read)
@@ -367,9 +377,60 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
             const float fy = on ? y - yf : 0.f, fx = on ? x - xf : 0.f;
             const float gy = 1.f - fy, gx = 1.f - fx;
             const float aa = on ? a : 0.f;
+#ifdef Q8_EXP_NOPK                                                       // (experiment r06: no packed fp32 multiplies in the weights)
+            float t0 = gy * gx, t1 = gy * fx, t2 = fy * gx, t3 = fy * fx;
+            asm volatile("" : "+v"(t0)); asm volatile("" : "+v"(t1)); asm volatile("" : "+v"(t2)); asm volatile("" : "+v"(t3));
+            float u0 = t0 * aa, u1 = t1 * aa, u2 = t2 * aa, u3 = t3 * aa;
+            asm volatile("" : "+v"(u0)); asm volatile("" : "+v"(u1)); asm volatile("" : "+v"(u2)); asm volatile("" : "+v"(u3));
+            const float w[4] = {u0, u1, u2, u3};
+#elif defined(Q8_EXP_PK1)                                                // (only the first packed multiply survives)
+            float t1 = gy * fx, t2 = fy * gx;
+            asm volatile("" : "+v"(t1), "+v"(t2));
+            float u1 = t1 * aa;
+            asm volatile("" : "+v"(u1));
+            float u2 = t2 * aa;
+            asm volatile("" : "+v"(u2));
+            const float w[4] = {gy * gx * aa, u1, u2, fy * fx * aa};
+#elif defined(Q8_EXP_PKNOP)                                              // (both packed multiplies, wait states between them)
+            float t1 = gy * fx, t2 = fy * gx;
+            asm volatile("s_nop 7" : "+v"(t1), "+v"(t2));
+            const float w[4] = {gy * gx * aa, t1 * aa, t2 * aa, fy * fx * aa};
+#elif defined(Q8_EXP_PKASM)                                              // (the two packed multiplies spelled out; Q8_EXP_PKASM = wait states between them, 0 = none)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 fr = {fy, fx}, gr = {gy, gx}, ar = {aa, aa}, tt, uu;
+#if Q8_EXP_PKASM == 0
+            asm volatile("v_pk_mul_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %4, %0 op_sel_hi:[0,1]"
+                         : "=&v"(tt), "=&v"(uu) : "v"(fr), "v"(gr), "v"(ar));
+#elif Q8_EXP_PKASM == 1
+            asm volatile("v_pk_mul_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 1\n\tv_pk_mul_f32 %1, %4, %0 op_sel_hi:[0,1]"
+                         : "=&v"(tt), "=&v"(uu) : "v"(fr), "v"(gr), "v"(ar));
+#elif Q8_EXP_PKASM == 2                                                  // (in place, as the compiler has it)
+            asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %0, %2, %0 op_sel_hi:[0,1]"
+                         : "+v"(gr) : "v"(fr), "v"(ar));
+            uu = gr;
+#else                                                                    // (in place, wait states in front, between and behind)
+            asm volatile("s_nop 3\n\tv_pk_mul_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 3\n\tv_pk_mul_f32 %0, %2, %0 op_sel_hi:[0,1]\n\ts_nop 3"
+                         : "+v"(gr) : "v"(fr), "v"(ar));
+            uu = gr;
+#endif
+            const float w[4] = {gy * gx * aa, uu[1], uu[0], fy * fx * aa};
+#elif defined(Q8_EXP_AOPAQUE)                                            // (the attention weight's conversion and test kept apart)
+            float aq = aa;
+            asm volatile("s_nop 3" : "+v"(aq));
+            const float w[4] = {gy * gx * aq, gy * fx * aq, fy * gx * aq, fy * fx * aq};
+#else
             const float w[4] = {gy * gx * aa, gy * fx * aa, fy * gx * aa, fy * fx * aa};
+#endif
             unsigned char *rec = smem + wrec + si * kRec;
             st_a = st_b = make_uint4(0u, 0u, 0u, 0u);                     // what this lane's 16-byte stores hand to the LDS
+#ifdef Q8_PROBE
+            pr_fy = fy; pr_gx = gx; pr_aa = aa;
+            asm volatile("" : "+v"(pr_fy), "+v"(pr_gx), "+v"(pr_aa));
+            pr_w2 = w[2];
+#ifdef Q8_EXP_PKASM
+            pr_t0 = tt[0]; pr_t1 = tt[1]; pr_u1 = uu[1];
+#endif
+#endif
             if (k_ok && resident) {
                 // "off": the last pixel of line -1 -- its four "corners" are that zero pixel, the border pixel (0, -1)
                 // behind it, the last (padding) pixel of line 0 and the border pixel (1, -1): zeros all
@@ -417,6 +478,38 @@ msda_fwd_q8(const T *__restrict__ value, const int64_t *__restrict__ shapes, con
         asm volatile("s_nop 15" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         keep_alive(st_a); keep_alive(st_b);                               // (the stores' registers were theirs until here)
+#endif
+#ifdef Q8_PROBE
+        if (k_ok) {
+            asm volatile("" : "+v"(pr_w2));
+            const float chk = pr_fy * pr_gx * pr_aa;
+            const unsigned char *rec = smem + wrec + si * kRec;
+            uint32_t got, want;
+            if (resident) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(rec + 32 + 16 * sj);
+                got = ((sj & 1) ? r.w : r.y) & 0xffffu;
+                uint32_t hi, lo;
+                M::split(chk, hi, lo);
+                want = hi;
+            } else {
+                const uint4 r = *reinterpret_cast<const uint4 *>(rec + 128 + 16 * sj);
+                got = r.y;
+                want = __float_as_uint(chk);
+            }
+            if (got != want) {
+                const unsigned int i = atomicAdd(&g_q8_probe_n, 1u);
+                if (i < 4096u) {
+                    unsigned int *o = g_q8_probe + 8 * i;
+                    o[0] = lane; o[1] = pass | (tile << 8) | (wave << 16) | ((resident ? 1u : 0u) << 24); o[2] = want; o[3] = got;
+                    o[4] = __float_as_uint(pr_w2);
+#ifdef Q8_EXP_PKASM
+                    o[5] = __float_as_uint(pr_t0); o[6] = __float_as_uint(pr_t1); o[7] = __float_as_uint(pr_u1);
+#else
+                    o[5] = __float_as_uint(pr_fy); o[6] = __float_as_uint(pr_gx); o[7] = __float_as_uint(pr_aa);
+#endif
+                }
+            }
+        }
 #endif
         wave_sync();
         if (pass + 1 < n_pass) prefetch(tile, pass + 1); else prefetch(tile + 1, 0);
@@ -672,6 +765,16 @@ hipError_t forward_q8(int dtype, const void *value, const int64_t *shapes, const
 }
 
 }  // namespace mmfs
+
+#ifdef Q8_PROBE
+extern "C" int mmfs_debug_q8_probe(unsigned int *out, unsigned int *n, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(n, HIP_SYMBOL(mmfs::g_q8_probe_n), sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mmfs::g_q8_probe), 4096 * 8 * sizeof(unsigned int));
+    if (e == hipSuccess && reset) { const unsigned int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(mmfs::g_q8_probe_n), &z, sizeof(z)); }
+    return (int)e;
+}
+#endif
 
 #ifdef MMFS_PROFILE_Q8
 extern "C" int mmfs_debug_q8_profile(unsigned long long *out, int reset)
