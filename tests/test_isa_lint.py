@@ -1,6 +1,10 @@
 """The built library must not contain the packed-fp32 instructions MI355X computes wrongly next to matrix products
 (v_pk_{mul,add,fma}_f32 with op_sel:[0,1,..]: tools/ubench/pk_opsel_mfma.hip, tools/fix_pk_opsel.py).  The scan runs over the
-disassembly of every code object embedded in libmmfs_msda.so -- the artefact that ships, not the intermediate files."""
+disassembly of every code object embedded in libmmfs_msda.so -- the artefact that ships, not the intermediate files.
+
+(Replaces round 5's tests/test_isa.py, which asserted three properties of msda_fwd_q8's instruction stream -- in-place inline-assembly
+products, no ds_read2_b64, wait states around every product -- that round 4 had shipped as the fix of an intermittent wrong result.
+Round 6 found the cause, profiles/r06_experiments.md r06aa: none of the three had anything to do with it.)"""
 import os
 import struct
 import subprocess

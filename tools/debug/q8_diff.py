@@ -1,4 +1,5 @@
-"""Where do repeated runs of the sliced forward differ?  (MMFS_MSDA_LIB = an experimental build, e.g. -DQ8_BUILTIN_MFMA.)
+"""Where do repeated runs of the sliced forward differ?  (MMFS_MSDA_LIB = an experimental build, e.g. the unrepaired
+kernel: RAW=1 tools/exp_build1.sh q8_raw msda_fwd_q8 "-DQ8_PROBE" -- see tools/debug/q8_probe.py.)
 Prints, for the SD block's shape in fp16 and bf16: how many elements of run i differ from run 0, the largest difference,
 the same against the row gather, and where the differing elements sit (query mod 8, channel mod 32, head, level of ... )."""
 import os, sys

@@ -1,6 +1,11 @@
-"""Reads the staging probe of a -DQ8_BUILTIN_MFMA -DQ8_PROBE build (MMFS_MSDA_LIB) after a few forwards at the image decoder's
-shape with fixed bilinear fractions: what did a lane store for corner 2 of its sample, what should it have stored, and what
-does the register that held the weight hold now?"""
+"""The sliced forward's round-4 heisenbug, caught in the act (profiles/r06_experiments.md).  Reads the staging probe of a -DQ8_PROBE
+build of msda_fwd_q8 (MMFS_MSDA_LIB) after a few forwards at the image decoder's shape with fixed bilinear fractions: what did a lane store for corner 2 of its sample, what should it have stored, and what
+does the register that held the weight hold now?
+
+    RAW=1 tools/exp_build1.sh q8_raw msda_fwd_q8 "-DQ8_PROBE"      # what hipcc alone makes of the kernel: ~14000 wrong rows per run,
+                                                                   # every logged lane in 48..63, corner 2's weight (fy * gx * a) == 0
+    tools/exp_build1.sh q8_fixed_probe msda_fwd_q8 "-DQ8_PROBE"    # the library's build (tools/fix_pk_opsel.py): 0
+    MMFS_MSDA_LIB=$PWD/mm-interleaved_amd/csrc/build/exp/q8_raw.so python tools/debug/q8_probe.py"""
 import os, sys, ctypes, struct
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mm-interleaved_amd"), os.path.join(ROOT, "tests")]
