@@ -7,7 +7,8 @@
 // (fx * gy) is right, its low result (fy * gx) is 0 in the last 16 lanes, with both operands intact before and after, wait
 // states in front / behind / between making no difference.  The bf16 kernel has no op_sel:[0,1] multiply (and never fails).
 //
-// This program: every wave alternates a burst of matrix products (form F) with a checked packed multiply.
+// This program: every wave alternates a burst of matrix products (form F; forms 5 .. 11: other things a neighbour might run)
+// with one checked packed instruction (SEL: which, with which selection).
 //   hipcc --offload-arch=gfx950 -O3 pk_opsel_mfma.hip -o /tmp/pk_opsel_mfma && /tmp/pk_opsel_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,10 +31,32 @@ __global__ void __launch_bounds__(1024) k(unsigned long long *bad, int iters, in
     u32x4 A, B;
     for (int j = 0; j < 4; ++j) { s = mix(s + j); A[j] = F16 ? 0x2c002c00u | (s & 0x03ff03ffu) : 0x3d803d80u | (s & 0x007f007fu); s = mix(s); B[j] = F16 ? 0x2c002c00u | (s & 0x03ff03ffu) : 0x3d803d80u | (s & 0x007f007fu); }
     f32x4 C = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    f32x16 C16;
+    for (int j = 0; j < 16; ++j) C16[j] = 0.f;
+    f64x4 C8 = {0., 0., 0., 0.};
+    u32x2 A2 = {A[0], A[1]}, B2 = {B[0], B[1]};
+    f32x2 P2 = {0.f, 0.f}, Q2 = {0.5f, 0.25f};
+    u32x4 L4 = {0u, 0u, 0u, 0u};
+    __shared__ __attribute__((aligned(16))) unsigned int lds_buf[4 * 1024];
+    for (int i = threadIdx.x; i < 4 * 1024; i += blockDim.x) lds_buf[i] = i;
+    __syncthreads();
+    typedef __attribute__((address_space(3))) unsigned int lds_u32;
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_u32 *)lds_buf + (threadIdx.x & 1023) * 16u;
     unsigned long long n_bad = 0, rows[4] = {0, 0, 0, 0}, zero = 0;
     for (int it = 0; it < iters; ++it) {
         const int nb = burst + ((wave + it) & 3);                                     // (the waves of a SIMD drift apart)
         for (int m = 0; m < nb; ++m) {
+            // what ELSE on the SIMD triggers it (forms 5 ..): other matrix shapes, dot products, plain and packed fp32, LDS traffic
+            if (FORM == 5) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(C16) : "v"(A), "v"(B));
+            if (FORM == 6) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(C) : "v"(A2), "v"(B2));
+            if (FORM == 7) asm volatile("v_dot2c_f32_f16 %0, %1, %2\n\tv_dot2c_f32_f16 %0, %1, %2\n\tv_dot2c_f32_f16 %0, %1, %2\n\tv_dot2c_f32_f16 %0, %1, %2" : "+v"(C[0]) : "v"(A[0]), "v"(B[0]));
+            if (FORM == 8) asm volatile("v_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %0, %1, %2, %0" : "+v"(C[0]) : "v"(C[1]), "v"(C[2]));
+            if (FORM == 9) asm volatile("v_pk_fma_f32 %0, %1, %1, %0\n\tv_pk_fma_f32 %0, %1, %1, %0\n\tv_pk_fma_f32 %0, %1, %1, %0\n\tv_pk_fma_f32 %0, %1, %1, %0" : "+v"(P2) : "v"(Q2));
+            if (FORM == 10) { asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(L4) : "v"(lds_addr)); C[3] += __uint_as_float(L4[0] & 0x3f800000u); }
+            if (FORM == 11) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(C8) : "v"(A2), "v"(B2));
             if (FORM == 4) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(C) : "v"(A), "v"(B));   // (as the shipped kernel has them)
             if (FORM == 0) {
                 if (F16 && FORM == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(C) : "v"(A), "v"(B));
@@ -93,7 +116,7 @@ __global__ void __launch_bounds__(1024) k(unsigned long long *bad, int iters, in
         if (b) { ++n_bad; ++rows[(threadIdx.x & 63) >> 4]; if (t[0] == 0.f) ++zero; }
     }
     if (n_bad) { atomicAdd(bad, n_bad); for (int j = 0; j < 4; ++j) if (rows[j]) atomicAdd(bad + 1 + j, rows[j]); atomicAdd(bad + 5, zero); }
-    if (C[0] + C[1] + C[2] + C[3] + D2[0] == 1.2345f) atomicAdd(bad + 6, 1ull);
+    if (C[0] + C[1] + C[2] + C[3] + D2[0] + C16[0] + C16[7] + (float)C8[0] + P2[0] + P2[1] == 1.2345f) atomicAdd(bad + 6, 1ull);
 }
 
 template <bool F16, int FORM, int SEL, int GAP>
@@ -145,6 +168,15 @@ int main()
     run<true, 0, 0, 1>(1024, 1, iters, burst, dbad);
     run<true, 0, 0, 4>(1024, 1, iters, burst, dbad);
     run<true, 0, 0, 16>(1024, 1, iters, burst, dbad);
+    printf("what the neighbours run (op_sel:[0,1] multiply, no gap, 16 waves per CU): 5 = v_mfma_f32_32x32x16_bf16, 6 = v_mfma_f32_4x4x4_16b_f16,\n"
+           "  7 = v_dot2c_f32_f16 x 4, 8 = v_fma_f32 x 4, 9 = v_pk_fma_f32 x 4, 10 = ds_read_b128 + wait, 11 = v_mfma_f64_16x16x4_f64\n");
+    run<true, 5, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 6, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 7, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 8, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 9, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 10, 0, 0>(1024, 1, iters, burst, dbad);
+    run<true, 11, 0, 0>(1024, 1, iters, burst, dbad);
     printf("the forms of the products\n");
     run<true, 3, 0, 0>(1024, 1, iters, burst, dbad);
     run<true, 4, 0, 0>(1024, 1, iters, burst, dbad);
